@@ -1,0 +1,127 @@
+"""Pins oracle/siegel_oracle.py (the CPU restatement) against
+  * outputs of the imported reference itself (tests/golden/*.npz, tools/make_golden.py),
+  * the known-answer vectors the reference's own tests hold (known_answers.json),
+  * the property tests of the reference: Takagi reconstruction, Cayley round trip,
+    dist symmetry, d(x,x)=0.
+CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import siegel_oracle as so
+
+torch.set_default_dtype(torch.float64)
+METRICS = ["riem", "fone", "finf", "fmin", "wsum"]
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).to(torch.float64)
+
+
+def close(a, b, rtol=1e-12, atol=1e-13):
+    return torch.allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("model", ["upper", "bounded"])
+def test_dist_matches_reference(golden_dir, model, n):
+    g = np.load(os.path.join(golden_dir, f"dist_{model}_n{n}.npz"))
+    w = T(g["wsum_weights"])
+    for case in g["case_names"]:
+        z1, z2 = T(g[f"{case}__z1"]), T(g[f"{case}__z2"])
+        for metric in METRICS:
+            got = so.manifold_dist(model, z1, z2, metric, w)
+            want = T(g[f"{case}__{metric}"])
+            # LAPACK eigh of the same matrices on the same box: agreement to rounding
+            assert close(got, want, rtol=1e-10, atol=1e-12), (model, n, case, metric,
+                                                              (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+def test_primitives_match_reference(golden_dir, n):
+    g = np.load(os.path.join(golden_dir, f"primitives_n{n}.npz"))
+    zs, anyc, nonsym = T(g["upper_pts"]), T(g["csym"]), T(g["nonsym"])
+    assert close(so.cinverse(anyc), T(g["inverse_csym"]))
+    assert close(so.cinverse(nonsym), T(g["inverse_nonsym"]))
+    realonly = anyc.clone(); realonly[:, 1] = 0
+    imagonly = anyc.clone(); imagonly[:, 0] = 0
+    assert close(so.cinverse(realonly), T(g["inverse_realonly"]))
+    assert close(so.cinverse(imagonly), T(g["inverse_imagonly"]))
+    assert close(so.matrix_sqrt(so.im(zs)), T(g["matrix_sqrt_imag"]))
+    assert close(so.cayley_transform(zs), T(g["cayley_upper"]))
+    assert close(so.inverse_cayley_transform(T(g["cayley_upper"])), T(g["inverse_cayley_of_cayley"]))
+    assert close(so.cmatmul(anyc, nonsym), T(g["bmm"]))
+    assert close(so.cmatmul3(anyc, nonsym, anyc), T(g["bmm3"]))
+    assert torch.equal(so.compound_symmetric(anyc), T(g["compound"]))
+    assert close(so.takagi_values(anyc), T(g["takagi_values"]))
+    vals, s = so.takagi_factorize(anyc)
+    diag = torch.diag_embed(vals)
+    diag = so.pack(diag, torch.zeros_like(diag))
+    rec = so.cmatmul3(so.conjugate(s), diag, so.conj_trans(s))
+    assert close(rec, T(g["takagi_reconstruction"]), rtol=1e-9, atol=1e-11)
+    assert close(rec, anyc, rtol=1e-9, atol=1e-11)        # test_takagi_factorization.py:15-125
+    proj, keep = so.positive_conjugate_projection(T(g["pcp_in"]))
+    assert close(proj, T(g["pcp_out"]))
+    assert torch.equal(keep, torch.from_numpy(g["pcp_keep"]))
+    u = T(g["grad_in"])
+    assert close(so.upper_egrad2rgrad(zs, u), T(g["upper_egrad2rgrad"]))
+    assert close(so.bounded_egrad2rgrad(T(g["cayley_upper"]), u), T(g["bounded_egrad2rgrad"]))
+    assert close(so.upper_projx(T(g["projx_in"]))[0], T(g["upper_projx"]))
+    assert close(so.bounded_projx(T(g["bounded_projx_in"]))[0], T(g["bounded_projx"]), rtol=1e-9, atol=1e-11)
+
+
+def test_known_answer_vectors_of_reference_tests(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))
+
+    def c(x):
+        return T(x).unsqueeze(0)
+
+    assert close(so.cmatmul(c(ka["bmm"]["x"]), c(ka["bmm"]["y"])), c(ka["bmm"]["expected"]), 1e-5, 1e-8)
+    e = ka["bmm3"]
+    assert close(so.cmatmul3(c(e["x"]), c(e["y"]), c(e["z"])), c(e["expected"]), 1e-5, 1e-8)
+    for k in ("inverse_symmetric_2d", "inverse_symmetric_3d", "inverse_nonsymmetric_3d"):
+        # reference builds these with torch.Tensor == float32 literals under default fp64 -> rtol 1e-5
+        assert close(so.cinverse(c(ka[k]["x"])), c(ka[k]["expected"]), 1e-5, 1e-8), k
+    e = ka["pcp_positive"]
+    assert close(so.positive_conjugate_projection(c(e["x"]))[0], c(e["expected"]), 1e-5, 1e-8)
+    e = ka["pcp_negative"]
+    assert close(so.positive_conjugate_projection(c(e["x"]))[0], c(e["expected"]), 1e-4, 1e-8)
+    e = ka["matrix_sqrt_4d"]
+    assert close(so.matrix_sqrt(c(e["x"])), c(e["expected"]), 1e-5, 1e-6)
+
+
+def test_model_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "model_forward.npz"))
+    trip = torch.from_numpy(g["triplets"])
+    for scale, coef in ((1.0, 1.0), (0.05, 1.0), (3.0, 2.0)):
+        for model in ("upper", "bounded"):
+            got = so.model_forward(T(g[f"table_{model}"]), trip, model, "riem",
+                                   scale=torch.tensor([scale]), scale_coef=coef)
+            assert close(got, T(g[f"{model}__scale{scale}_coef{coef}"]), 1e-10, 1e-12)
+
+
+@pytest.mark.parametrize("model", ["upper", "bounded"])
+def test_reference_property_tests(model):
+    """tests/test_upper_half.py:109-186, tests/test_bounded_domain.py:95-127,
+    tests/test_cayley_transform.py:18-74 restated on the oracle."""
+    g = torch.Generator().manual_seed(42)
+    x = so.upper_random(10, 3, generator=g)
+    y = so.upper_random(10, 3, generator=g)
+    back = so.inverse_cayley_transform(so.cayley_transform(x))
+    assert close(back, x, 1e-5, 1e-8)
+    if model == "bounded":
+        x, y = so.cayley_transform(x), so.cayley_transform(y)
+    dxy = so.manifold_dist(model, x, y)
+    dyx = so.manifold_dist(model, y, x)
+    assert close(dxy, dyx, 1e-5, 1e-8)
+    dxx = so.manifold_dist(model, x, x)
+    assert close(dxx, torch.zeros_like(dxx), 1e-5, 1e-8)
+
+
+def test_loss_formula():
+    gd = torch.tensor([1.0, 2.0, 4.0])
+    md = torch.tensor([1.5, 2.0, 2.0])
+    assert float(so.distortion_loss(gd, md)) == pytest.approx(abs(1.5 ** 2 - 1) + 0 + abs(0.25 - 1))
