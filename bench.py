@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- pairwise Siegel distances/sec on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path (fused Model.forward: gather + distance + metric + scale,
+C-ABI `sympa_model_forward`) over one batch of synthetic pairs, inputs already resident in HBM.
+Default workload: upper / riem / n=4, batch 65 536 pairs per GPU, table of 5 041 nodes
+(the configuration the headline target is quoted on).  Weak scaling: every rank
+processes its own 65 536-pair shard of a (65 536 x N)-pair global batch (DistributedSampler-style
+interleave rank::N), table replicated, NO data-path collective.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 7 for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (model, metric, dims, nodes, batch per GPU)  -- BASELINE.json configs
+    "upper-riem-n4-b65536": ("upper", "riem", 4, 5041, 65536),     # headline
+    "tree-upper-riem-n4-b8192": ("upper", "riem", 4, 1093, 8192),  # configs[1]
+    "grid-upper-riem-n2-b512": ("upper", "riem", 2, 125, 512),     # configs[0]
+    "margulis-bounded-finf-n4-b65536": ("bounded", "finf", 4, 5041, 65536),  # configs[2]
+    "cartesian-upper-riem-n8-b262144": ("upper", "riem", 8, 45500, 262144),  # configs[3], per-GPU shard 32768 at 8 GPUs
+}
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # AMD datasheet (vector fp64); reported as the honest second roof
+
+
+def algorithmic_bytes_per_pair(n):
+    """2 int64 indices + two fp64 [2,n,n] points + one fp64 output, no reuse credit."""
+    return 2 * 8 + 2 * (2 * n * n * 8) + 8
+
+
+def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
+    """Oracle (op-for-op torch-CPU fp64 restatement of the reference) timed on the host cores."""
+    import torch
+    from oracle import siegel_oracle as so
+    from sympa_amd import data
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    table = data.trained_like_table(nodes, n, model=model, seed=seed)
+    pairs = data.sample_pairs(nodes, batch, 0, seed)
+    with torch.no_grad():
+        so.model_forward(table, pairs[: min(batch, 4096)], model, metric)     # warm
+        done, t0 = 0, time.perf_counter()
+        iters = 0
+        while True:
+            so.model_forward(table, pairs, model, metric)
+            done += batch
+            iters += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or iters >= 50:
+                break
+    return {"value": done / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} x batch {batch} of the same workload, oracle/siegel_oracle.py model_forward, "
+                      f"{el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="upper-riem-n4-b65536", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step")
+    ap.add_argument("--table", default="trained", choices=["trained", "init"])
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-batches", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sympa_amd import _lib, data, ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    _lib.load()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    model, metric, n, nodes, batch = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    table_cpu = (data.trained_like_table(nodes, n, model=model, seed=args.seed) if args.table == "trained"
+                 else data.init_table(nodes, n, seed=args.seed))
+    if args.table == "init" and model == "bounded":
+        raise SystemExit("init table is defined for the upper model")
+    table = table_cpu.to(dev)
+    scale = torch.ones(1, dtype=torch.float64, device=dev)
+    # global batch j has batch*world pairs; this rank takes the interleave rank::world (weak scaling)
+    nb = max(1, min(args.distinct_batches, args.steps))
+    batches = []
+    for j in range(nb):
+        glob = data.sample_pairs(nodes, batch * world, j, args.seed)
+        batches.append(glob[rank::world].contiguous().to(dev))
+    out = torch.empty(batch, dtype=torch.float64, device=dev)
+
+    def step(i):
+        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=out)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ops.check_status(dev)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration, HIP events on the launch stream (torch's current stream), same launches
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for i in range(args.steps):
+        ev[i][0].record()
+        step(i)
+        ev[i][1].record()
+    torch.cuda.synchronize(dev)
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    kernel_med_ms = kernel_ms[len(kernel_ms) // 2]
+
+    checksum = float(out.sum().item())
+    assert checksum == checksum and checksum > 0, "bench produced non-finite distances"
+
+    if rank == 0:
+        pairs_total = batch * world * args.steps
+        value = pairs_total / elapsed
+        bpp = algorithmic_bytes_per_pair(n)
+        achieved = bpp * batch / (kernel_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        rec = {
+            "metric": "pairwise Siegel distances/sec (upper, riem, n=4)" if args.workload == "upper-riem-n4-b65536"
+                      else f"pairwise Siegel distances/sec ({model}, {metric}, n={n})",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "model": None, "manifold": model, "dist_metric": metric,
+                       "dims": n, "nodes": nodes, "pairs_per_gpu_per_step": batch,
+                       "global_pairs_per_step": batch * world, "table": args.table,
+                       "parallelism": f"pairs sharded rank::{world}, table replicated, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "siegel_dist_kernel", "kernel_avg_us": kernel_avg_ms * 1e3,
+                         "kernel_median_us": kernel_med_ms * 1e3,
+                         "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": batch,
+                         "pairs_per_s_kernel_only": batch / (kernel_avg_ms * 1e-3)},
+        }
+        del rec["config"]["model"]
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, batch, args.seed)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+/* sympa_hip.h -- C-ABI of the MI355X (gfx950) Siegel-distance library  (libsympa_hip.so)
+ *
+ * The reference (fedelopez77/sympa) is pure Python/torch and has no FFI layer; its drop-in boundary
+ * for this path is the Python API  Model.forward -> manifold.dist  (SURVEY.md section 8b).  These
+ * entry points are what a binding for that path binds: one call per reference method, plain
+ * pointers and sizes, no torch types.  Each entry cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; the caller owns all buffers,
+ *     the library allocates nothing and keeps no mutable global state (re-entrant);
+ *   - a point is [2, n, n] fp64 row-major, plane 0 = Re, plane 1 = Im (sympa/math/csym_math.py:1-8);
+ *     only the upper triangle (i <= j) of each plane is read (points on the manifold are symmetric);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and the
+ *     call returns without synchronising; it is safe to capture into a hipGraph;
+ *   - return value: 0 = enqueued, <0 = argument error (SYMPA_ERR_*), >0 = hipError_t of the launch;
+ *     sympa_last_error() gives a thread-local message;
+ *   - numeric-range violations the reference reports with `assert` (siegel_manifold.py:64-66) or a
+ *     Python IndexError are reported through `status` (device int32[2], may be NULL):
+ *         status[0] |= SYMPA_ST_* bits,   status[1] += number of offending pairs.
+ *     The caller zeroes it and reads it back lazily (no host sync inside the library).
+ */
+#ifndef SYMPA_HIP_H
+#define SYMPA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* models: ManifoldFactory.sympa_manifolds keys (sympa/embeddings.py:145-149) */
+#define SYMPA_MODEL_UPPER 0   /* UpperHalfManifold   sympa/manifolds/upper_half.py:8 */
+#define SYMPA_MODEL_BOUNDED 1 /* BoundedDomainManifold sympa/manifolds/bounded_domain.py:10 */
+
+/* metrics: MetricType values (sympa/manifolds/metrics.py:6-12) */
+#define SYMPA_METRIC_RIEM 0
+#define SYMPA_METRIC_FONE 1
+#define SYMPA_METRIC_FINF 2
+#define SYMPA_METRIC_FMIN 3
+#define SYMPA_METRIC_WSUM 4
+
+#define SYMPA_ST_NOT_PD 1         /* Im(z) (upper) or I - z z^H (bounded) not positive definite */
+#define SYMPA_ST_NONFINITE 2      /* result is NaN/Inf */
+#define SYMPA_ST_BAD_INDEX 4      /* gather index outside [0, num_rows) (reference: IndexError) */
+#define SYMPA_ST_NO_CONVERGENCE 8 /* eigenvalue iteration hit its sweep cap */
+
+#define SYMPA_ERR_BAD_ARG (-1)
+#define SYMPA_ERR_UNSUPPORTED_DIMS (-2)
+
+#define SYMPA_MAX_DIMS 8 /* largest n with a register-resident kernel in this build */
+
+/* Library / build identification. */
+const char* sympa_version(void);
+const char* sympa_last_error(void);
+int sympa_max_dims(void);
+
+/* manifold.dist(z1, z2) for pre-gathered points.
+ * Replaces SiegelManifold.dist (sympa/manifolds/siegel_manifold.py:41-72) for model = UPPER and
+ * BoundedDomainManifold.dist (sympa/manifolds/bounded_domain.py:27-39) for model = BOUNDED,
+ * including Metric.compute_metric (sympa/manifolds/metrics.py:42-121).
+ *   z1, z2    [b, 2, n, n] fp64 contiguous
+ *   metric_w  [n] fp64, the wsum weights (metrics.py:103-108); may be NULL unless metric = WSUM
+ *   eps       clamp of (1 - d), reference EPS[float64] = 1e-5 (sympa/config.py:19)
+ *   out       [b] fp64 distances
+ *   vvd_out   [b, n] fp64 ascending vector-valued distance v (siegel_manifold.py:69-70), or NULL
+ */
+int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
+                          const double* metric_w, double eps, double* out, double* vvd_out, int32_t* status,
+                          void* stream);
+
+/* Model.forward(input_triplet) fused: gather two table rows per pair, distance, times the scale.
+ * Replaces Model.forward / Model.distance / Model.get_scale (sympa/model.py:16-41) and
+ * Embeddings.forward (sympa/embeddings.py:29-34).
+ *   table      [num_rows, 2, n, n] fp64 (the ManifoldParameter, embeddings.py:27,68)
+ *   src, dst   int64 node ids, element i at src[i * src_stride] (so input_triplet[:, 0] / [:, 1] of a
+ *              [b, 2|3] int64 tensor are passed without a copy: stride 2 or 3)
+ *   scale      device pointer to the model's scale parameter (1 fp64) or NULL for 1.0;
+ *              out = dist * max(scale / scale_coef, 0.1)          (model.py:40-41)
+ */
+int sympa_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                        const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
+                        const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
+                        int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYMPA_HIP_H */

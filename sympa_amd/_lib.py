@@ -1,0 +1,67 @@
+"""ctypes binding of the C-ABI in include/sympa_hip.h.
+
+The product path has NO fallback: if libsympa_hip.so is missing or does not export a declared
+symbol, importing/using the ops raises.  (Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C sympa_amd/csrc`.)"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsympa_hip.so")
+
+# every symbol include/sympa_hip.h declares (tests check the header against this list)
+SYMBOLS = (
+    "sympa_version",
+    "sympa_last_error",
+    "sympa_max_dims",
+    "sympa_siegel_dist_fwd",
+    "sympa_model_forward",
+)
+
+_c_double_p = ctypes.c_void_p
+_c_i64_p = ctypes.c_void_p
+_c_i32_p = ctypes.c_void_p
+
+_lib = None
+
+
+class SympaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libsympa_hip.so once and sets the prototypes.  Raises SympaHipError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SympaHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; "
+            "run __graft_entry__.build() (hipcc --offload-arch=gfx950)."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise SympaHipError(f"{LIB_PATH} does not export {s}")
+    lib.sympa_version.restype = ctypes.c_char_p
+    lib.sympa_last_error.restype = ctypes.c_char_p
+    lib.sympa_max_dims.restype = ctypes.c_int
+    lib.sympa_siegel_dist_fwd.restype = ctypes.c_int
+    lib.sympa_siegel_dist_fwd.argtypes = [
+        _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_void_p,
+    ]
+    lib.sympa_model_forward.restype = ctypes.c_int
+    lib.sympa_model_forward.argtypes = [
+        _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p,
+        ctypes.c_double, _c_double_p, _c_i32_p, ctypes.c_void_p,
+    ]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().sympa_last_error().decode()
+        raise SympaHipError(f"sympa_hip call failed (code {rc}): {msg}")

@@ -1,0 +1,173 @@
+// gfx950 kernels + C-ABI for the Siegel-distance hot path (include/sympa_hip.h).
+//
+// Mapping: ONE PAIR PER LANE.  A wavefront handles 64 independent pairs; the
+// complex n x n matrices of a pair live entirely in that lane's VGPRs (siegel_math.hpp unrolls to
+// static register indices), so the factorisations, solves and the Jacobi iteration need no
+// cross-lane traffic at all and no lane idles in an elementwise stage.  The only wave-level
+// operation is the ballot that ends the Jacobi loop when all 64 pairs have converged.
+// The workload is VALU-fp64 bound: the table rows come out of L2 / Infinity Cache.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/sympa_hip.h"
+#include "siegel_math.hpp"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct DistArgs {
+    const double* base1;   // z1 [b,2,n,n]   or the table
+    const double* base2;   // z2 [b,2,n,n]   or the table
+    const int64_t* idx1;   // nullptr -> row i
+    const int64_t* idx2;
+    int64_t idx1_stride;
+    int64_t idx2_stride;
+    int64_t num_rows;      // rows addressable through idx (bounds check)
+    int64_t b;
+    const double* metric_w;
+    const double* scale;   // device scalar or nullptr
+    double scale_coef;
+    double eps;
+    double* out;
+    double* vvd;
+    int32_t* status;
+    int metric;
+};
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < a.b;
+    const int64_t ii = live ? i : a.b - 1;   // idle tail lanes recompute the last pair (wave ballots need them)
+
+    int st = 0;
+    int64_t r1 = ii, r2 = ii;
+    if (a.idx1 != nullptr) {
+        r1 = a.idx1[ii * a.idx1_stride];
+        r2 = a.idx2[ii * a.idx2_stride];
+        if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) {
+            st |= sympa::ST_BAD_INDEX;
+            r1 = 0;
+            r2 = 0;
+        }
+    }
+    constexpr int64_t ROW = 2 * N * N;
+    double* vv = (a.vvd != nullptr && live) ? a.vvd + i * N : nullptr;
+    double d = sympa::pair_distance<N, MODEL>(a.base1 + r1 * ROW, a.base2 + r2 * ROW, a.metric, a.metric_w,
+                                              a.eps, vv, st);
+    if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
+    if (a.scale != nullptr) d *= fmax(a.scale[0] / a.scale_coef, 0.1);   // model.py:40-41
+    if (live) a.out[i] = d;
+
+    if (a.status != nullptr) {
+        const int flagged = (live && st != 0) ? 1 : 0;
+        const unsigned long long m = __ballot(flagged);
+        if (m != 0ull) {   // rare path
+            if (flagged) atomicOr(&a.status[0], st);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
+        }
+    }
+}
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+    std::snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+template <int N>
+int launch_n(const DistArgs& a, int model, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
+    if (model == SYMPA_MODEL_UPPER)
+        hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int launch(const DistArgs& a, int n, int model, void* stream) {
+    if (a.b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
+    if (a.b == 0) return 0;
+    if (a.base1 == nullptr || a.base2 == nullptr || a.out == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
+    if (a.metric < SYMPA_METRIC_RIEM || a.metric > SYMPA_METRIC_WSUM) return fail(SYMPA_ERR_BAD_ARG, "unknown metric");
+    if (a.metric == SYMPA_METRIC_WSUM && a.metric_w == nullptr)
+        return fail(SYMPA_ERR_BAD_ARG, "metric wsum needs metric_w");
+    if (!(a.eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
+    if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (n) {
+        case 1: return launch_n<1>(a, model, s);
+        case 2: return launch_n<2>(a, model, s);
+        case 3: return launch_n<3>(a, model, s);
+        case 4: return launch_n<4>(a, model, s);
+        case 5: return launch_n<5>(a, model, s);
+        case 6: return launch_n<6>(a, model, s);
+        case 7: return launch_n<7>(a, model, s);
+        case 8: return launch_n<8>(a, model, s);
+        default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS]");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sympa_version(void) { return "sympa_hip 0.1.0 (gfx950)"; }
+const char* sympa_last_error(void) { return g_err; }
+int sympa_max_dims(void) { return SYMPA_MAX_DIMS; }
+
+int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
+                          const double* metric_w, double eps, double* out, double* vvd_out, int32_t* status,
+                          void* stream) {
+    DistArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.base1 = z1;
+    a.base2 = z2;
+    a.b = b;
+    a.num_rows = b;
+    a.metric_w = metric_w;
+    a.scale_coef = 1.0;
+    a.eps = eps;
+    a.out = out;
+    a.vvd = vvd_out;
+    a.status = status;
+    a.metric = metric;
+    return launch(a, n, model, stream);
+}
+
+int sympa_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                        const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
+                        const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
+                        int32_t* status, void* stream) {
+    if (b > 0 && (src == nullptr || dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null index buffer");
+    if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    DistArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.base1 = table;
+    a.base2 = table;
+    a.idx1 = src;
+    a.idx2 = dst;
+    a.idx1_stride = src_stride;
+    a.idx2_stride = dst_stride;
+    a.num_rows = num_rows;
+    a.b = b;
+    a.metric_w = metric_w;
+    a.scale = scale;
+    a.scale_coef = scale_coef;
+    a.eps = eps;
+    a.out = out;
+    a.vvd = nullptr;
+    a.status = status;
+    a.metric = metric;
+    return launch(a, n, model, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// Per-pair arithmetic of the Siegel-distance hot path, written once and compiled twice:
+//   * by hipcc for gfx950 inside the kernels of siegel_dist.hip (the product), one pair per lane,
+//     every matrix in registers (all loops below unroll completely, every index is static);
+//   * by g++ for tests/hostsim (CPU, `-m "not gpu"` tests only) so the exact kernel arithmetic is
+//     checked against the oracle in the container that has no GPU.  hostsim is never shipped or
+//     loaded by the product package.
+//
+// What it replaces in the reference (fedelopez77/sympa), per pair (z1, z2):
+//   SiegelManifold.dist            sympa/manifolds/siegel_manifold.py:41-72
+//   sm.matrix_sqrt + .inverse()    sympa/math/csym_math.py:509-520, siegel_manifold.py:53
+//   sm.bmm3 sandwich               sympa/math/csym_math.py:91-128
+//   cayley_transform / sm.inverse  sympa/math/cayley_transform.py:10-24, csym_math.py:197-249
+//   inverse_cayley_transform x2    sympa/math/cayley_transform.py:27-40 (bounded_domain.py:27-39)
+//   TakagiFactorization.factorize  sympa/math/takagi_factorization.py:66-75
+//   v = log((1+d)/clamp(1-d,eps))  siegel_manifold.py:68-70
+//   Metric.compute_metric          sympa/manifolds/metrics.py:42-121
+//
+// The reference evaluates  d_i = singular values of  W = Cayley(Y1^-1/2 (Z2 - X1) Y1^-1/2)  through
+// two symmetric eigendecompositions (n x n and 2n x 2n), three LU inverses and 17 matmuls.
+// This file evaluates the same quantity through the identity
+//
+//        sinh(v_i / 2) = d_i / sqrt(1 - d_i^2) = 1/2 * sigma_i( L1^-1 (Z2 - Z1) L2^-T ),   Y_k = L_k L_k^T
+//
+// (upper half space) and, for the bounded domain, with A_k = I - W_k W_k^H = C_k C_k^H,
+//
+//        sinh(v_i / 2) = sigma_i( C1^-1 (W2 - W1) C2^-T )
+//
+// i.e. two Cholesky factorisations, two triangular solves, one n x n Hermitian Gram matrix and a
+// cyclic Jacobi eigenvalue iteration on it: no matrix square root, no complex inverse, no 2n x 2n
+// problem, no cancellation in 1 - d.  The reference's clamp of (1 - d) at eps is reproduced exactly.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define SYMPA_HD __host__ __device__ __forceinline__
+#else
+#define SYMPA_HD inline
+#endif
+
+namespace sympa {
+
+enum Model : int { MODEL_UPPER = 0, MODEL_BOUNDED = 1 };
+enum Metric : int { METRIC_RIEM = 0, METRIC_FONE = 1, METRIC_FINF = 2, METRIC_FMIN = 3, METRIC_WSUM = 4 };
+
+// status bits accumulated per launch (device counter words, see include/sympa_hip.h)
+enum StatusBit : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_BAD_INDEX = 4, ST_NO_CONVERGENCE = 8 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+SYMPA_HD bool wave_all(bool p) { return __all(p ? 1 : 0) != 0; }
+SYMPA_HD double d_sqrt(double x) { return __builtin_sqrt(x); }
+SYMPA_HD double d_log1p(double x) { return ::log1p(x); }
+#else
+SYMPA_HD bool wave_all(bool p) { return p; }
+SYMPA_HD double d_sqrt(double x) { return std::sqrt(x); }
+SYMPA_HD double d_log1p(double x) { return std::log1p(x); }
+#endif
+SYMPA_HD double d_rsqrt(double x) { return 1.0 / d_sqrt(x); }
+SYMPA_HD double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// A complex n x n matrix in registers: separate real / imaginary planes.
+template <int N>
+struct CMat {
+    double re[N][N];
+    double im[N][N];
+};
+
+// Lower-triangular factor with reciprocal diagonal kept separately (the solves multiply by it).
+template <int N, bool COMPLEX>
+struct Tri {
+    double re[N][N];   // strictly-lower part used: re[i][j], j < i
+    double im[N][N];   // only when COMPLEX
+    double rdiag[N];   // 1 / L[i][i]   (diagonal is real positive in both cases)
+};
+
+// ---------------------------------------------------------------------------------------------
+// Loads.  A point is [2, n, n] fp64 row-major (reference layout, csym_math.py:1-8).  Only the upper
+// triangle (i <= j) is read: points on the manifold are symmetric (reference PRE-condition; the
+// reference's own symeig(upper=True) also reads only the upper triangle of Y).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD void load_point(const double* __restrict__ p, CMat<N>& z) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            z.re[i][j] = p[(i <= j) ? i * N + j : j * N + i];
+            z.im[i][j] = p[N * N + ((i <= j) ? i * N + j : j * N + i)];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky of a real SPD matrix (upper model: Y = L L^T).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD bool chol_real(const double (&y)[N][N], Tri<N, false>& l) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double s = y[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = d_fma(-l.re[j][k], l.re[j][k], s);
+        ok = ok && (s > 0.0);
+        const double r = d_rsqrt(s);
+        l.rdiag[j] = r;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double t = y[j][i];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = d_fma(-l.re[i][k], l.re[j][k], t);
+            l.re[i][j] = t * r;
+        }
+    }
+    return ok;
+}
+
+// Cholesky of the Hermitian matrix A = I - W W^H for complex-symmetric W (bounded model).
+// (A)_ij = delta_ij - sum_l w_il conj(w_jl);  A = C C^H.
+template <int N>
+SYMPA_HD bool chol_id_minus_wwh(const CMat<N>& w, Tri<N, true>& c) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double s = 1.0;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            s = d_fma(-w.re[j][l], w.re[j][l], s);
+            s = d_fma(-w.im[j][l], w.im[j][l], s);
+        }
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            s = d_fma(-c.re[j][k], c.re[j][k], s);
+            s = d_fma(-c.im[j][k], c.im[j][k], s);
+        }
+        ok = ok && (s > 0.0);
+        const double r = d_rsqrt(s);
+        c.rdiag[j] = r;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            // a_ij = - sum_l w_il conj(w_jl)          (i != j)
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                tr = d_fma(-w.re[i][l], w.re[j][l], tr);
+                tr = d_fma(-w.im[i][l], w.im[j][l], tr);
+                ti = d_fma(-w.im[i][l], w.re[j][l], ti);
+                ti = d_fma(w.re[i][l], w.im[j][l], ti);
+            }
+            // minus sum_k c_ik conj(c_jk)
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                tr = d_fma(-c.re[i][k], c.re[j][k], tr);
+                tr = d_fma(-c.im[i][k], c.im[j][k], tr);
+                ti = d_fma(-c.im[i][k], c.re[j][k], ti);
+                ti = d_fma(c.re[i][k], c.im[j][k], ti);
+            }
+            c.re[i][j] = tr * r;
+            c.im[i][j] = ti * r;
+        }
+    }
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------
+// E <- L1^-1 * E   (forward substitution, column by column; E is overwritten)
+// ---------------------------------------------------------------------------------------------
+template <int N, bool COMPLEX>
+SYMPA_HD void solve_left(const Tri<N, COMPLEX>& l, CMat<N>& e) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double tr = e.re[i][c], ti = e.im[i][c];
+#pragma unroll
+            for (int k = 0; k < i; ++k) {
+                tr = d_fma(-l.re[i][k], e.re[k][c], tr);
+                ti = d_fma(-l.re[i][k], e.im[k][c], ti);
+                if (COMPLEX) {
+                    tr = d_fma(l.im[i][k], e.im[k][c], tr);
+                    ti = d_fma(-l.im[i][k], e.re[k][c], ti);
+                }
+            }
+            e.re[i][c] = tr * l.rdiag[i];
+            e.im[i][c] = ti * l.rdiag[i];
+        }
+    }
+}
+
+// E <- E * L2^-T   (solve X L2^T = E row by row; plain transpose, no conjugation)
+template <int N, bool COMPLEX>
+SYMPA_HD void solve_right_t(const Tri<N, COMPLEX>& l, CMat<N>& e) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double tr = e.re[r][j], ti = e.im[r][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                tr = d_fma(-e.re[r][k], l.re[j][k], tr);
+                ti = d_fma(-e.im[r][k], l.re[j][k], ti);
+                if (COMPLEX) {
+                    tr = d_fma(e.im[r][k], l.im[j][k], tr);
+                    ti = d_fma(-e.re[r][k], l.im[j][k], ti);
+                }
+            }
+            e.re[r][j] = tr * l.rdiag[j];
+            e.im[r][j] = ti * l.rdiag[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hermitian Gram matrix H = E^H E, stored as real diagonal d[] + strictly-upper complex part.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct Herm {
+    double d[N];
+    double re[N][N];   // re[j][k], j < k
+    double im[N][N];
+};
+
+template <int N>
+SYMPA_HD void gram(const CMat<N>& e, Herm<N>& h) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            s = d_fma(e.re[i][j], e.re[i][j], s);
+            s = d_fma(e.im[i][j], e.im[i][j], s);
+        }
+        h.d[j] = s;
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) {
+            double tr = 0.0, ti = 0.0;   // sum_i conj(e_ij) e_ik
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                tr = d_fma(e.re[i][j], e.re[i][k], tr);
+                tr = d_fma(e.im[i][j], e.im[i][k], tr);
+                ti = d_fma(e.re[i][j], e.im[i][k], ti);
+                ti = d_fma(-e.im[i][j], e.re[i][k], ti);
+            }
+            h.re[j][k] = tr;
+            h.im[j][k] = ti;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cyclic (row-by-row) Jacobi eigenvalue iteration on a Hermitian matrix, eigenvalues only.
+// Pivot (p,q), beta = h_pq = a e^{i phi}:  J = [[c, s e^{i phi}], [-s e^{-i phi}, c]],  H <- J^H H J.
+// With u = t / a = sgn(delta) * 2 / (|delta| + sqrt(delta^2 + 4 a^2)), delta = h_qq - h_pp, no
+// sqrt(a^2) is needed:  t^2 = u^2 a^2,  c = rsqrt(1 + t^2),  w = s e^{i phi} = c u beta.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD void jacobi_sweep(Herm<N>& h) {
+#pragma unroll
+    for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+        for (int q = p + 1; q < N; ++q) {
+            const double br = h.re[p][q], bi = h.im[p][q];
+            const double a2 = d_fma(br, br, bi * bi);
+            const double delta = h.d[q] - h.d[p];
+            const double rad = d_sqrt(d_fma(delta, delta, 4.0 * a2));
+            const double den = fabs(delta) + rad;
+            const double u = (den > 0.0) ? copysign(2.0, delta) / den : 0.0;
+            const double ua2 = u * a2;            // t * |beta|
+            const double c = d_rsqrt(d_fma(u, ua2, 1.0));   // 1/sqrt(1 + t^2)
+            const double cu = c * u;
+            const double wr = cu * br, wi = cu * bi;
+            h.d[p] -= ua2;
+            h.d[q] += ua2;
+            h.re[p][q] = 0.0;
+            h.im[p][q] = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (k == p || k == q) continue;
+                // x = h_kp, y = h_kq  (conjugate when the stored element is the transposed one)
+                double xr, xi, yr, yi;
+                if (k < p) { xr = h.re[k][p]; xi = h.im[k][p]; } else { xr = h.re[p][k]; xi = -h.im[p][k]; }
+                if (k < q) { yr = h.re[k][q]; yi = h.im[k][q]; } else { yr = h.re[q][k]; yi = -h.im[q][k]; }
+                // x' = c x - conj(w) y ;  y' = w x + c y
+                const double nxr = d_fma(-wi, yi, d_fma(-wr, yr, c * xr));
+                const double nxi = d_fma(wi, yr, d_fma(-wr, yi, c * xi));
+                const double nyr = d_fma(-wi, xi, d_fma(wr, xr, c * yr));
+                const double nyi = d_fma(wi, xr, d_fma(wr, xi, c * yi));
+                if (k < p) { h.re[k][p] = nxr; h.im[k][p] = nxi; } else { h.re[p][k] = nxr; h.im[p][k] = -nxi; }
+                if (k < q) { h.re[k][q] = nyr; h.im[k][q] = nyi; } else { h.re[q][k] = nyr; h.im[q][k] = -nyi; }
+            }
+        }
+    }
+}
+
+template <int N>
+SYMPA_HD void herm_norms(const Herm<N>& h, double& off2, double& diag2) {
+    off2 = 0.0;
+    diag2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        diag2 = d_fma(h.d[j], h.d[j], diag2);
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) {
+            off2 = d_fma(h.re[j][k], h.re[j][k], off2);
+            off2 = d_fma(h.im[j][k], h.im[j][k], off2);
+        }
+    }
+}
+
+// Off-diagonal Frobenius mass below JACOBI_TOL2 * diagonal mass ends the iteration:
+// ||off||_F <= 1e-11 ||diag||_F bounds every eigenvalue error by 1e-11 ||H|| (Weyl) and, with the
+// quadratic convergence of the cyclic method, typically by ~1e-22 ||H||^2 / gap.
+constexpr double JACOBI_TOL2 = 1e-22;
+constexpr int JACOBI_MAX_SWEEPS = 16;
+
+// Returns false when the sweep cap was hit before convergence.
+template <int N>
+SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
+    if (N == 1) return true;
+    bool conv = false;
+    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        double off2, diag2;
+        herm_norms<N>(h, off2, diag2);
+        conv = !(off2 > JACOBI_TOL2 * diag2);   // also true for NaN-free all-zero H
+        if (wave_all(conv)) break;
+        jacobi_sweep<N>(h);
+    }
+    return conv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// v = log((1+d)/max(1-d, eps)) from lambda = sinh^2(v/2) = d^2/(1-d^2)   (siegel_manifold.py:68-70)
+//   s = sqrt(lambda), c = sqrt(1+lambda):  d = s/c,  (1+d)/(1-d) = (c+s)^2 = 1 + 2 s (s + c),
+//   1 - d = 1/(c (c+s)).  The clamp is active iff  2 s (s+c) > (1+d)/eps - 1.
+// ---------------------------------------------------------------------------------------------
+SYMPA_HD double vvd_from_sinh2(double lambda, double eps) {
+    const double s = d_sqrt(lambda);
+    const double c = d_sqrt(1.0 + lambda);
+    const double unclamped = 2.0 * s * (s + c);
+    const double clamped = (1.0 + s / c) / eps - 1.0;
+    return d_log1p(unclamped < clamped ? unclamped : clamped);
+}
+
+template <int N>
+SYMPA_HD void sort_ascending(double (&v)[N]) {
+    // odd-even transposition network: N rounds, static indices
+#pragma unroll
+    for (int round = 0; round < N; ++round) {
+#pragma unroll
+        for (int i = (round & 1); i + 1 < N; i += 2) {
+            const double lo = fmin(v[i], v[i + 1]);
+            const double hi = fmax(v[i], v[i + 1]);
+            v[i] = lo;
+            v[i + 1] = hi;
+        }
+    }
+}
+
+// Metric.compute_metric on the ascending vector v (metrics.py:42-121). `w` = learnable wsum weights.
+template <int N>
+SYMPA_HD double reduce_metric(double (&v)[N], int metric, const double* __restrict__ w) {
+    double acc = 0.0;
+    if (metric == METRIC_RIEM) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc = d_fma(v[i], v[i], acc);
+        return d_sqrt(acc);
+    }
+    if (metric == METRIC_FONE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += v[i];
+        return acc;
+    }
+    if (metric == METRIC_FINF) {
+        acc = v[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i) acc = fmax(acc, v[i]);
+        return acc;
+    }
+    sort_ascending<N>(v);
+    if (metric == METRIC_FMIN) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc = d_fma(2.0 * i, v[i], acc);
+        return acc;
+    }
+    // METRIC_WSUM: sum relu(w_i) v_i
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc = d_fma(fmax(w[i], 0.0), v[i], acc);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pair, start to finish.  p1/p2 point at [2,n,n] fp64 points.  Returns the metric value; the
+// ascending vector-valued distance is written to vvd (if non-null) and status bits are OR-ed.
+// ---------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+SYMPA_HD double pair_distance(const double* __restrict__ p1, const double* __restrict__ p2, int metric,
+                              const double* __restrict__ w, double eps, double* __restrict__ vvd, int& status) {
+    CMat<N> e;
+    Herm<N> h;
+    bool ok;
+    {
+        CMat<N> z1, z2;
+        load_point<N>(p1, z1);
+        load_point<N>(p2, z2);
+        if (MODEL == MODEL_UPPER) {
+            Tri<N, false> l1, l2;
+            ok = chol_real<N>(z1.im, l1);
+            ok = chol_real<N>(z2.im, l2) && ok;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                    e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+                }
+            solve_left<N, false>(l1, e);
+            solve_right_t<N, false>(l2, e);
+        } else {
+            Tri<N, true> c1, c2;
+            ok = chol_id_minus_wwh<N>(z1, c1);
+            ok = chol_id_minus_wwh<N>(z2, c2) && ok;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                    e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+                }
+            solve_left<N, true>(c1, e);
+            solve_right_t<N, true>(c2, e);
+        }
+    }
+    gram<N>(e, h);
+    const bool conv = herm_eigenvalues<N>(h);
+
+    const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
+    double v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = vvd_from_sinh2(fmax(h.d[i], 0.0) * scale, eps);
+
+    if (vvd != nullptr) {
+        sort_ascending<N>(v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) vvd[i] = v[i];
+    }
+    const double out = reduce_metric<N>(v, metric, w);
+    if (!ok) status |= ST_NOT_PD;
+    if (!conv) status |= ST_NO_CONVERGENCE;
+    if (!(out == out) || !(fabs(out) <= 1.79e308)) status |= ST_NONFINITE;
+    return out;
+}
+
+}  // namespace sympa

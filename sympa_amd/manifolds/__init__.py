@@ -1,0 +1,6 @@
+from sympa_amd.manifolds.siegel_manifold import SiegelManifold
+from sympa_amd.manifolds.upper_half import UpperHalfManifold
+from sympa_amd.manifolds.bounded_domain import BoundedDomainManifold
+from sympa_amd.manifolds.metrics import MetricType, Metric
+
+__all__ = ["SiegelManifold", "UpperHalfManifold", "BoundedDomainManifold", "MetricType", "Metric"]

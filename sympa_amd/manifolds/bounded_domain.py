@@ -1,0 +1,86 @@
+"""BoundedDomainManifold  D_n = {Z in Sym(n,C) | I - conj(Z) Z > 0}
+(reference sympa/manifolds/bounded_domain.py).
+
+`dist`: the reference maps both points to the upper half space with two inverse Cayley transforms
+(two complex inverses) and then runs the upper distance (bounded_domain.py:27-39).  The HIP kernel
+evaluates the same vector-valued distance directly in the disc.
+Optimiser-side methods: device torch ops for now, see upper_half.py."""
+import torch
+
+from sympa_amd.config import EPS
+from sympa_amd.manifolds.base import Manifold
+from sympa_amd.manifolds.metrics import MetricType
+from sympa_amd.manifolds.siegel_manifold import SiegelManifold
+from sympa_amd.manifolds.upper_half import UpperHalfManifold
+
+
+def _c(z):
+    return torch.complex(z[:, 0], z[:, 1])
+
+
+def _r(c):
+    return torch.stack((c.real, c.imag), dim=1)
+
+
+def get_id_minus_conjugate_z_times_z(z):  # bounded_domain.py:163-170
+    zc = _c(z)
+    eye = torch.eye(z.shape[-1], dtype=zc.dtype, device=z.device)
+    return _r(eye - zc.conj() @ zc)
+
+
+class BoundedDomainManifold(SiegelManifold):
+    ndim = 1
+    reversible = False
+    name = "Bounded Domain"
+    __scaling__ = Manifold.__scaling__.copy()
+    model_name = "bounded"
+
+    def __init__(self, dims=2, ndim=2, metric=MetricType.RIEMANNIAN):
+        super().__init__(dims=dims, ndim=ndim, metric=metric)
+
+    def egrad2rgrad(self, z, u):  # bounded_domain.py:41-53: A G A, A = I - conj(Z) Z
+        a = _c(get_id_minus_conjugate_z_times_z(z))
+        return _r(a @ _c(u) @ a)
+
+    def projx(self, z):
+        """Intended behaviour of bounded_domain.py:55-84 (the in-tree call is broken at the surveyed
+        commit): clamp the Takagi values of Z at 1 - eps."""
+        z = super().projx(z)
+        n = z.shape[-1]
+        a, b = z[:, 0], z[:, 1]
+        comp = torch.cat((torch.cat((a, b), -1), torch.cat((b, -a), -1)), -2)   # csym_math.py:421-436
+        lam, q = torch.linalg.eigh(comp, UPLO="U")
+        vals = lam[:, n:]
+        right = q[..., n:]
+        s = torch.complex(right[..., :n, :], -right[..., n:, :])               # takagi_factorization.py:45-64
+        eps = EPS[z.dtype]
+        d = torch.diag_embed(torch.clamp(vals, max=1 - eps)).to(s.dtype)
+        z_tilde = _r(s.conj() @ d @ s.conj().transpose(-1, -2))
+        keep = torch.all(vals < 1 - eps, dim=-1, keepdim=True)
+        self.projected_points += len(z) - int(keep.sum().item())
+        return torch.where(keep.unsqueeze(-1).unsqueeze(-1).expand_as(z), z, z_tilde)
+
+    def inner(self, z, u, v=None, *, keepdim=False):  # bounded_domain.py:86-117
+        if v is None:
+            v = u
+        zc = _c(z)
+        eye = torch.eye(z.shape[-1], dtype=zc.dtype, device=z.device)
+        left = torch.linalg.inv(eye - zc.conj() @ zc)
+        right = torch.linalg.inv(eye - zc @ zc.conj())
+        res = left @ _c(u) @ right @ _c(v).conj()
+        real = res.real.diagonal(dim1=-2, dim2=-1).sum(-1, keepdim=True).unsqueeze(-1)
+        return torch.stack((real, real), dim=1)
+
+    def _check_point_on_manifold(self, x, *, atol=1e-5, rtol=1e-5):  # bounded_domain.py:119-150
+        if not self._check_matrices_are_symmetric(x, atol=atol, rtol=rtol):
+            return False, "Matrices are not symmetric"
+        a = _c(get_id_minus_conjugate_z_times_z(x.unsqueeze(0)))
+        ok = bool(torch.allclose(a, a.conj().transpose(-1, -2)))
+        return ok, None if ok else "'Id - ẐZ' is not hermitian (is not definite positive)"
+
+    def random(self, *size, dtype=None, device=None, **kwargs):  # bounded_domain.py:152-160
+        pts = UpperHalfManifold(dims=self.dims).random(*size, **kwargs)
+        zc = _c(pts)
+        eye = torch.eye(self.dims, dtype=zc.dtype)
+        out = _r((zc - 1j * eye) @ torch.linalg.inv(zc + 1j * eye))   # cayley_transform.py:10-24
+        return out.to(device=device, dtype=dtype)

@@ -1,0 +1,43 @@
+"""Graph-embedding model on a Siegel manifold (reference sympa/model.py:8-47).
+
+`forward` is the drop-in boundary of the hot path: instead of two `index` gathers that materialise
+2 x [b,2,n,n] in HBM followed by ~100 ATen ops, one fused HIP kernel reads the two table rows of
+each pair straight from the table and writes the b scaled distances."""
+import torch
+import torch.nn as nn
+
+from sympa_amd import autograd as sa
+from sympa_amd.embeddings import EmbeddingsFactory, ManifoldFactory
+from sympa_amd.manifolds.metrics import MetricType
+
+
+class Model(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.manifold = ManifoldFactory.get_manifold(manifold_name=args.manifold, metric_name=args.metric,
+                                                     dims=args.dims)
+        self.embeddings = EmbeddingsFactory.get_embeddings(args.manifold, args.num_points, args.dims,
+                                                           self.manifold)
+        self.scale_coef = args.scale_coef
+        self.scale = torch.nn.Parameter(torch.Tensor([self.scale_coef * args.scale_init]),
+                                        requires_grad=args.train_scale)
+
+    def forward(self, input_triplet):
+        """input_triplet: int64 [b, 2|3] (src_id, dst_id[, graph_distance]) -> b distances * scale
+        (model.py:16-30)."""
+        man = self.manifold
+        weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
+        return sa.model_forward(self.embeddings.embeds, input_triplet, man.model_name, man.metric.kind.value,
+                                weights, self.scale, self.scale_coef)
+
+    def distance(self, src_embeds, dst_embeds):   # model.py:32-38
+        return self.manifold.dist(src_embeds, dst_embeds)
+
+    def get_scale(self):                          # model.py:40-41
+        return (self.scale / self.scale_coef).clamp_min(0.1)
+
+    def check_all_points(self):
+        return self.embeddings.check_all_points()
+
+    def embeds_norm(self):
+        return self.embeddings.norm()

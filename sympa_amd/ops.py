@@ -1,0 +1,147 @@
+"""Torch-facing entry points of the hot path.  PyTorch only supplies device memory and the
+current HIP stream; all arithmetic happens in libsympa_hip.so through the C-ABI
+(include/sympa_hip.h).  There is no CPU path: CPU tensors raise.
+
+Error contract: the reference raises AssertionError from inside dist()
+(siegel_manifold.py:64-66), which costs host syncs per call.  Here range violations are
+accumulated in a per-device status word; `check_status()` (or `set_debug(True)`) surfaces them as
+the same AssertionError / IndexError lazily."""
+import ctypes
+
+import torch
+
+from sympa_amd import _lib
+from sympa_amd.config import EPS
+
+MODEL_IDS = {"upper": 0, "bounded": 1}
+METRIC_IDS = {"riem": 0, "fone": 1, "finf": 2, "fmin": 3, "wsum": 4}
+
+ST_NOT_PD, ST_NONFINITE, ST_BAD_INDEX, ST_NO_CONVERGENCE = 1, 2, 4, 8
+
+_status = {}   # device index -> int32[2] tensor
+_debug = False
+
+
+def set_debug(flag: bool):
+    """When on, every call synchronises and raises like the reference's in-line asserts."""
+    global _debug
+    _debug = bool(flag)
+
+
+def _status_buf(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _status.get(idx)
+    if buf is None:
+        buf = torch.zeros(2, dtype=torch.int32, device=device)
+        _status[idx] = buf
+    return buf
+
+
+def check_status(device=None, reset=True):
+    """Reads the device status word (one host sync) and raises what the reference would have."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    buf = _status_buf(torch.device(device))
+    bits, count = (int(x) for x in buf.tolist())
+    if reset and bits:
+        buf.zero_()
+    if bits & ST_BAD_INDEX:
+        raise IndexError(f"index out of range in Model.forward gather ({count} pairs flagged)")
+    if bits & (ST_NOT_PD | ST_NONFINITE | ST_NO_CONVERGENCE):
+        raise AssertionError(
+            f"Siegel distance: {count} pairs outside the manifold / non-finite (status bits {bits}); "
+            "reference: 'assert 0 <= eigvalues <= 1' (siegel_manifold.py:64-66)")
+    return bits, count
+
+
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.SympaHipError(f"{name} is on {t.device}: the Siegel-distance path runs on the GPU only "
+                                 "(HIP kernels, no CPU fallback)")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _weights(metric, weights, n, device):
+    if metric != "wsum":
+        return None
+    if weights is None:
+        raise ValueError("metric 'wsum' needs its weights")
+    w = weights.detach().reshape(-1).to(device=device, dtype=torch.float64).contiguous()
+    if w.numel() != n:
+        raise ValueError(f"wsum weights must have {n} entries")
+    return w
+
+
+def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=None, return_vvd=False):
+    """manifold.dist for pre-gathered points z1, z2 [b,2,n,n] fp64 on the GPU -> [b]
+    (C-ABI sympa_siegel_dist_fwd; reference siegel_manifold.py:41-72 / bounded_domain.py:27-39)."""
+    lib = _lib.load()
+    _need_gpu(z1, "z1"); _need_gpu(z2, "z2")
+    if z1.dtype != torch.float64 or z2.dtype != torch.float64:
+        raise TypeError("points must be float64 (reference default dtype, config.py:17-18)")
+    if z1.shape != z2.shape or z1.dim() != 4 or z1.shape[1] != 2 or z1.shape[2] != z1.shape[3]:
+        raise ValueError(f"expected two [b,2,n,n] tensors, got {tuple(z1.shape)} and {tuple(z2.shape)}")
+    z1 = z1.detach().contiguous()
+    z2 = z2.detach().contiguous()
+    b, _, n, _ = z1.shape
+    out = torch.empty(b, dtype=torch.float64, device=z1.device)
+    vvd = torch.empty(b, n, dtype=torch.float64, device=z1.device) if return_vvd else None
+    w = _weights(metric, weights, n, z1.device)
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(z1.device)
+    with torch.cuda.device(z1.device):
+        rc = lib.sympa_siegel_dist_fwd(_ptr(z1), _ptr(z2), b, n, MODEL_IDS[model], METRIC_IDS[metric],
+                                       _ptr(w), eps, _ptr(out), _ptr(vvd), _ptr(st), _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(z1.device)
+    return (out, vvd) if return_vvd else out
+
+
+def model_forward(table, triplets, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0,
+                  eps=None, out=None):
+    """Fused Model.forward (C-ABI sympa_model_forward; reference model.py:16-41): gathers table rows
+    triplets[:,0] / triplets[:,1] inside the kernel, returns dist * clamp_min(scale/scale_coef, 0.1)."""
+    lib = _lib.load()
+    _need_gpu(table, "table"); _need_gpu(triplets, "triplets")
+    if table.dtype != torch.float64:
+        raise TypeError("table must be float64")
+    if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
+        raise TypeError("triplets must be an int64 [b, >=2] tensor (src, dst[, graph_distance])")
+    if table.dim() != 4 or table.shape[1] != 2 or table.shape[2] != table.shape[3]:
+        raise ValueError(f"table must be [N,2,n,n], got {tuple(table.shape)}")
+    tab = table.detach()
+    if not tab.is_contiguous():
+        tab = tab.contiguous()
+    num_rows, _, n, _ = tab.shape
+    b = triplets.shape[0]
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    if out is None:
+        out = torch.empty(b, dtype=torch.float64, device=tab.device)
+    if b == 0:
+        return out
+    w = _weights(metric, weights, n, tab.device)
+    sc = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(tab.device)
+    src_ptr = ctypes.c_void_p(triplets.data_ptr())
+    dst_ptr = ctypes.c_void_p(triplets.data_ptr() + 8)
+    with torch.cuda.device(tab.device):
+        rc = lib.sympa_model_forward(_ptr(tab), num_rows, n, src_ptr, stride, dst_ptr, stride, b,
+                                     MODEL_IDS[model], METRIC_IDS[metric], _ptr(w), eps, _ptr(sc),
+                                     float(scale_coef), _ptr(out), _ptr(st), _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(tab.device)
+    return out

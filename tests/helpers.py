@@ -1,0 +1,81 @@
+"""Shared helpers for the tests: golden loading, synthetic points, hostsim binding."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+METRICS = ["riem", "fone", "finf", "fmin", "wsum"]
+MODELS = ["upper", "bounded"]
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.float64)
+
+
+def rel_err(got, want, atol=1e-12):
+    """max over the batch of max(|got-want| - atol, 0) / |want|: relative error with an absolute
+    floor for d ~ 0 (the reference's own d(x,x) is ~1e-15, not 0)."""
+    got, want = torch.as_tensor(got), torch.as_tensor(want)
+    excess = ((got - want).abs() - atol).clamp_min(0.0)
+    return (excess / want.abs().clamp_min(1e-300)).max().item()
+
+
+def sym(x):
+    return 0.5 * (x + x.transpose(-1, -2))
+
+
+def upper_points(b, n, s, g):
+    x = sym(torch.randn(b, n, n, generator=g, dtype=torch.float64) * s)
+    y = torch.matrix_exp(sym(torch.randn(b, n, n, generator=g, dtype=torch.float64) * s))
+    return torch.stack((x, sym(y)), 1)
+
+
+def to_bounded(z):
+    """Cayley image, exactly symmetric (what a projected bounded table row looks like)."""
+    zc = torch.complex(z[:, 0], z[:, 1])
+    eye = torch.eye(z.shape[-1], dtype=zc.dtype)
+    w = (zc - 1j * eye) @ torch.linalg.inv(zc + 1j * eye)
+    w = 0.5 * (w + w.transpose(-1, -2))
+    return torch.stack((w.real, w.imag), 1)
+
+
+def points(model, b, n, s, g):
+    z = upper_points(b, n, s, g)
+    return to_bounded(z) if model == "bounded" else z
+
+
+_hostsim = None
+
+
+def hostsim():
+    """CPU build of the kernel arithmetic (tests/hostsim), built on demand with g++."""
+    global _hostsim
+    if _hostsim is None:
+        d = os.path.join(ROOT, "tests", "hostsim")
+        so = os.path.join(d, "libsympa_hostsim.so")
+        srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], cwd=d)
+        _hostsim = ctypes.CDLL(so)
+    return _hostsim
+
+
+def hostsim_dist(z1, z2, model, metric, weights=None, eps=1e-5):
+    lib = hostsim()
+    P = ctypes.c_void_p
+    z1 = np.ascontiguousarray(z1, dtype=np.float64)
+    z2 = np.ascontiguousarray(z2, dtype=np.float64)
+    b, _, n, _ = z1.shape
+    out = np.zeros(b)
+    vvd = np.zeros((b, n))
+    st = ctypes.c_int32(0)
+    w = np.ascontiguousarray(np.ones(n) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1))
+    rc = lib.sympa_hostsim_dist(P(z1.ctypes.data), P(z2.ctypes.data), ctypes.c_int64(b), n,
+                                MODELS.index(model), METRICS.index(metric), P(w.ctypes.data),
+                                ctypes.c_double(eps), P(out.ctypes.data), P(vvd.ctypes.data), ctypes.byref(st))
+    assert rc == 0, rc
+    return out, vvd, st.value

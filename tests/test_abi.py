@@ -1,0 +1,62 @@
+"""CPU (`-m "not gpu"`): the C-ABI library loads, exports every symbol include/sympa_hip.h declares,
+and validates arguments (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from sympa_amd import _lib
+from tests.helpers import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sympa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sympa_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_matches_binding():
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.sympa_version()
+    assert lib.sympa_max_dims() == 8
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)   # never dereferenced: validation happens before any launch
+    # b == 0 is a no-op
+    assert lib.sympa_siegel_dist_fwd(one, one, 0, 4, 0, 0, None, 1e-5, one, None, None, None) == 0
+    assert lib.sympa_siegel_dist_fwd(one, one, -1, 4, 0, 0, None, 1e-5, one, None, None, None) == -1
+    assert lib.sympa_siegel_dist_fwd(None, one, 8, 4, 0, 0, None, 1e-5, one, None, None, None) == -1
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 7, 0, None, 1e-5, one, None, None, None) == -1   # model
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 9, None, 1e-5, one, None, None, None) == -1   # metric
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 4, None, 1e-5, one, None, None, None) == -1   # wsum w/o w
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 0, None, 0.0, one, None, None, None) == -1    # eps
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 99, 0, 0, None, 1e-5, one, None, None, None) == -2  # dims
+    assert b"dims" in lib.sympa_last_error()
+    assert lib.sympa_model_forward(one, 10, 4, None, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, None) == -1
+    assert lib.sympa_model_forward(one, 0, 4, one, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, None) == -1
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from sympa_amd import ops
+    z = torch.zeros(2, 2, 3, 3, dtype=torch.float64)
+    with pytest.raises(_lib.SympaHipError):
+        ops.siegel_dist_forward(z, z)
+    with pytest.raises(_lib.SympaHipError):
+        ops.model_forward(z, torch.zeros(2, 2, dtype=torch.int64))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsympa_hip.so")
+    with pytest.raises(_lib.SympaHipError):
+        _lib.load()

@@ -1,0 +1,176 @@
+"""GPU (`-m gpu`): parity of the HIP path, called through the C-ABI (sympa_amd.ops -> libsympa_hip.so),
+against (1) golden vectors produced by the imported reference, (2) the oracle on seeded inputs,
+(3) size-independent properties at BASELINE.json's full batch sizes.
+Tolerance: 1e-9 relative for distances (north_star: 1e-4), abs floor 1e-12; index handling bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import siegel_oracle as so
+from tests.helpers import GOLDEN, METRICS, MODELS, T, hostsim_dist, points, rel_err, sym, upper_points
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+TOL_FAR_VS_REFERENCE = 1e-6   # see tests/test_hostsim_parity.py
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from sympa_amd import _lib
+    _lib.load()          # the HIP library must be the thing that runs
+    return torch.device("cuda:0")
+
+
+def gpu_dist(z1, z2, model, metric, w=None, dev="cuda:0", vvd=False):
+    from sympa_amd import ops
+    r = ops.siegel_dist_forward(T(z1).to(dev), T(z2).to(dev), model, metric,
+                                None if w is None else T(w).to(dev), return_vvd=vvd)
+    ops.check_status(torch.device(dev))
+    return (r[0].cpu(), r[1].cpu()) if vvd else r.cpu()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_golden_vectors_of_the_reference(dev, model, n):
+    g = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
+    for case in g["case_names"]:
+        z1, z2 = g[f"{case}__z1"], g[f"{case}__z2"]
+        for metric in METRICS:
+            got = gpu_dist(z1, z2, model, metric, g["wsum_weights"])
+            tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
+            assert rel_err(got, g[f"{case}__{metric}"]) < tol, (model, n, case, metric)
+        if f"{case}__vvd_exact50" in g:
+            _, vvd = gpu_dist(z1, z2, model, "riem", vvd=True)
+            assert rel_err(vvd, g[f"{case}__vvd_exact50"]) < (1e-12 if model == "upper" else 1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_against_oracle_seeded(dev, model, n):
+    g = torch.Generator().manual_seed(1000 + n)
+    b = 777   # ragged: not a multiple of the 256-lane block
+    for s in (1e-3, 0.3, 0.8):
+        z1, z2 = points(model, b, n, s, g), points(model, b, n, s, g)
+        for metric in METRICS:
+            w = torch.linspace(-0.3, 1.2, n)
+            got = gpu_dist(z1, z2, model, metric, w)
+            want = so.manifold_dist(model, z1, z2, metric, w)
+            assert rel_err(got, want) < TOL, (model, n, s, metric)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_matches_cpu_build_of_same_arithmetic(dev, model):
+    """hipcc device code vs g++ host build of siegel_math.hpp: same algorithm, agreement to rounding."""
+    g = torch.Generator().manual_seed(5)
+    z1, z2 = points(model, 300, 4, 0.5, g), points(model, 300, 4, 0.5, g)
+    got, vv = gpu_dist(z1, z2, model, "riem", vvd=True)
+    ref, vref, _ = hostsim_dist(z1.numpy(), z2.numpy(), model, "riem")
+    assert rel_err(got, ref) < 1e-12
+    assert rel_err(vv, vref, atol=1e-13) < 1e-10
+
+
+def test_model_forward_golden_and_bit_exact_gather(dev):
+    from sympa_amd import ops
+    g = np.load(f"{GOLDEN}/model_forward.npz")
+    trip = torch.from_numpy(g["triplets"]).to(dev)          # int64 [b,3]: strided src/dst, no copy
+    for model in MODELS:
+        table = T(g[f"table_{model}"]).to(dev)
+        for scale, coef in ((1.0, 1.0), (0.05, 1.0), (3.0, 2.0)):
+            sc = torch.tensor([scale], device=dev)
+            got = ops.model_forward(table, trip, model, "riem", None, sc, coef)
+            ops.check_status(dev)
+            assert rel_err(got.cpu(), g[f"{model}__scale{scale}_coef{coef}"]) < TOL
+        # fused in-kernel gather == explicit gather + dist, bit for bit (index work is exact)
+        fused = ops.model_forward(table, trip, model, "riem")
+        two_step = ops.siegel_dist_forward(table[trip[:, 0]], table[trip[:, 1]], model, "riem")
+        assert torch.equal(fused, two_step)
+        # [b,2] triplets (runner.py:149 builds those) give the same bits as [b,3]
+        assert torch.equal(ops.model_forward(table, trip[:, :2].contiguous(), model, "riem"), fused)
+
+
+def test_model_class_is_a_drop_in(dev):
+    from sympa_amd import ops
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "upper", "wsum", 3, 40
+        scale_coef, scale_init, train_scale = 2.0, 1.5, False
+
+    m = Model(A).to(dev)
+    assert set(m.state_dict().keys()) == {"scale", "embeddings.embeds", "manifold.metric.weights"}
+    trip = torch.randint(0, 40, (100, 3), device=dev)
+    with torch.no_grad():
+        out = m(trip)
+    ops.check_status(dev)
+    want = so.model_forward(m.embeddings.embeds.detach().cpu(), trip.cpu(), "upper", "wsum",
+                            m.manifold.metric.weights.detach().cpu(), m.scale.detach().cpu(), A.scale_coef)
+    assert rel_err(out.cpu(), want) < TOL
+    z1 = m.embeddings(trip[:, 0]).detach()
+    z2 = m.embeddings(trip[:, 1]).detach()
+    assert rel_err((m.distance(z1, z2) * m.get_scale()).detach().cpu(), want) < TOL
+
+
+def test_edge_cases(dev):
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(9)
+    table = upper_points(10, 4, 0.3, g).to(dev)
+    # empty batch
+    assert ops.model_forward(table, torch.zeros(0, 2, dtype=torch.int64, device=dev)).shape == (0,)
+    assert ops.siegel_dist_forward(table[:0], table[:0]).shape == (0,)
+    # single pair
+    one = ops.model_forward(table, torch.tensor([[1, 2]], device=dev))
+    assert one.shape == (1,) and torch.isfinite(one).all()
+    ops.check_status(dev)
+    # index out of range -> status + NaN, like the reference's IndexError
+    bad = ops.model_forward(table, torch.tensor([[1, 2], [3, 10], [-1, 0]], device=dev))
+    assert torch.isfinite(bad[0]) and torch.isnan(bad[1]) and torch.isnan(bad[2])
+    with pytest.raises(IndexError):
+        ops.check_status(dev)
+    # point outside the manifold (Im z not PD) -> AssertionError like siegel_manifold.py:64-66
+    off = table.clone()
+    off[4, 1] = -off[4, 1]
+    ops.model_forward(off, torch.tensor([[4, 5], [1, 2]], device=dev))
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+    # d(x, x) == 0 exactly (reference test_upper_half.py:128-133 asserts allclose to 0)
+    assert torch.all(ops.siegel_dist_forward(table, table) == 0)
+    # unsupported dims fail loudly
+    with pytest.raises(RuntimeError):
+        ops.siegel_dist_forward(torch.zeros(2, 2, 9, 9, device=dev), torch.zeros(2, 2, 9, 9, device=dev))
+
+
+@pytest.mark.parametrize("model,n,b,N", [("upper", 4, 8192, 1093), ("bounded", 4, 65536, 5041),
+                                         ("upper", 8, 262144, 45500), ("upper", 2, 512, 125)])
+def test_full_size_properties(dev, model, n, b, N):
+    """BASELINE.json config sizes, checked through properties that need no CPU reference:
+    symmetry d(x,y) = d(y,x); d(x,x) = 0; invariance under the isometries Z -> A Z A^T + S of the
+    upper half space (and agreement upper == bounded through the Cayley map on a sample)."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(11)
+    tab_u = upper_points(N, n, 0.4, g)
+    table = (tab_u if model == "upper" else __import__("tests.helpers", fromlist=["to_bounded"]).to_bounded(tab_u)).to(dev)
+    src = torch.randint(0, N, (b,), generator=g)
+    dst = (src + 1 + torch.randint(0, N - 1, (b,), generator=g)) % N
+    trip = torch.stack((src, dst), 1).to(dev)
+    d_xy = ops.model_forward(table, trip, model, "riem")
+    d_yx = ops.model_forward(table, trip.flip(1).contiguous(), model, "riem")
+    ops.check_status(dev)
+    assert torch.isfinite(d_xy).all() and (d_xy > 0).all()
+    assert rel_err(d_xy.cpu(), d_yx.cpu()) < 1e-10
+    same = torch.stack((src, src), 1).to(dev)
+    assert torch.all(ops.model_forward(table, same, model, "riem") == 0)
+    if model == "upper":
+        a = (torch.eye(n) + 0.3 * torch.randn(n, n, generator=g)).to(dev)
+        s = sym(torch.randn(n, n, generator=g)).to(dev)
+        moved = torch.stack((a @ table[:, 0] @ a.T + s, a @ table[:, 1] @ a.T), 1)
+        moved = torch.stack((sym(moved[:, 0]), sym(moved[:, 1])), 1)
+        d_moved = ops.model_forward(moved, trip, model, "riem")
+        assert rel_err(d_moved.cpu(), d_xy.cpu()) < 1e-9
+    else:
+        d_up = ops.model_forward(tab_u.to(dev), trip, "upper", "riem")
+        assert rel_err(d_xy.cpu(), d_up.cpu()) < 1e-9
+    # a bounded sample against the oracle as well
+    k = 256
+    want = so.model_forward(table.cpu(), trip[:k].cpu(), model, "riem")
+    assert rel_err(d_xy[:k].cpu(), want) < 1e-8

@@ -1,0 +1,77 @@
+"""CPU: host-side integer/index logic is bit-exact: keyed RNG, pair sampling, graph
+triplets (vs networkx BFS), DistributedSampler sharding (vs torch's own sampler)."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DistributedSampler, TensorDataset
+
+from sympa_amd import data
+
+
+def _splitmix_scalar(x):
+    m = (1 << 64) - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
+def test_keyed_rng_matches_scalar_python():
+    seed, stream = 42, 10
+    key = _splitmix_scalar(((seed << 32) | stream) & ((1 << 64) - 1))
+    want = [_splitmix_scalar(c ^ key) for c in range(50)]
+    got = data.keyed_u64(seed, stream, np.arange(50)).tolist()
+    assert got == want
+
+
+def test_sample_pairs_bit_exact_and_rank_independent():
+    n, b = 1093, 4096
+    p = data.sample_pairs(n, b, batch_id=3, seed=42)
+    assert p.dtype == torch.int64 and p.shape == (b, 2)
+    assert (p[:, 0] != p[:, 1]).all() and p.min() >= 0 and p.max() < n
+    # pure-python restatement of the same keyed draw
+    m = (1 << 64) - 1
+    k10 = _splitmix_scalar(((42 << 32) | 10) & m)
+    k11 = _splitmix_scalar(((42 << 32) | 11) & m)
+    for k in (0, 1, 77, b - 1):
+        c = 3 * b + k
+        i = _splitmix_scalar(c ^ k10) % n
+        j = (i + 1 + _splitmix_scalar(c ^ k11) % (n - 1)) % n
+        assert p[k].tolist() == [i, j]
+    # same bytes whoever generates them
+    assert torch.equal(p, data.sample_pairs(n, b, batch_id=3, seed=42))
+
+
+@pytest.mark.parametrize("name,nodes,triplets,diam", [("grid3d-125", 125, 7750, 12)])
+def test_graph_triplets_match_networkx_bfs(name, nodes, triplets, diam):
+    import networkx as nx
+    g = data.named_graph(name)
+    trip, id2node = data.graph_triplets(g)
+    assert len(id2node) == nodes and trip.shape == (triplets, 3) and int(trip[:, 2].max()) == diam
+    relabelled = nx.convert_node_labels_to_integers(g, ordering="sorted")
+    sp = dict(nx.all_pairs_shortest_path_length(relabelled))
+    want = [(i, j, sp[i][j]) for i in range(nodes) for j in range(i + 1, nodes)]
+    assert trip.tolist() == [list(t) for t in want]          # lexicographic, exact integers
+
+
+@pytest.mark.parametrize("length,world", [(103, 4), (8, 3), (5, 8), (64, 2), (7750, 8)])
+@pytest.mark.parametrize("drop_last", [False, True])
+def test_distributed_sampler_semantics(length, world, drop_last):
+    ds = TensorDataset(torch.arange(length))
+    for rank in range(world):
+        s = DistributedSampler(ds, num_replicas=world, rank=rank, seed=3, drop_last=drop_last)
+        s.set_epoch(2)
+        assert list(s) == data.distributed_sampler_indices(length, world, rank, epoch=2, seed=3,
+                                                           drop_last=drop_last)
+
+
+def test_tables_are_on_the_manifold():
+    t = data.trained_like_table(64, 4)
+    assert t.shape == (64, 2, 4, 4) and t.dtype == torch.float64
+    assert torch.equal(t, t.transpose(-1, -2))
+    assert (torch.linalg.eigvalsh(t[:, 1]) > 0).all()
+    w = data.trained_like_table(64, 4, model="bounded")
+    wc = torch.complex(w[:, 0], w[:, 1])
+    assert (torch.linalg.svdvals(wc) < 1).all()
+    i = data.init_table(64, 3)
+    assert ((i[:, 1] - torch.eye(3)).abs() <= 1e-3).all() and (i[:, 0].abs() <= 1e-3).all()

@@ -1,0 +1,64 @@
+"""CPU (`-m "not gpu"`): the per-pair arithmetic the gfx950 kernel runs (siegel_math.hpp compiled by
+g++, tests/hostsim) against the golden vectors of the imported reference and against the oracle.
+Tolerance: 1e-9 relative (abs floor 1e-9 for d ~ 0); north_star asks 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import siegel_oracle as so
+from tests.helpers import GOLDEN, METRICS, MODELS, T, hostsim_dist, points, rel_err
+
+TOL = 1e-9
+# 'far' (and the tail of 's1.0' at n=8) = the regime 1 - d in [1e-8, 1e-5] where the reference's own fp64 evaluation carries ~1e-7
+# error (see vvd_exact50); there we hold 1e-6 against the reference and 1e-12 against the exact value.
+TOL_FAR_VS_REFERENCE = 1e-6
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_golden(model, n):
+    g = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
+    for case in g["case_names"]:
+        z1, z2 = g[f"{case}__z1"], g[f"{case}__z2"]
+        for metric in METRICS:
+            out, vvd, st = hostsim_dist(z1, z2, model, metric, g["wsum_weights"])
+            assert st == 0
+            tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
+            assert rel_err(out, g[f"{case}__{metric}"]) < tol, (model, n, case, metric)
+        if f"{case}__vvd_exact50" in g:
+            # bounded points near the boundary: forming I - W W^H cancels ~5 digits (conditioning of
+            # the disc representation itself), so 1e-9 there; upper model: 1e-12
+            tol_exact = 1e-12 if model == "upper" else 1e-9
+            assert rel_err(vvd, g[f"{case}__vvd_exact50"]) < tol_exact, (model, n, case)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_oracle_seeded(model, n):
+    g = torch.Generator().manual_seed(100 + n)
+    for s in (1e-3, 0.3, 0.8):
+        z1, z2 = points(model, 40, n, s, g), points(model, 40, n, s, g)
+        for metric in ("riem", "fmin"):
+            out, vvd, st = hostsim_dist(z1.numpy(), z2.numpy(), model, metric)
+            want = so.manifold_dist(model, z1, z2, metric)
+            assert st == 0
+            assert rel_err(out, want) < TOL, (model, n, s, metric)
+        v_ref, _ = so.vector_valued_distance(*( (so.inverse_cayley_transform(z1), so.inverse_cayley_transform(z2))
+                                               if model == "bounded" else (z1, z2)))
+        assert rel_err(vvd, v_ref, atol=1e-9) < 1e-7   # individual small v_i next to large ones
+
+
+def test_status_not_positive_definite():
+    g = torch.Generator().manual_seed(3)
+    z1, z2 = points("upper", 8, 3, 0.3, g), points("upper", 8, 3, 0.3, g)
+    z1[2, 1] = -z1[2, 1]     # Im z not PD
+    _, _, st = hostsim_dist(z1.numpy(), z2.numpy(), "upper", "riem")
+    assert st & 1
+
+
+def test_same_point_is_exactly_zero():
+    g = torch.Generator().manual_seed(4)
+    for model in MODELS:
+        z = points(model, 16, 4, 0.5, g)
+        out, _, st = hostsim_dist(z.numpy(), z.numpy(), model, "riem")
+        assert st == 0 and np.all(out == 0.0)

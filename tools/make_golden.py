@@ -76,6 +76,35 @@ def build_cases(n, g, b=24):
     return cases
 
 
+def mp_exact_vvd(model, z1, z2, eps="1e-5", dps=50):
+    """50-digit evaluation of the REFERENCE formula (sqrt, inverse, Cayley, singular values, clamp)
+    with mpmath: tells fp64 rounding of the reference apart from real disagreement in the
+    ill-conditioned 'far' regime (1 - d ~ 1e-5 .. 1e-8)."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    eps = mp.mpf(eps)
+    out = []
+    for a, b in zip(z1.numpy(), z2.numpy()):
+        n = a.shape[-1]
+        eye = mp.eye(n)
+        A = mp.matrix(a[0].tolist()) + 1j * mp.matrix(a[1].tolist())
+        B = mp.matrix(b[0].tolist()) + 1j * mp.matrix(b[1].tolist())
+        if model == "bounded":   # cayley_transform.py:27-40
+            A = 1j * (eye + A) * ((eye - A) ** -1)
+            B = 1j * (eye + B) * ((eye - B) ** -1)
+        X1 = A.apply(mp.re)
+        Y1 = A.apply(mp.im)
+        Y1 = (Y1 + Y1.T) / 2
+        lam, V = mp.eigsy(Y1)
+        Si = (V * mp.diag([mp.sqrt(l) for l in lam]) * V.T) ** -1
+        Z3 = Si * (B - X1) * Si
+        W = (Z3 - 1j * eye) * ((Z3 + 1j * eye) ** -1)
+        sv = mp.svd_c(W, compute_uv=False)
+        v = sorted(mp.log((1 + d) / max(1 - d, eps)) for d in sv)
+        out.append([float(x) for x in v])
+    return np.array(out)
+
+
 def main():
     torch.set_default_dtype(torch.float64)
     sm, cay, tak, UH, BD, met = ref_shim.import_reference()
@@ -95,6 +124,8 @@ def main():
                     z1, z2 = sm.to_symmetric(z1), sm.to_symmetric(z2)
                 blob[f"{name}__z1"] = z1.numpy()
                 blob[f"{name}__z2"] = z2.numpy()
+                if name in ("far", "s1.0") and n <= 4:
+                    blob[f"{name}__vvd_exact50"] = mp_exact_vvd(model, z1, z2)
                 for metric in METRICS:
                     man = (UH if model == "upper" else BD)(dims=n, metric=met.MetricType.from_str(metric))
                     if metric == "wsum":
