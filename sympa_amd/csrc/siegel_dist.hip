@@ -29,8 +29,8 @@ struct DistArgs {
     int64_t b;
     const double* metric_w;
     const double* scale;   // device scalar or nullptr
-    double scale_coef;
-    double eps;
+    double inv_scale_coef;
+    double inv_eps;        // 1 / eps, computed on the host
     double* out;
     double* vvd;
     int32_t* status;
@@ -57,9 +57,9 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     constexpr int64_t ROW = 2 * N * N;
     double* vv = (a.vvd != nullptr && live) ? a.vvd + i * N : nullptr;
     double d = sympa::pair_distance<N, MODEL>(a.base1 + r1 * ROW, a.base2 + r2 * ROW, a.metric, a.metric_w,
-                                              a.eps, vv, st);
+                                              a.inv_eps, vv, st);
     if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
-    if (a.scale != nullptr) d *= fmax(a.scale[0] / a.scale_coef, 0.1);   // model.py:40-41
+    if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
     if (live) a.out[i] = d;
 
     if (a.status != nullptr) {
@@ -99,7 +99,7 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     if (a.metric < SYMPA_METRIC_RIEM || a.metric > SYMPA_METRIC_WSUM) return fail(SYMPA_ERR_BAD_ARG, "unknown metric");
     if (a.metric == SYMPA_METRIC_WSUM && a.metric_w == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "metric wsum needs metric_w");
-    if (!(a.eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
+    if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
@@ -133,8 +133,8 @@ int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, 
     a.b = b;
     a.num_rows = b;
     a.metric_w = metric_w;
-    a.scale_coef = 1.0;
-    a.eps = eps;
+    a.inv_scale_coef = 1.0;
+    a.inv_eps = 1.0 / eps;
     a.out = out;
     a.vvd = vvd_out;
     a.status = status;
@@ -161,8 +161,8 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
     a.b = b;
     a.metric_w = metric_w;
     a.scale = scale;
-    a.scale_coef = scale_coef;
-    a.eps = eps;
+    a.inv_scale_coef = 1.0 / scale_coef;
+    a.inv_eps = 1.0 / eps;
     a.out = out;
     a.vvd = nullptr;
     a.status = status;

@@ -15,8 +15,8 @@ void run(const double* z1, const double* z2, int64_t b, int model, int metric, c
         const double* p2 = z2 + i * 2 * N * N;
         double* vv = vvd ? vvd + i * N : nullptr;
         out[i] = (model == sympa::MODEL_UPPER)
-                     ? sympa::pair_distance<N, sympa::MODEL_UPPER>(p1, p2, metric, w, eps, vv, st)
-                     : sympa::pair_distance<N, sympa::MODEL_BOUNDED>(p1, p2, metric, w, eps, vv, st);
+                     ? sympa::pair_distance<N, sympa::MODEL_UPPER>(p1, p2, metric, w, 1.0 / eps, vv, st)
+                     : sympa::pair_distance<N, sympa::MODEL_BOUNDED>(p1, p2, metric, w, 1.0 / eps, vv, st);
     }
     if (status) *status = st;
 }

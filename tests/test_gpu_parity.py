@@ -98,7 +98,9 @@ def test_model_class_is_a_drop_in(dev):
         scale_coef, scale_init, train_scale = 2.0, 1.5, False
 
     m = Model(A).to(dev)
-    assert set(m.state_dict().keys()) == {"scale", "embeddings.embeds", "manifold.metric.weights"}
+    # same keys as the reference's Model (the manifold is registered under Model and under Embeddings)
+    assert set(m.state_dict().keys()) == {"scale", "embeddings.embeds", "manifold.metric.weights",
+                                          "embeddings.manifold.metric.weights"}
     trip = torch.randint(0, 40, (100, 3), device=dev)
     with torch.no_grad():
         out = m(trip)
