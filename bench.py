@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="graph launch only: capture the steps on this many parallel HIP streams so that "
+                         "independent steps (different batches) overlap on the GPU; 1 = strictly sequential")
     ap.add_argument("--launch", default="graph", choices=["graph", "direct"],
                     help="graph: the steps are replayed from a captured hipGraph of --distinct-batches kernel "
                          "nodes (one node = one step); direct: one Python->C-ABI call per step")
@@ -127,10 +130,12 @@ def main():
     for j in range(nb):
         glob = data.sample_pairs(nodes, batch * world, j, args.seed)
         batches.append(glob[rank::world].contiguous().to(dev))
-    out = torch.empty(batch, dtype=torch.float64, device=dev)
+    outs = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(nb)]
+    out = outs[0]
+    flags = ops.FLAG_LOW_LDS if args.streams > 1 else 0
 
     def step(i):
-        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=out)
+        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb], flags=flags)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -146,9 +151,20 @@ def main():
             step(i)            # warm (allocates the status word etc. outside capture)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
+        side = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
         with torch.cuda.graph(graph):
+            main = torch.cuda.current_stream()
+            for st in side:
+                st.wait_stream(main)                     # fork
             for i in range(nb):
-                step(i)
+                k = i % args.streams
+                if k == 0:
+                    step(i)
+                else:
+                    with torch.cuda.stream(side[k - 1]):
+                        step(i)
+            for st in side:
+                main.wait_stream(st)                     # join
 
     def run_steps(k):
         done = 0
@@ -209,7 +225,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "model": None, "manifold": model, "dist_metric": metric,
                        "dims": n, "nodes": nodes, "pairs_per_gpu_per_step": batch,
-                       "global_pairs_per_step": batch * world, "table": args.table, "launch": args.launch,
+                       "global_pairs_per_step": batch * world, "table": args.table, "launch": args.launch, "streams": args.streams,
                        "parallelism": f"pairs sharded rank::{world}, table replicated, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

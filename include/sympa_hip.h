@@ -47,6 +47,10 @@ extern "C" {
 #define SYMPA_ERR_BAD_ARG (-1)
 #define SYMPA_ERR_UNSUPPORTED_DIMS (-2)
 
+/* flags */
+#define SYMPA_FLAG_LOW_LDS 1 /* stage one endpoint at a time: half the LDS per block, so blocks of two launches
+                                that overlap (different streams / independent graph nodes) share a CU */
+
 #define SYMPA_MAX_DIMS 8 /* largest n with a register-resident kernel in this build */
 
 /* Library / build identification. */
@@ -63,10 +67,11 @@ int sympa_max_dims(void);
  *   eps       clamp of (1 - d), reference EPS[float64] = 1e-5 (sympa/config.py:19)
  *   out       [b] fp64 distances
  *   vvd_out   [b, n] fp64 ascending vector-valued distance v (siegel_manifold.py:69-70), or NULL
+ *   flags     0 or SYMPA_FLAG_*
  */
 int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
                           const double* metric_w, double eps, double* out, double* vvd_out, int32_t* status,
-                          void* stream);
+                          int flags, void* stream);
 
 /* Model.forward(input_triplet) fused: gather two table rows per pair, distance, times the scale.
  * Replaces Model.forward / Model.distance / Model.get_scale (sympa/model.py:16-41) and
@@ -80,7 +85,7 @@ int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, 
 int sympa_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                         const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                         const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
-                        int32_t* status, void* stream);
+                        int32_t* status, int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 
 #include "../../include/sympa_hip.h"
 #include "siegel_math.hpp"
+#include "siegel_gather.hpp"
 
 namespace {
 
@@ -35,10 +36,14 @@ struct DistArgs {
     double* vvd;
     int32_t* status;
     int metric;
+    int flags;
 };
 
-template <int N, int MODEL>
+template <int N, int MODEL, bool LOWLDS>
 __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
+    constexpr int WAVE_SLOTS = DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
+                                                   : Tile<N>::WAVE_SLOTS;
+    __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < a.b;
     const int64_t ii = live ? i : a.b - 1;   // idle tail lanes recompute the last pair (wave ballots need them)
@@ -56,8 +61,21 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     }
     constexpr int64_t ROW = 2 * N * N;
     double* vv = (a.vvd != nullptr && live) ? a.vvd + i * N : nullptr;
-    double d = sympa::pair_distance<N, MODEL>(a.base1 + r1 * ROW, a.base2 + r2 * ROW, a.metric, a.metric_w,
-                                              a.inv_eps, vv, st);
+    double d;
+    if constexpr (Tile<N>::STAGED) {
+        sympa::CMat<N> z1, z2;
+        v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
+        if constexpr (DmaTile<N>::ENABLED && LOWLDS)
+            gather_pair_dma_low<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+        else if constexpr (DmaTile<N>::ENABLED)
+            gather_pair_dma<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+        else
+            gather_pair_staged<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+        d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);
+    } else {
+        d = sympa::pair_distance<N, MODEL>(a.base1 + r1 * ROW, a.base2 + r2 * ROW, a.metric, a.metric_w,
+                                           a.inv_eps, vv, st);
+    }
     if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
     if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
     if (live) a.out[i] = d;
@@ -82,10 +100,15 @@ int fail(int code, const char* msg) {
 template <int N>
 int launch_n(const DistArgs& a, int model, hipStream_t s) {
     const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
-    if (model == SYMPA_MODEL_UPPER)
-        hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, a);
-    else
-        hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, a);
+    // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
+    const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256);
+    if (model == SYMPA_MODEL_UPPER) {
+        if (low) hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    } else {
+        if (low) hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
@@ -101,6 +124,7 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
         return fail(SYMPA_ERR_BAD_ARG, "metric wsum needs metric_w");
     if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
+    if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
         case 1: return launch_n<1>(a, model, s);
@@ -125,7 +149,7 @@ int sympa_max_dims(void) { return SYMPA_MAX_DIMS; }
 
 int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
                           const double* metric_w, double eps, double* out, double* vvd_out, int32_t* status,
-                          void* stream) {
+                          int flags, void* stream) {
     DistArgs a;
     std::memset(&a, 0, sizeof(a));
     a.base1 = z1;
@@ -139,13 +163,14 @@ int sympa_siegel_dist_fwd(const double* z1, const double* z2, int64_t b, int n, 
     a.vvd = vvd_out;
     a.status = status;
     a.metric = metric;
+    a.flags = flags;
     return launch(a, n, model, stream);
 }
 
 int sympa_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                         const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                         const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
-                        int32_t* status, void* stream) {
+                        int32_t* status, int flags, void* stream) {
     if (b > 0 && (src == nullptr || dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null index buffer");
     if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
     if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
@@ -167,6 +192,7 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
     a.vvd = nullptr;
     a.status = status;
     a.metric = metric;
+    a.flags = flags;
     return launch(a, n, model, stream);
 }
 

@@ -1,0 +1,174 @@
+// Device-only helpers shared by the product kernels (siegel_dist.hip) and the ablation tools
+// (tools/microbench): cooperative, coalesced row gather through a wave-private LDS tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "siegel_math.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// Row gather.  A lane-per-pair load of a 16 n^2-byte row touches 64 different cache lines per wave
+// instruction and is bound by the texture-address unit (measured: 3 us of a 9.6 us launch at n = 4,
+// profiles/r01_kernel_anatomy.txt).  For n <= 4 the wave therefore loads rows COOPERATIVELY: a row is
+// C = n^2 chunks of 16 B, consecutive lanes fetch consecutive chunks (coalesced 16n^2-byte segments),
+// the chunks are staged in a wave-private LDS tile [pair][SLOTS] and each lane then reads back its own
+// row with ds_read_b128.  SLOTS (row pitch in 16-B slots) is odd, so the 16 lanes of a b128 read group
+// fall on 16 distinct 4-bank slots: conflict-free.
+// The tile belongs to ONE wave: LDS operations of a wave are processed in order, so no block barrier
+// is needed, only a compiler-level fence that keeps the cross-lane write -> read order.
+// ---------------------------------------------------------------------------------------------
+typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B chunk
+
+template <int N>
+struct Tile {
+    static constexpr int C = N * N;                       // 16-B chunks per row
+    static constexpr int SLOTS = (C % 2 == 1) ? C : C + 1;
+    static constexpr bool STAGED = (N >= 2 && N <= 4);
+    static constexpr int WAVE_SLOTS = STAGED ? 64 * SLOTS : 1;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Issues the coalesced loads of the 64 rows `row` (one per lane) of `base`; chunk t of this lane.
+template <int N>
+__device__ __forceinline__ void gather_issue(const double* __restrict__ base, const int row, v2d (&v)[N * N]) {
+    constexpr int C = Tile<N>::C;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int g = t * 64 + lane;
+        const int p = g / C, c = g - p * C;
+        const int r = __shfl(row, p);
+        v[t] = reinterpret_cast<const v2d*>(base + (int64_t)r * (2 * N * N))[c];
+    }
+}
+
+// Transposes the staged chunks through the wave's tile: afterwards lane i holds row i.
+template <int N>
+__device__ __forceinline__ void gather_transpose(const v2d (&v)[N * N], v2d* __restrict__ tile, sympa::CMat<N>& z) {
+    constexpr int C = Tile<N>::C, SLOTS = Tile<N>::SLOTS;
+    const int lane = threadIdx.x & 63;
+    wave_lds_fence();   // earlier reads of the tile (previous side) are complete in program order
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int g = t * 64 + lane;
+        const int p = g / C, c = g - p * C;
+        tile[p * SLOTS + c] = v[t];
+    }
+    wave_lds_fence();
+    v2d q[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) q[c] = tile[lane * SLOTS + c];
+    // flat index f of [2, n, n]: element f lives in chunk f / 2, half f % 2
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int fr = (i <= j) ? i * N + j : j * N + i;
+            const int fi = N * N + fr;
+            z.re[i][j] = (fr & 1) ? q[fr >> 1].y : q[fr >> 1].x;
+            z.im[i][j] = (fi & 1) ? q[fi >> 1].y : q[fi >> 1].x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (n = 2, 4: C = n^2 divides 64).  `global_load_lds_dwordx4` moves 64 x 16 B straight
+// from the per-lane SOURCE addresses into 1 KiB of contiguous LDS (no VGPR staging, no ds_write).
+// Instruction j of a side fetches the R = 64 / C rows of pairs {j, j + C, j + 2C, ...} (16 lanes = one
+// coalesced row); its 1 KiB lands at j * 1040 B.  Lane i then finds chunk k of its row at
+//      (i % C) * 1040 + (i / C) * 16 C + 16 k        [bytes]
+// and the odd slot pitch 1040 / 16 = 65 makes every ds_read_b128 lane group conflict-free.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct DmaTile {
+    static constexpr int C = N * N;
+    static constexpr bool ENABLED = (N == 2 || N == 4);
+    static constexpr int INSTR_SLOTS = 65;                  // 1040 B
+    static constexpr int SIDE_SLOTS = ENABLED ? C * INSTR_SLOTS : 1;
+    static constexpr int WAVE_SLOTS = 2 * SIDE_SLOTS;       // both endpoints in flight
+    static constexpr int WAVE_SLOTS_LOW = SIDE_SLOTS;       // one endpoint at a time (half the LDS)
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void dma_issue(const double* __restrict__ base, const int row, v2d* __restrict__ side) {
+    constexpr int C = DmaTile<N>::C;
+    const int lane = threadIdx.x & 63;
+    const int r = lane / C, c = lane - r * C;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int rr = __shfl(row, j + C * r);
+        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * c;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(side + j * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void dma_read(const v2d* __restrict__ side, sympa::CMat<N>& z) {
+    constexpr int C = DmaTile<N>::C;
+    const int lane = threadIdx.x & 63;
+    const v2d* mine = side + (lane % C) * DmaTile<N>::INSTR_SLOTS + (lane / C) * C;
+    v2d q[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) q[c] = mine[c];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int fr = (i <= j) ? i * N + j : j * N + i;
+            const int fi = N * N + fr;
+            z.re[i][j] = (fr & 1) ? q[fr >> 1].y : q[fr >> 1].x;
+            z.im[i][j] = (fi & 1) ? q[fi >> 1].y : q[fi >> 1].x;
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void gather_pair_dma(const double* __restrict__ base1, const int row1,
+                                                const double* __restrict__ base2, const int row2,
+                                                v2d* __restrict__ tile, sympa::CMat<N>& z1, sympa::CMat<N>& z2) {
+    v2d* side1 = tile;
+    v2d* side2 = tile + DmaTile<N>::SIDE_SLOTS;
+    dma_issue<N>(base1, row1, side1);
+    dma_issue<N>(base2, row2, side2);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): LDS-DMA is counted like a load; the compiler does not track it
+    wave_lds_fence();
+    dma_read<N>(side1, z1);
+    dma_read<N>(side2, z2);
+}
+
+// Low-LDS form: one endpoint at a time through one side buffer.  Exposes one more L2 round trip per
+// wave but halves the LDS footprint, so twice as many waves fit on a CU (used when launches overlap or
+// the grid is several waves per SIMD deep: the other wave's arithmetic hides the round trip).
+template <int N>
+__device__ __forceinline__ void gather_pair_dma_low(const double* __restrict__ base1, const int row1,
+                                                    const double* __restrict__ base2, const int row2,
+                                                    v2d* __restrict__ tile, sympa::CMat<N>& z1, sympa::CMat<N>& z2) {
+    dma_issue<N>(base1, row1, tile);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    wave_lds_fence();
+    dma_read<N>(tile, z1);
+    wave_lds_fence();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): our reads of the buffer are done before it is refilled
+    dma_issue<N>(base2, row2, tile);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    wave_lds_fence();
+    dma_read<N>(tile, z2);
+}
+
+// Both endpoints: all global loads are in flight before the first transpose starts.
+template <int N>
+__device__ __forceinline__ void gather_pair_staged(const double* __restrict__ base1, const int row1,
+                                                   const double* __restrict__ base2, const int row2,
+                                                   v2d* __restrict__ tile, sympa::CMat<N>& z1, sympa::CMat<N>& z2) {
+    v2d v1[N * N], v2[N * N];
+    gather_issue<N>(base1, row1, v1);
+    gather_issue<N>(base2, row2, v2);
+    gather_transpose<N>(v1, tile, z1);
+    gather_transpose<N>(v2, tile, z2);
+}

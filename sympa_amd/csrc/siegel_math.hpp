@@ -381,29 +381,92 @@ SYMPA_HD void herm_norms(const Herm<N>& h, double& off2, double& diag2) {
     }
 }
 
-// Off-diagonal Frobenius mass below JACOBI_TOL2 * diagonal mass ends the iteration:
-// ||off||_F <= 1e-10 ||diag||_F bounds every eigenvalue error by 1e-10 ||H|| (Weyl) and, with the
-// quadratic convergence of the cyclic method, typically by ~1e-20 ||H||^2 / gap.
-constexpr double JACOBI_TOL2 = 1e-20;
-constexpr int JACOBI_MAX_SWEEPS = 16;
-constexpr int JACOBI_BLIND_SWEEPS = 2;   // no pair of the measured inputs converges earlier (n >= 3)
+// Finishing sweep.  Once every pivot's rotation angle is small the second-order shifts
+//   d_p -= t|beta|,  d_q += t|beta|     (exact eigenvalues of each 2 x 2 pivot problem)
+// are applied to the diagonal WITHOUT rotating the remaining off-diagonal entries (40 % of the cost of a
+// full sweep).  What this drops, in Rayleigh-Schroedinger terms:
+//   * third order  sum_{j,k} f_ij f_jk f_ki / (D_ij D_ik): needs a triangle of non-zero off-diagonal
+//     entries.  For n = 4 the round-robin sweep ends with the rounds {(0,2),(1,3)}, {(0,3),(1,2)}; the last
+//     round leaves h_03 = h_12 = 0 exactly and every triangle of four indices contains one of those two
+//     edges, so the third-order term VANISHES identically;
+//   * fourth order  ~ n^2 t^4 ||H||  with t = max |h_pq / (h_qq - h_pp)|.
+// Certificate (jacobi_can_finish): t^2 <= 1e-3 on every pivot (or the pivot is negligible against the
+// whole matrix) and off-diagonal mass <= 1e-4 of the diagonal mass  =>  dropped terms <= 16 * 1e-6 ||H||,
+// i.e. a certified relative error of the distance below 2e-5 (north_star tolerance: 1e-4).  MEASURED on
+// 4 x 65 536 pairs of each benchmark table (init, trained 0.3, trained 1.0) and on every golden vector:
+// <= 3e-12, typically 1e-15, because after three sweeps t is ~1e-5 on all but a handful of pivots
+// (tools/jacobi_convergence.py reproduces these statistics).  For n > 4 the certificate is tightened to
+// t^2 <= 1e-8, off <= 1e-12 (dropped terms <= 6e-13 ||H||), which in practice means one more full sweep.
+template <int N>
+SYMPA_HD void jacobi_diag_update(Herm<N>& h, const int p, const int q) {
+    const double br = h.re[p][q], bi = h.im[p][q];
+    const double a2 = d_fma(br, br, bi * bi);
+    const double delta = h.d[q] - h.d[p];
+    const double ad = fabs(delta) + 1e-150;
+    const double qr = d_rsqrt(d_fma(ad, ad, 4.0 * a2));
+    const double c2 = d_fma(0.5 * ad, qr, 0.5);
+    // t |beta| = a^2 / (r c^2);  1 / c^2 = 2 - c^2 + O(t^4)
+    const double ua2 = (copysign(qr, delta) * a2) * (2.0 - c2);
+    h.d[p] -= ua2;
+    h.d[q] += ua2;
+}
 
-// Returns false when the sweep cap was hit before convergence.
+template <int N>
+SYMPA_HD void jacobi_final_sweep(Herm<N>& h) {
+#pragma unroll
+    for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+        for (int q = p + 1; q < N; ++q) jacobi_diag_update<N>(h, p, q);
+    }
+}
+
+// Certificate for the finishing sweep (thresholds above): every pivot has t^2 = |h_pq|^2 / delta^2 small, or is
+// already negligible against the whole matrix (|h_pq|^2 <= 1e-24 ||diag||^2: exactly or numerically
+// degenerate pairs), and the off-diagonal mass is small against the diagonal mass.
+template <int N> constexpr double finish_t2() { return N <= 4 ? 1e-3 : 1e-8; }
+template <int N> constexpr double finish_off2() { return N <= 4 ? 1e-4 : 1e-12; }
+constexpr double FINISH_NEGLIGIBLE2 = 1e-24;
+
+template <int N>
+SYMPA_HD bool jacobi_can_finish(const Herm<N>& h) {
+    double diag2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) diag2 = d_fma(h.d[j], h.d[j], diag2);
+    const double floor2 = FINISH_NEGLIGIBLE2 * diag2;
+    double off2 = 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+        for (int q = p + 1; q < N; ++q) {
+            const double a2 = d_fma(h.re[p][q], h.re[p][q], h.im[p][q] * h.im[p][q]);
+            const double delta = h.d[q] - h.d[p];
+            off2 += a2;
+            ok = ok && (a2 <= fmax(finish_t2<N>() * delta * delta, floor2));
+        }
+    }
+    return ok && !(off2 > finish_off2<N>() * diag2);
+}
+
+constexpr int JACOBI_MAX_SWEEPS = 16;
+// sweeps run before the first test: no pair of the measured inputs passes the certificate earlier
+template <int N>
+constexpr int jacobi_blind_sweeps() { return N <= 2 ? 1 : 3; }
+
+// Returns false when the sweep cap was hit before the certificate held.
 template <int N>
 SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
     if (N == 1) return true;
-    bool conv = false;
-    if (N > 2) {
 #pragma unroll
-        for (int sweep = 0; sweep < JACOBI_BLIND_SWEEPS; ++sweep) jacobi_sweep<N>(h);
-    }
-    for (int sweep = (N > 2 ? JACOBI_BLIND_SWEEPS : 0); sweep < JACOBI_MAX_SWEEPS; ++sweep) {
-        double off2, diag2;
-        herm_norms<N>(h, off2, diag2);
-        conv = !(off2 > JACOBI_TOL2 * diag2);   // also true for NaN-free all-zero H
+    for (int sweep = 0; sweep < jacobi_blind_sweeps<N>(); ++sweep) jacobi_sweep<N>(h);
+    if (N == 2) return true;    // a single rotation diagonalises a 2 x 2 matrix exactly
+    bool conv = false;
+    for (int sweep = jacobi_blind_sweeps<N>(); sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        conv = jacobi_can_finish<N>(h);
         if (wave_all(conv)) break;
         jacobi_sweep<N>(h);
     }
+    jacobi_final_sweep<N>(h);
     return conv;
 }
 
@@ -476,15 +539,12 @@ SYMPA_HD double reduce_metric(double (&v)[N], int metric, const double* __restri
 // ascending vector-valued distance is written to vvd (if non-null) and status bits are OR-ed.
 // ---------------------------------------------------------------------------------------------
 template <int N, int MODEL>
-SYMPA_HD double pair_distance(const double* __restrict__ p1, const double* __restrict__ p2, int metric,
-                              const double* __restrict__ w, double inv_eps, double* __restrict__ vvd, int& status) {
+SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
+                                   double inv_eps, double* __restrict__ vvd, int& status) {
     CMat<N> e;
     Herm<N> h;
     bool ok;
     {
-        CMat<N> z1, z2;
-        load_point<N>(p1, z1);
-        load_point<N>(p2, z2);
         if (MODEL == MODEL_UPPER) {
             Tri<N, false> l1, l2;
             ok = chol_real<N>(z1.im, l1);
@@ -531,6 +591,16 @@ SYMPA_HD double pair_distance(const double* __restrict__ p1, const double* __res
     if (!conv) status |= ST_NO_CONVERGENCE;
     if (!(out == out) || !(fabs(out) <= 1.79e308)) status |= ST_NONFINITE;
     return out;
+}
+
+// Same, reading the two points straight from memory (lane-per-row loads; used for n > 4 and on the host).
+template <int N, int MODEL>
+SYMPA_HD double pair_distance(const double* __restrict__ p1, const double* __restrict__ p2, int metric,
+                              const double* __restrict__ w, double inv_eps, double* __restrict__ vvd, int& status) {
+    CMat<N> z1, z2;
+    load_point<N>(p1, z1);
+    load_point<N>(p2, z2);
+    return pair_distance_mats<N, MODEL>(z1, z2, metric, w, inv_eps, vvd, status);
 }
 
 }  // namespace sympa

@@ -79,7 +79,10 @@ def _weights(metric, weights, n, device):
     return w
 
 
-def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=None, return_vvd=False):
+FLAG_LOW_LDS = 1
+
+
+def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=None, return_vvd=False, flags=0):
     """manifold.dist for pre-gathered points z1, z2 [b,2,n,n] fp64 on the GPU -> [b]
     (C-ABI sympa_siegel_dist_fwd; reference siegel_manifold.py:41-72 / bounded_domain.py:27-39)."""
     lib = _lib.load()
@@ -98,7 +101,7 @@ def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=
     st = _status_buf(z1.device)
     with torch.cuda.device(z1.device):
         rc = lib.sympa_siegel_dist_fwd(_ptr(z1), _ptr(z2), b, n, MODEL_IDS[model], METRIC_IDS[metric],
-                                       _ptr(w), eps, _ptr(out), _ptr(vvd), _ptr(st), _stream())
+                                       _ptr(w), eps, _ptr(out), _ptr(vvd), _ptr(st), int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(z1.device)
@@ -106,7 +109,7 @@ def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=
 
 
 def model_forward(table, triplets, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0,
-                  eps=None, out=None):
+                  eps=None, out=None, flags=0):
     """Fused Model.forward (C-ABI sympa_model_forward; reference model.py:16-41): gathers table rows
     triplets[:,0] / triplets[:,1] inside the kernel, returns dist * clamp_min(scale/scale_coef, 0.1)."""
     lib = _lib.load()
@@ -140,7 +143,7 @@ def model_forward(table, triplets, model="upper", metric="riem", weights=None, s
     with torch.cuda.device(tab.device):
         rc = lib.sympa_model_forward(_ptr(tab), num_rows, n, src_ptr, stride, dst_ptr, stride, b,
                                      MODEL_IDS[model], METRIC_IDS[metric], _ptr(w), eps, _ptr(sc),
-                                     float(scale_coef), _ptr(out), _ptr(st), _stream())
+                                     float(scale_coef), _ptr(out), _ptr(st), int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(tab.device)

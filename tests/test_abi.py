@@ -32,17 +32,17 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     one = ctypes.c_void_p(16)   # never dereferenced: validation happens before any launch
     # b == 0 is a no-op
-    assert lib.sympa_siegel_dist_fwd(one, one, 0, 4, 0, 0, None, 1e-5, one, None, None, None) == 0
-    assert lib.sympa_siegel_dist_fwd(one, one, -1, 4, 0, 0, None, 1e-5, one, None, None, None) == -1
-    assert lib.sympa_siegel_dist_fwd(None, one, 8, 4, 0, 0, None, 1e-5, one, None, None, None) == -1
-    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 7, 0, None, 1e-5, one, None, None, None) == -1   # model
-    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 9, None, 1e-5, one, None, None, None) == -1   # metric
-    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 4, None, 1e-5, one, None, None, None) == -1   # wsum w/o w
-    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 0, None, 0.0, one, None, None, None) == -1    # eps
-    assert lib.sympa_siegel_dist_fwd(one, one, 8, 99, 0, 0, None, 1e-5, one, None, None, None) == -2  # dims
+    assert lib.sympa_siegel_dist_fwd(one, one, 0, 4, 0, 0, None, 1e-5, one, None, None, 0, None) == 0
+    assert lib.sympa_siegel_dist_fwd(one, one, -1, 4, 0, 0, None, 1e-5, one, None, None, 0, None) == -1
+    assert lib.sympa_siegel_dist_fwd(None, one, 8, 4, 0, 0, None, 1e-5, one, None, None, 0, None) == -1
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 7, 0, None, 1e-5, one, None, None, 0, None) == -1   # model
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 9, None, 1e-5, one, None, None, 0, None) == -1   # metric
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 4, None, 1e-5, one, None, None, 0, None) == -1   # wsum w/o w
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 4, 0, 0, None, 0.0, one, None, None, 0, None) == -1    # eps
+    assert lib.sympa_siegel_dist_fwd(one, one, 8, 99, 0, 0, None, 1e-5, one, None, None, 0, None) == -2  # dims
     assert b"dims" in lib.sympa_last_error()
-    assert lib.sympa_model_forward(one, 10, 4, None, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, None) == -1
-    assert lib.sympa_model_forward(one, 0, 4, one, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, None) == -1
+    assert lib.sympa_model_forward(one, 10, 4, None, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, 0, None) == -1
+    assert lib.sympa_model_forward(one, 0, 4, one, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, 0, None) == -1
 
 
 def test_product_path_refuses_cpu_tensors():

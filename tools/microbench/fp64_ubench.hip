@@ -74,6 +74,42 @@ __global__ void lat(double* out, unsigned long long* cyc, int iters) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// EXEC-masked variant: only the first `active` lanes of each wave run the FMA loop
+__global__ void lat_masked(double* out, unsigned long long* cyc, int iters, int active) {
+    double a[8];
+    for (int k = 0; k < 8; ++k) a[k] = 1.0 + 1e-3 * (threadIdx.x + k);
+    const double m = 0.999999, c = 1e-7;
+    unsigned long long t0 = 0, t1 = 0;
+    if ((threadIdx.x & 63) < active) {
+        t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(a[k], m, c);
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    double s = 0;
+    for (int k = 0; k < 8; ++k) s += a[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+__global__ void thr_masked(double* out, int iters, int active) {
+    double a[8];
+    for (int k = 0; k < 8; ++k) a[k] = 1.0 + 1e-3 * (threadIdx.x + k);
+    const double m = 0.999999, c = 1e-7;
+    if ((threadIdx.x & 63) < active) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(a[k], m, c);
+        }
+    }
+    double s = 0;
+    for (int k = 0; k < 8; ++k) s += a[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void thr(double* out, int iters) {
     double a[8];
     for (int k = 0; k < 8; ++k) a[k] = 1.0 + 1e-3 * (threadIdx.x + k);
@@ -117,6 +153,21 @@ int main() {
 #define RUN(M) { lat<M><<<1, 64>>>(a, cyc, iters); unsigned long long h; CK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost)); \
                  printf("1 wave: %-26s %7.2f cycles per op\n", names[M], (double)h / (iters * 8.0)); }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
+    for (int act : {64, 32, 16}) {
+        lat_masked<<<1, 64>>>(a, cyc, iters, act);
+        unsigned long long h; CK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
+        printf("1 wave, %2d active lanes: fma 8 indep %7.2f cycles per op\n", act, (double)h / (iters * 8.0));
+    }
+    {
+        hipEvent_t s0, e0; CK(hipEventCreate(&s0)); CK(hipEventCreate(&e0));
+        for (int act : {64, 32}) for (int wps : {1, 2, 4}) {
+            int blocks = 256 * wps; const int it2 = 20000;
+            thr_masked<<<blocks, 256>>>(a, 100, act);
+            CK(hipEventRecord(s0)); thr_masked<<<blocks, 256>>>(a, it2, act); CK(hipEventRecord(e0)); CK(hipEventSynchronize(e0));
+            float ms; CK(hipEventElapsedTime(&ms, s0, e0));
+            printf("chip, %d active lanes, %d wave(s)/SIMD: %.3f ms  -> %.1f G lane-FMA/s\n", act, wps, ms, 8.0 * it2 * act * 4.0 * blocks / ms / 1e6);
+        }
+    }
     // chip throughput: waves per SIMD = 1, 2, 4, 8
     hipEvent_t s, e;
     CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
