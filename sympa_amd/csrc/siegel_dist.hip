@@ -51,8 +51,9 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     int st = 0;
     int64_t r1 = ii, r2 = ii;
     if (a.idx1 != nullptr) {
-        r1 = a.idx1[ii * a.idx1_stride];
-        r2 = a.idx2[ii * a.idx2_stride];
+        // index batches and outputs stream through once: non-temporal, so they do not evict table rows from L2
+        r1 = __builtin_nontemporal_load(a.idx1 + ii * a.idx1_stride);
+        r2 = __builtin_nontemporal_load(a.idx2 + ii * a.idx2_stride);
         if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) {
             st |= sympa::ST_BAD_INDEX;
             r1 = 0;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     }
     if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
     if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
-    if (live) a.out[i] = d;
+    if (live) __builtin_nontemporal_store(d, a.out + i);
 
     if (a.status != nullptr) {
         const int flagged = (live && st != 0) ? 1 : 0;

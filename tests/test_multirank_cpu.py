@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the forward metric.  The path shards by pair with no
+data-path collective, so what has to be right is the index logic: every rank
+derives its shard of each global batch from the same keyed RNG, the shards are disjoint, their union
+is the single-rank batch, DistributedSampler semantics hold, and the max-over-ranks timing reduction
+works.  (The kernels themselves need a GPU; the oracle stands in for the arithmetic here.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import siegel_oracle as so
+from sympa_amd import data
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nodes, n, batch = 200, 3, 256
+        table = data.trained_like_table(nodes, n, seed=42)           # replicated, identical bytes
+        glob = data.sample_pairs(nodes, batch * world, 5, seed=42)   # global batch 5
+        mine = glob[rank::world].contiguous()                        # bench.py's sharding
+        d = so.model_forward(table, mine, "upper", "riem")
+        # gather the shards on rank 0 (test-only collective) and compare with the single-rank result
+        outs = [torch.zeros_like(d) for _ in range(world)]
+        idxs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(outs, d)
+        dist.all_gather(idxs, mine)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # bench.py's max-over-ranks
+        # DistributedSampler semantics for a triplet list (train.py:105-110)
+        shard = data.distributed_sampler_indices(1001, world, rank, epoch=3, seed=0)
+        all_shards = [None] * world
+        dist.all_gather_object(all_shards, shard)
+        if rank == 0:
+            full = so.model_forward(table, glob, "upper", "riem")
+            merged = torch.empty_like(full)
+            merged_idx = torch.empty_like(glob)
+            for r in range(world):
+                merged[r::world] = outs[r]
+                merged_idx[r::world] = idxs[r]
+            results["union_equal"] = bool(torch.equal(merged_idx, glob))
+            results["dist_equal"] = bool(torch.equal(merged, full))
+            results["max"] = float(t.item())
+            flat = sorted(i for s in all_shards for i in s)
+            results["sampler_cover"] = sorted(set(flat)) == list(range(1001)) and len(flat) == 1002
+            results["sampler_sizes"] = [len(s) for s in all_shards]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_over_gloo():
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    assert results["union_equal"] and results["dist_equal"]
+    assert results["max"] == 2.0
+    assert results["sampler_cover"] and results["sampler_sizes"] == [501, 501]
