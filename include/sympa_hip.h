@@ -51,7 +51,8 @@ extern "C" {
 #define SYMPA_FLAG_LOW_LDS 1 /* stage one endpoint at a time: half the LDS per block, so blocks of two launches
                                 that overlap (different streams / independent graph nodes) share a CU */
 
-#define SYMPA_MAX_DIMS 8 /* largest n with a register-resident kernel in this build */
+#define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
+#define SYMPA_MAX_DIMS_BACKWARD 6 /* largest n with a backward kernel in this build */
 
 /* Library / build identification. */
 const char* sympa_version(void);
@@ -86,6 +87,28 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
                         const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                         const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
                         int32_t* status, int flags, void* stream);
+
+/* Backward of manifold.dist for pre-gathered points: what torch autograd computes through
+ * siegel_manifold.py:41-72 / bounded_domain.py:27-39 when runner.py:105 calls loss.backward().
+ *   grad_out          [b] fp64 dLoss/d(dist)
+ *   grad_z1, grad_z2  [b, 2, n, n] fp64, written (symmetric matrices, like the reference's gradients)
+ *   grad_w            [n] fp64 gradient of the wsum weights, ACCUMULATED (zero it first), or NULL
+ */
+int sympa_siegel_dist_bwd(const double* z1, const double* z2, const double* grad_out, int64_t b, int n, int model,
+                          int metric, const double* metric_w, double eps, double* grad_z1, double* grad_z2,
+                          double* grad_w, int32_t* status, int flags, void* stream);
+
+/* Backward of Model.forward (sympa/model.py:16-41 under runner.py:105): recomputes the distances and
+ * ACCUMULATES (fp64 atomics; zero the buffers first)
+ *   grad_table  [num_rows, 2, n, n]  the dense embeds.grad the reference's DDP all-reduces (train.py:59)
+ *   grad_w      [n]  wsum weights (or NULL),      grad_scale  [1]  model scale (or NULL)
+ * `out` (may be NULL) receives the forward values [b] again.
+ */
+int sympa_model_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                         const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
+                         const double* metric_w, double eps, const double* scale, double scale_coef,
+                         const double* grad_out, double* grad_table, double* grad_w, double* grad_scale,
+                         double* out, int32_t* status, int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,5 @@
-"""autograd glue for the hot path.  Forward = HIP kernel through the C-ABI.  The analytic backward
-kernel is SURVEY 8f-1 (next row); until it lands, differentiating through dist raises instead of
-silently falling back to torch ops."""
+"""autograd glue for the hot path: forward and backward are both HIP kernels behind the C-ABI.
+The backward kernels recompute the forward quantities (nothing but the inputs is saved)."""
 import torch
 
 from sympa_amd import ops
@@ -11,17 +10,22 @@ def _needs_grad(*tensors):
 
 
 class _SiegelDistFn(torch.autograd.Function):
+    """manifold.dist(z1, z2) with the analytic backward (sympa_siegel_dist_bwd)."""
+
     @staticmethod
     def forward(ctx, z1, z2, weights, model, metric):
-        ctx.save_for_backward(z1, z2, weights if weights is not None else torch.empty(0))
-        ctx.model, ctx.metric = model, metric
+        ctx.save_for_backward(z1, z2, weights if weights is not None else torch.empty(0, device=z1.device))
+        ctx.model, ctx.metric, ctx.has_w = model, metric, weights is not None
         return ops.siegel_dist_forward(z1, z2, model, metric, weights)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            "backward of the Siegel distance kernel is not built yet (SURVEY 8f-1); "
-            "run forward under torch.no_grad()")
+        z1, z2, w = ctx.saved_tensors
+        w = w if ctx.has_w else None
+        g1, g2, gw = ops.siegel_dist_backward(z1, z2, grad_out, ctx.model, ctx.metric, w)
+        if gw is not None and w is not None:
+            gw = gw.reshape(w.shape)
+        return g1, g2, (gw if ctx.has_w and ctx.metric == "wsum" else None), None, None
 
 
 def siegel_dist(z1, z2, model, metric, weights=None):
@@ -31,16 +35,31 @@ def siegel_dist(z1, z2, model, metric, weights=None):
 
 
 class _ModelForwardFn(torch.autograd.Function):
+    """Fused Model.forward with the scatter-add backward (sympa_model_backward): the gradient of the
+    table is the dense [N,2,n,n] tensor the reference's DDP all-reduces (train.py:59, runner.py:105)."""
+
     @staticmethod
     def forward(ctx, table, triplets, weights, scale, model, metric, scale_coef):
-        ctx.save_for_backward(table, triplets)
+        dev = table.device
+        ctx.save_for_backward(table, triplets, weights if weights is not None else torch.empty(0, device=dev),
+                              scale if scale is not None else torch.empty(0, device=dev))
+        ctx.cfg = (model, metric, scale_coef, weights is not None, scale is not None)
         return ops.model_forward(table, triplets, model, metric, weights, scale, scale_coef)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            "backward of the fused Model.forward kernel is not built yet (SURVEY 8f-1); "
-            "run forward under torch.no_grad()")
+        table, triplets, w, scale = ctx.saved_tensors
+        model, metric, scale_coef, has_w, has_scale = ctx.cfg
+        w = w if has_w else None
+        scale = scale if has_scale else None
+        gt, gw, gs = ops.model_backward(table, triplets, grad_out, model, metric, w, scale, scale_coef)
+        if gw is not None and w is not None:
+            gw = gw.reshape(w.shape)
+        if gs is not None and scale is not None:
+            gs = gs.reshape(scale.shape)
+        return (gt if ctx.needs_input_grad[0] else None, None,
+                gw if (has_w and metric == "wsum" and ctx.needs_input_grad[2]) else None,
+                gs if (has_scale and ctx.needs_input_grad[3]) else None, None, None, None)
 
 
 def model_forward(table, triplets, model, metric, weights=None, scale=None, scale_coef=1.0):

@@ -1,0 +1,416 @@
+// Analytic backward of the Siegel distance, per pair, same compile-twice scheme as
+// siegel_math.hpp (hipcc for the kernels, g++ for tests/hostsim).
+//
+// It replaces what the reference obtains from torch autograd through eigh / inverse / bmm
+// (runner.py:105 `loss.backward()` over siegel_manifold.py:41-72): given go = dLoss/d(dist) it returns
+// the SYMMETRIC matrix gradients dLoss/dZ1, dLoss/dZ2 (real and imaginary planes), i.e. exactly the
+// tensors autograd puts into `embeds.grad` rows (the reference's gradients are symmetric to 1e-12,
+// tests/golden/autograd_*.npz), plus the gradient of the wsum weights.
+//
+// With E = L1^-1 D L2^-T (upper; D = Z2 - Z1, Y_k = L_k L_k^T) or E = C1^-1 D C2^-T (bounded;
+// D = W2 - W1, A_k = I - W_k W_k^H = C_k C_k^H), H = E^H E = V diag(lambda) V^H, out = m(v(lambda)):
+//   phi_i  = go * dm/dv_i * dv/dlambda_i                      dv/dlambda' = 1/sqrt(lambda'(1+lambda'))
+//   Hbar   = V diag(phi) V^H,   K = V diag(phi lambda) V^H = Hbar H
+//   Ebar   = 2 E Hbar,          G = E Hbar E^H
+//   Dbar   = L1^-H Ebar conj(L2)^-1                            (conj only matters for complex factors)
+//   L1bar  = -2 tril(L1^-H G),  L2bar = -2 tril(L2^-H conj(K))
+//   Abar_k = herm( L_k^-H Phi(L_k^H Lbar_k) L_k^-1 )           Phi: lower triangle, diagonal halved
+//   upper  : Ybar_k += Abar_k (real);    X2bar += Re Dbar, Y2bar += Im Dbar, X1bar -= ..., Y1bar -= ...
+//   bounded: Wbar_k  = -/+ Dbar - 2 Abar_k W_k
+// and finally every plane is symmetrised.  Derivation and the numpy prototype that was checked against
+// the reference's autograd to 1e-11: DESIGN.md section 9.  Eigenvectors come from the same Jacobi
+// iteration with the rotations accumulated, run to ||off|| <= 1e-11 ||diag|| (no finishing shortcut).
+#pragma once
+
+#include "siegel_math.hpp"
+
+namespace sympa {
+
+// ---------------------------------------------------------------------------------------------
+// Jacobi with eigenvectors: H <- J^H H J, V <- V J.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD void jacobi_rotate_vec(Herm<N>& h, CMat<N>& v, const int p, const int q) {
+    const double br = h.re[p][q], bi = h.im[p][q];
+    const double a2 = d_fma(br, br, bi * bi);
+    const double delta = h.d[q] - h.d[p];
+    const double ad = fabs(delta) + 1e-150;
+    const double qr = d_rsqrt(d_fma(ad, ad, 4.0 * a2));
+    const double c2 = d_fma(0.5 * ad, qr, 0.5);
+    const double ic = d_rsqrt(c2);
+    const double c = c2 * ic;
+    const double cu = copysign(qr, delta) * ic;
+    const double ua2 = (cu * ic) * a2;
+    const double wr = cu * br, wi = cu * bi;
+    h.d[p] -= ua2;
+    h.d[q] += ua2;
+    h.re[p][q] = 0.0;
+    h.im[p][q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (k == p || k == q) continue;
+        double xr, xi, yr, yi;
+        if (k < p) { xr = h.re[k][p]; xi = h.im[k][p]; } else { xr = h.re[p][k]; xi = -h.im[p][k]; }
+        if (k < q) { yr = h.re[k][q]; yi = h.im[k][q]; } else { yr = h.re[q][k]; yi = -h.im[q][k]; }
+        const double nxr = d_fma(-wi, yi, d_fma(-wr, yr, c * xr));
+        const double nxi = d_fma(wi, yr, d_fma(-wr, yi, c * xi));
+        const double nyr = d_fma(-wi, xi, d_fma(wr, xr, c * yr));
+        const double nyi = d_fma(wi, xr, d_fma(wr, xi, c * yi));
+        if (k < p) { h.re[k][p] = nxr; h.im[k][p] = nxi; } else { h.re[p][k] = nxr; h.im[p][k] = -nxi; }
+        if (k < q) { h.re[k][q] = nyr; h.im[k][q] = nyi; } else { h.re[q][k] = nyr; h.im[q][k] = -nyi; }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {   // columns p, q of V
+        const double xr = v.re[k][p], xi = v.im[k][p], yr = v.re[k][q], yi = v.im[k][q];
+        v.re[k][p] = d_fma(-wi, yi, d_fma(-wr, yr, c * xr));
+        v.im[k][p] = d_fma(wi, yr, d_fma(-wr, yi, c * xi));
+        v.re[k][q] = d_fma(-wi, xi, d_fma(wr, xr, c * yr));
+        v.im[k][q] = d_fma(wi, xr, d_fma(wr, xi, c * yi));
+    }
+}
+
+constexpr double JACOBI_VEC_TOL2 = 1e-22;
+
+template <int N>
+SYMPA_HD bool herm_eigen_vectors(Herm<N>& h, CMat<N>& v) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) { v.re[i][j] = (i == j) ? 1.0 : 0.0; v.im[i][j] = 0.0; }
+    if (N == 1) return true;
+    bool conv = false;
+    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        double off2, diag2;
+        herm_norms<N>(h, off2, diag2);
+        conv = !(off2 > JACOBI_VEC_TOL2 * diag2);
+        if (wave_all(conv)) break;
+        if (N == 4) {
+            jacobi_rotate_vec<N>(h, v, 0, 1); jacobi_rotate_vec<N>(h, v, 2, 3);
+            jacobi_rotate_vec<N>(h, v, 0, 2); jacobi_rotate_vec<N>(h, v, 1, 3);
+            jacobi_rotate_vec<N>(h, v, 0, 3); jacobi_rotate_vec<N>(h, v, 1, 2);
+        } else {
+#pragma unroll
+            for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+                for (int q = p + 1; q < N; ++q) jacobi_rotate_vec<N>(h, v, p, q);
+            }
+        }
+    }
+    return conv;
+}
+
+// out_jk = sum_i s_i V_ji conj(V_ki)    (full Hermitian matrix, both triangles)
+template <int N>
+SYMPA_HD void herm_from_eig(const CMat<N>& v, const double (&s)[N], CMat<N>& out) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int k = j; k < N; ++k) {
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double ar = s[i] * v.re[j][i], ai = s[i] * v.im[j][i];
+                tr = d_fma(ar, v.re[k][i], tr);
+                tr = d_fma(ai, v.im[k][i], tr);
+                ti = d_fma(ai, v.re[k][i], ti);
+                ti = d_fma(-ar, v.im[k][i], ti);
+            }
+            out.re[j][k] = tr; out.im[j][k] = (j == k) ? 0.0 : ti;
+            out.re[k][j] = tr; out.im[k][j] = (j == k) ? 0.0 : -ti;
+        }
+    }
+}
+
+// c = alpha * a * b
+template <int N>
+SYMPA_HD void cmatmul(const CMat<N>& a, const CMat<N>& b, double alpha, CMat<N>& c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                tr = d_fma(a.re[i][k], b.re[k][j], tr);
+                tr = d_fma(-a.im[i][k], b.im[k][j], tr);
+                ti = d_fma(a.re[i][k], b.im[k][j], ti);
+                ti = d_fma(a.im[i][k], b.re[k][j], ti);
+            }
+            c.re[i][j] = alpha * tr;
+            c.im[i][j] = alpha * ti;
+        }
+}
+
+// c = alpha * a * b^H
+template <int N>
+SYMPA_HD void cmatmul_bh(const CMat<N>& a, const CMat<N>& b, double alpha, CMat<N>& c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {   // a_ik conj(b_jk)
+                tr = d_fma(a.re[i][k], b.re[j][k], tr);
+                tr = d_fma(a.im[i][k], b.im[j][k], tr);
+                ti = d_fma(a.im[i][k], b.re[j][k], ti);
+                ti = d_fma(-a.re[i][k], b.im[j][k], ti);
+            }
+            c.re[i][j] = alpha * tr;
+            c.im[i][j] = alpha * ti;
+        }
+}
+
+// Element (i, j) of the lower-triangular factor as a complex number (diagonal = 1 / rdiag, real).
+template <int N, bool COMPLEX>
+SYMPA_HD void tri_elem(const Tri<N, COMPLEX>& l, const double (&diag)[N], int i, int j, double& re, double& im) {
+    if (i == j) { re = diag[i]; im = 0.0; }
+    else { re = l.re[i][j]; im = COMPLEX ? l.im[i][j] : 0.0; }
+}
+
+// X <- L^-H X   (back substitution, column by column)
+template <int N, bool COMPLEX>
+SYMPA_HD void solve_lh_left(const Tri<N, COMPLEX>& l, CMat<N>& x) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i) {
+            double tr = x.re[i][c], ti = x.im[i][c];
+#pragma unroll
+            for (int k = i + 1; k < N; ++k) {   // (L^H)_ik = conj(L_ki)
+                tr = d_fma(-l.re[k][i], x.re[k][c], tr);
+                ti = d_fma(-l.re[k][i], x.im[k][c], ti);
+                if (COMPLEX) {
+                    tr = d_fma(-l.im[k][i], x.im[k][c], tr);
+                    ti = d_fma(l.im[k][i], x.re[k][c], ti);
+                }
+            }
+            x.re[i][c] = tr * l.rdiag[i];
+            x.im[i][c] = ti * l.rdiag[i];
+        }
+    }
+}
+
+// X <- X M^-1 with M = L (CONJ = false) or conj(L) (CONJ = true); row by row, columns from the right
+template <int N, bool COMPLEX, bool CONJ>
+SYMPA_HD void solve_l_right(const Tri<N, COMPLEX>& l, CMat<N>& x) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int j = N - 1; j >= 0; --j) {
+            double tr = x.re[r][j], ti = x.im[r][j];
+#pragma unroll
+            for (int k = j + 1; k < N; ++k) {   // minus x_rk M_kj
+                const double mi = COMPLEX ? (CONJ ? -l.im[k][j] : l.im[k][j]) : 0.0;
+                tr = d_fma(-x.re[r][k], l.re[k][j], tr);
+                ti = d_fma(-x.im[r][k], l.re[k][j], ti);
+                if (COMPLEX) {
+                    tr = d_fma(x.im[r][k], mi, tr);
+                    ti = d_fma(-x.re[r][k], mi, ti);
+                }
+            }
+            x.re[r][j] = tr * l.rdiag[j];
+            x.im[r][j] = ti * l.rdiag[j];
+        }
+    }
+}
+
+// Cholesky adjoint.  In: L (factor), M (full matrix; only tril(L^-H M) enters), scale.  Computes
+//   Lbar = scale * tril(L^-H M),  P = Phi(L^H Lbar),  Abar = herm(L^-H P L^-1)
+// and returns Abar as a full Hermitian matrix.
+template <int N, bool COMPLEX>
+SYMPA_HD void chol_adjoint(const Tri<N, COMPLEX>& l, CMat<N>& m, double scale, CMat<N>& abar) {
+    double diag[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) diag[i] = d_rcp(l.rdiag[i]);
+    solve_lh_left<N, COMPLEX>(l, m);           // m = L^-H M
+    // Lbar = scale * tril(m)
+    // P = Phi(L^H Lbar):  P_ij = sum_{k >= max(i,j)} conj(L_ki) Lbar_kj,  for i >= j
+    CMat<N> p;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double tr = 0.0, ti = 0.0;
+            if (i >= j) {
+#pragma unroll
+                for (int k = i; k < N; ++k) {
+                    double lr, li;
+                    tri_elem<N, COMPLEX>(l, diag, k, i, lr, li);
+                    const double br = scale * m.re[k][j], bi = COMPLEX ? scale * m.im[k][j] : 0.0;
+                    // conj(L_ki) * Lbar_kj
+                    tr = d_fma(lr, br, tr);
+                    if (COMPLEX) {
+                        tr = d_fma(li, bi, tr);
+                        ti = d_fma(lr, bi, ti);
+                        ti = d_fma(-li, br, ti);
+                    }
+                }
+                if (i == j) { tr *= 0.5; ti = 0.0; }
+            }
+            p.re[i][j] = tr;
+            p.im[i][j] = ti;
+        }
+    // S = L^-H P L^-1
+    solve_lh_left<N, COMPLEX>(l, p);
+    solve_l_right<N, COMPLEX, false>(l, p);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            abar.re[i][j] = 0.5 * (p.re[i][j] + p.re[j][i]);
+            abar.im[i][j] = COMPLEX ? 0.5 * (p.im[i][j] - p.im[j][i]) : 0.0;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pair: forward value + gradients.  g1, g2: symmetric matrix gradients w.r.t. Z1, Z2 (both planes);
+// gw[k] += d out / d w_k * go for the wsum metric (k = rank of the eigenvalue, ascending).
+// ---------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
+                              double inv_eps, double go, CMat<N>& g1, CMat<N>& g2, double (&gw)[N], int& status) {
+    constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
+    Tri<N, CPLX> l1, l2;
+    CMat<N> e;
+    bool ok;
+    if constexpr (MODEL == MODEL_UPPER) {
+        ok = chol_real<N>(z1.im, l1);
+        ok = chol_real<N>(z2.im, l2) && ok;
+    } else {
+        ok = chol_id_minus_wwh<N>(z1, l1);
+        ok = chol_id_minus_wwh<N>(z2, l2) && ok;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+            e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+        }
+    solve_left<N, CPLX>(l1, e);
+    solve_right_t<N, CPLX>(l2, e);
+    Herm<N> h;
+    gram<N>(e, h);
+    CMat<N> v;
+    const bool conv = herm_eigen_vectors<N>(h, v);
+
+    const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
+    double vv[N], dv[N], lam[N];
+    int rank[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        lam[i] = fmax(h.d[i], 0.0);
+        const double lp = lam[i] * scale;
+        const double root = d_sqrt(d_fma(lp, lp, lp));       // sqrt(lp (1 + lp))
+        double u = 2.0 * (lp + root);
+        double deriv = (lp > 0.0) ? scale * d_rcp(root + TINY) : 0.0;     // dv/dlambda = scale / sqrt(lp(1+lp))
+        if (u >= inv_eps - 1.0) {
+            const double ilp = d_rcp(1.0 + lp);
+            const double d = d_sqrt(lp * ilp);
+            const double clamped = d_fma(1.0 + d, inv_eps, -1.0);
+            if (clamped < u) {   // v = log((1 + d) / eps):  dv/dlp = 1 / ((1 + d) 2 d (1 + lp)^2)
+                u = clamped;
+                deriv = scale * d_rcp((1.0 + d) * 2.0 * d) * ilp * ilp;
+            }
+        }
+        vv[i] = d_log1p(u);
+        dv[i] = deriv;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {   // ascending rank, ties broken by index
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) r += (vv[j] < vv[i] || (vv[j] == vv[i] && j < i)) ? 1 : 0;
+        rank[i] = r;
+    }
+    double out = 0.0, vbar[N];
+    if (metric == METRIC_RIEM) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) out = d_fma(vv[i], vv[i], out);
+        out = d_sqrt(out);
+        const double inv = (out > 0.0) ? d_rcp(out) : 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) vbar[i] = vv[i] * inv;
+    } else if (metric == METRIC_FONE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { out += vv[i]; vbar[i] = 1.0; }
+    } else if (metric == METRIC_FINF) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const bool top = rank[i] == N - 1; vbar[i] = top ? 1.0 : 0.0; out += top ? vv[i] : 0.0; }
+    } else if (metric == METRIC_FMIN) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { vbar[i] = 2.0 * rank[i]; out = d_fma(vbar[i], vv[i], out); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double wk = w[rank[i]];
+            vbar[i] = fmax(wk, 0.0);
+            out = d_fma(vbar[i], vv[i], out);
+#pragma unroll
+            for (int k = 0; k < N; ++k) gw[k] += (rank[i] == k && wk > 0.0) ? go * vv[i] : 0.0;
+        }
+    }
+    double phi[N], philam[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { phi[i] = go * vbar[i] * dv[i]; philam[i] = phi[i] * h.d[i]; }
+
+    CMat<N> hbar, ebar, gm, km;
+    herm_from_eig<N>(v, phi, hbar);
+    herm_from_eig<N>(v, philam, km);          // K = Hbar H
+    cmatmul<N>(e, hbar, 2.0, ebar);           // Ebar = 2 E Hbar
+    cmatmul_bh<N>(ebar, e, 0.5, gm);          // G = E Hbar E^H
+    // Dbar = L1^-H Ebar conj(L2)^-1
+    solve_lh_left<N, CPLX>(l1, ebar);
+    solve_l_right<N, CPLX, true>(l2, ebar);
+    if (CPLX) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) km.im[i][j] = -km.im[i][j];    // conj(K)
+    }
+    CMat<N> a1, a2;
+    chol_adjoint<N, CPLX>(l1, gm, -2.0, a1);
+    chol_adjoint<N, CPLX>(l2, km, -2.0, a2);
+
+    if (MODEL == MODEL_UPPER) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double dr = 0.5 * (ebar.re[i][j] + ebar.re[j][i]);
+                const double di = 0.5 * (ebar.im[i][j] + ebar.im[j][i]);
+                g2.re[i][j] = dr;
+                g2.im[i][j] = di + a2.re[i][j];
+                g1.re[i][j] = -dr;
+                g1.im[i][j] = -di + a1.re[i][j];
+            }
+    } else {
+        // Wbar_1 = -Dbar - 2 A1bar W1,  Wbar_2 = Dbar - 2 A2bar W2, then symmetrise each plane
+        CMat<N> t1, t2;
+        cmatmul<N>(a1, z1, -2.0, t1);
+        cmatmul<N>(a2, z2, -2.0, t2);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                t1.re[i][j] -= ebar.re[i][j]; t1.im[i][j] -= ebar.im[i][j];
+                t2.re[i][j] += ebar.re[i][j]; t2.im[i][j] += ebar.im[i][j];
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                g1.re[i][j] = 0.5 * (t1.re[i][j] + t1.re[j][i]);
+                g1.im[i][j] = 0.5 * (t1.im[i][j] + t1.im[j][i]);
+                g2.re[i][j] = 0.5 * (t2.re[i][j] + t2.re[j][i]);
+                g2.im[i][j] = 0.5 * (t2.im[i][j] + t2.im[j][i]);
+            }
+    }
+    if (!ok) status |= ST_NOT_PD;
+    if (!conv) status |= ST_NO_CONVERGENCE;
+    if (!(out == out) || !(fabs(out) <= 1.79e308)) status |= ST_NONFINITE;
+    return out;
+}
+
+}  // namespace sympa

@@ -148,3 +148,69 @@ def model_forward(table, triplets, model="upper", metric="riem", weights=None, s
     if _debug:
         check_status(tab.device)
     return out
+
+
+def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None):
+    """Backward of manifold.dist for pre-gathered points (C-ABI sympa_siegel_dist_bwd).
+    Returns (grad_z1, grad_z2, grad_weights or None): what torch autograd produces through the
+    reference's dist (runner.py:105 over siegel_manifold.py:41-72)."""
+    lib = _lib.load()
+    _need_gpu(z1, "z1"); _need_gpu(z2, "z2"); _need_gpu(grad_out, "grad_out")
+    z1 = z1.detach().contiguous()
+    z2 = z2.detach().contiguous()
+    go = grad_out.detach().to(torch.float64).contiguous()
+    b, _, n, _ = z1.shape
+    g1 = torch.empty_like(z1)
+    g2 = torch.empty_like(z2)
+    w = _weights(metric, weights, n, z1.device)
+    gw = torch.zeros(n, dtype=torch.float64, device=z1.device) if metric == "wsum" else None
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(z1.device)
+    if b > 0:
+        with torch.cuda.device(z1.device):
+            rc = lib.sympa_siegel_dist_bwd(_ptr(z1), _ptr(z2), _ptr(go), b, n, MODEL_IDS[model], METRIC_IDS[metric],
+                                           _ptr(w), eps, _ptr(g1), _ptr(g2), _ptr(gw), _ptr(st), 0, _stream())
+        _lib.check(rc)
+    if _debug:
+        check_status(z1.device)
+    return g1, g2, gw
+
+
+def model_backward(table, triplets, grad_out, model="upper", metric="riem", weights=None, scale=None,
+                   scale_coef=1.0, eps=None, grad_table=None):
+    """Backward of the fused Model.forward (C-ABI sympa_model_backward): scatter-adds the two gradient
+    rows of every pair into a dense [N,2,n,n] gradient (created zeroed unless `grad_table` is given, in
+    which case it accumulates), returns (grad_table, grad_weights or None, grad_scale or None)."""
+    lib = _lib.load()
+    _need_gpu(table, "table"); _need_gpu(triplets, "triplets"); _need_gpu(grad_out, "grad_out")
+    tab = table.detach()
+    if not tab.is_contiguous():
+        tab = tab.contiguous()
+    num_rows, _, n, _ = tab.shape
+    b = triplets.shape[0]
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    go = grad_out.detach().to(torch.float64).contiguous()
+    if grad_table is None:
+        grad_table = torch.zeros_like(tab)
+    w = _weights(metric, weights, n, tab.device)
+    gw = torch.zeros(n, dtype=torch.float64, device=tab.device) if metric == "wsum" else None
+    sc = gs = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
+        gs = torch.zeros(1, dtype=torch.float64, device=tab.device)
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(tab.device)
+    if b > 0:
+        src_ptr = ctypes.c_void_p(triplets.data_ptr())
+        dst_ptr = ctypes.c_void_p(triplets.data_ptr() + 8)
+        with torch.cuda.device(tab.device):
+            rc = lib.sympa_model_backward(_ptr(tab), num_rows, n, src_ptr, stride, dst_ptr, stride, b,
+                                          MODEL_IDS[model], METRIC_IDS[metric], _ptr(w), eps, _ptr(sc),
+                                          float(scale_coef), _ptr(go), _ptr(grad_table), _ptr(gw), _ptr(gs), None,
+                                          _ptr(st), 0, _stream())
+        _lib.check(rc)
+    if _debug:
+        check_status(tab.device)
+    return grad_table, gw, gs

@@ -57,7 +57,8 @@ def hostsim():
     if _hostsim is None:
         d = os.path.join(ROOT, "tests", "hostsim")
         so = os.path.join(d, "libsympa_hostsim.so")
-        srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp")]
+        srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp"),
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], cwd=d)
         _hostsim = ctypes.CDLL(so)
@@ -79,3 +80,24 @@ def hostsim_dist(z1, z2, model, metric, weights=None, eps=1e-5):
                                 ctypes.c_double(eps), P(out.ctypes.data), P(vvd.ctypes.data), ctypes.byref(st))
     assert rc == 0, rc
     return out, vvd, st.value
+
+
+def hostsim_dist_bwd(z1, z2, go, model, metric, weights=None, eps=1e-5):
+    lib = hostsim()
+    P = ctypes.c_void_p
+    z1 = np.ascontiguousarray(z1, dtype=np.float64)
+    z2 = np.ascontiguousarray(z2, dtype=np.float64)
+    go = np.ascontiguousarray(go, dtype=np.float64)
+    b, _, n, _ = z1.shape
+    out = np.zeros(b)
+    g1 = np.zeros_like(z1)
+    g2 = np.zeros_like(z2)
+    gw = np.zeros(n)
+    st = ctypes.c_int32(0)
+    w = np.ascontiguousarray(np.ones(n) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1))
+    rc = lib.sympa_hostsim_dist_bwd(P(z1.ctypes.data), P(z2.ctypes.data), P(go.ctypes.data), ctypes.c_int64(b), n,
+                                    MODELS.index(model), METRICS.index(metric), P(w.ctypes.data), ctypes.c_double(eps),
+                                    P(out.ctypes.data), P(g1.ctypes.data), P(g2.ctypes.data), P(gw.ctypes.data),
+                                    ctypes.byref(st))
+    assert rc == 0, rc
+    return out, g1, g2, gw, st.value

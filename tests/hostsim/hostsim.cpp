@@ -4,6 +4,7 @@
 // path fails loudly when the HIP library is missing.
 #include <cstdint>
 #include "../../sympa_amd/csrc/siegel_math.hpp"
+#include "../../sympa_amd/csrc/siegel_math_bwd.hpp"
 
 namespace {
 template <int N>
@@ -33,6 +34,49 @@ extern "C" int sympa_hostsim_dist(const double* z1, const double* z2, int64_t b,
         case 6: run<6>(z1, z2, b, model, metric, w, eps, out, vvd, status); return 0;
         case 7: run<7>(z1, z2, b, model, metric, w, eps, out, vvd, status); return 0;
         case 8: run<8>(z1, z2, b, model, metric, w, eps, out, vvd, status); return 0;
+        default: return -2;
+    }
+}
+
+namespace {
+template <int N>
+void run_bwd(const double* z1, const double* z2, const double* go, int64_t b, int model, int metric, const double* w,
+             double eps, double* out, double* g1, double* g2, double* gw, int32_t* status) {
+    int st = 0;
+    double gwacc[N];
+    for (int k = 0; k < N; ++k) gwacc[k] = 0.0;
+    for (int64_t i = 0; i < b; ++i) {
+        sympa::CMat<N> a, c, ga, gc;
+        sympa::load_point<N>(z1 + i * 2 * N * N, a);
+        sympa::load_point<N>(z2 + i * 2 * N * N, c);
+        out[i] = (model == sympa::MODEL_UPPER)
+                     ? sympa::pair_backward<N, sympa::MODEL_UPPER>(a, c, metric, w, 1.0 / eps, go[i], ga, gc, gwacc, st)
+                     : sympa::pair_backward<N, sympa::MODEL_BOUNDED>(a, c, metric, w, 1.0 / eps, go[i], ga, gc, gwacc, st);
+        for (int r = 0; r < N; ++r)
+            for (int s = 0; s < N; ++s) {
+                g1[i * 2 * N * N + r * N + s] = ga.re[r][s];
+                g1[i * 2 * N * N + N * N + r * N + s] = ga.im[r][s];
+                g2[i * 2 * N * N + r * N + s] = gc.re[r][s];
+                g2[i * 2 * N * N + N * N + r * N + s] = gc.im[r][s];
+            }
+    }
+    for (int k = 0; k < N; ++k) gw[k] = gwacc[k];
+    if (status) *status = st;
+}
+}  // namespace
+
+extern "C" int sympa_hostsim_dist_bwd(const double* z1, const double* z2, const double* go, int64_t b, int n, int model,
+                                      int metric, const double* w, double eps, double* out, double* g1, double* g2,
+                                      double* gw, int32_t* status) {
+    switch (n) {
+        case 1: run_bwd<1>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 2: run_bwd<2>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 3: run_bwd<3>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 4: run_bwd<4>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 5: run_bwd<5>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 6: run_bwd<6>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 7: run_bwd<7>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 8: run_bwd<8>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         default: return -2;
     }
 }
