@@ -110,6 +110,18 @@ int sympa_model_backward(const double* table, int64_t num_rows, int n, const int
                          const double* grad_out, double* grad_table, double* grad_w, double* grad_scale,
                          double* out, int32_t* status, int flags, void* stream);
 
+/* One fused training step of the reference's loop (sympa/runner.py:98-105 with sympa/losses.py:10-19):
+ *   d = Model.forward(triplets);  loss = loss_scale * sum |(d / graph_dist)^2 - 1|;  loss.backward()
+ * in ONE kernel: distances, loss (accumulated into loss[0]), and the gradients of the table, of the wsum
+ * weights and of the scale (all ACCUMULATED: zero them first, or keep accumulating over grad-accum steps;
+ * loss_scale = 1 / grad_accum_steps, runner.py:104).  graph_dist: [b] fp64.  `out` (may be NULL): d.
+ */
+int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                              const int64_t* dst, int64_t dst_stride, const double* graph_dist, int64_t b, int model,
+                              int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
+                              double loss_scale, double* loss, double* grad_table, double* grad_w, double* grad_scale,
+                              double* out, int32_t* status, int flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

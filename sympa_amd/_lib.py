@@ -18,6 +18,7 @@ SYMBOLS = (
     "sympa_model_forward",
     "sympa_siegel_dist_bwd",
     "sympa_model_backward",
+    "sympa_model_loss_backward",
 )
 
 _c_double_p = ctypes.c_void_p
@@ -69,6 +70,13 @@ def load():
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
         _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+    ]
+    lib.sympa_model_loss_backward.restype = ctypes.c_int
+    lib.sympa_model_loss_backward.argtypes = [
+        _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
+        ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int,
+        ctypes.c_void_p,
     ]
     _lib = lib
     return lib

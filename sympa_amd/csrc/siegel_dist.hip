@@ -106,6 +106,9 @@ struct BwdArgs {
     double* g2;              // dense [b,2,n,n] or the grad table
     double* gw;              // [n] accumulated, or null
     double* gscale;          // [1] accumulated, or null
+    const double* graph_dist;   // fused loss: [b] graph distances (then `go` is ignored), or null
+    double* loss;               // fused loss: [1] accumulated sum |(d/g)^2 - 1| * loss_scale
+    double loss_scale;
 };
 
 template <int N>
@@ -180,13 +183,37 @@ __global__ __launch_bounds__(BLOCK) void siegel_bwd_kernel(const BwdArgs a) {
         sc_active = raw > 0.1;
         sc = sc_active ? raw : 0.1;
     }
-    const double go = live ? a.go[i] : 0.0;
     sympa::CMat<N> g1, g2;
     double gw[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) gw[k] = 0.0;
-    const double dist = sympa::pair_backward<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, go * sc, g1, g2, gw, st);
+    // every gradient is linear in go: run the adjoint with go = 1 and scale afterwards (the fused loss
+    // needs the distance before it knows go)
+    const double dist = sympa::pair_backward<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, 1.0, g1, g2, gw, st);
     const bool bad = (st & sympa::ST_BAD_INDEX) != 0;
+    double go = 0.0, loss_i = 0.0;
+    if (a.graph_dist != nullptr) {   // AverageDistortionLoss (losses.py:10-19): sum |(d/g)^2 - 1|
+        const double gd = live ? a.graph_dist[i] : 1.0;
+        const double ratio = dist * sc / gd;
+        const double e = ratio * ratio - 1.0;
+        loss_i = (live && !bad) ? fabs(e) * a.loss_scale : 0.0;
+        go = (e > 0.0 ? 1.0 : (e < 0.0 ? -1.0 : 0.0)) * 2.0 * ratio / gd * a.loss_scale;
+        if (!live) go = 0.0;
+    } else {
+        go = live ? a.go[i] : 0.0;
+    }
+    {
+        const double gs_ = go * sc;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                g1.re[r][c] *= gs_; g1.im[r][c] *= gs_;
+                g2.re[r][c] *= gs_; g2.im[r][c] *= gs_;
+            }
+#pragma unroll
+        for (int k = 0; k < N; ++k) gw[k] *= gs_;
+    }
     if (live && f.out != nullptr) f.out[i] = bad ? __builtin_nan("") : dist * sc;
 
     if constexpr (SCATTER) {
@@ -219,6 +246,12 @@ __global__ __launch_bounds__(BLOCK) void siegel_bwd_kernel(const BwdArgs a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
         if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.gscale, x);
+    }
+    if (a.loss != nullptr && a.graph_dist != nullptr) {
+        double x = loss_i;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.loss, x);
     }
     if (f.status != nullptr) {
         const int flagged = (live && st != 0) ? 1 : 0;
@@ -311,7 +344,8 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     const int rc = validate(a.f, model);
     if (rc != 0) return rc;
     if (a.f.b == 0) return 0;
-    if (a.go == nullptr || a.g1 == nullptr || a.g2 == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null gradient buffer");
+    if ((a.go == nullptr && a.graph_dist == nullptr) || a.g1 == nullptr || a.g2 == nullptr)
+        return fail(SYMPA_ERR_BAD_ARG, "null gradient buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
         case 1: return launch_bwd_n<1>(a, model, scatter, s);
@@ -434,6 +468,43 @@ int sympa_model_backward(const double* table, int64_t num_rows, int n, const int
     a.g2 = grad_table;
     a.gw = grad_w;
     a.gscale = grad_scale;
+    return launch_bwd(a, n, model, true, stream);
+}
+
+int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                              const int64_t* dst, int64_t dst_stride, const double* graph_dist, int64_t b, int model,
+                              int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
+                              double loss_scale, double* loss, double* grad_table, double* grad_w, double* grad_scale,
+                              double* out, int32_t* status, int flags, void* stream) {
+    if (b > 0 && (src == nullptr || dst == nullptr || graph_dist == nullptr))
+        return fail(SYMPA_ERR_BAD_ARG, "null index / graph-distance buffer");
+    if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    BwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.f.base1 = table;
+    a.f.base2 = table;
+    a.f.idx1 = src;
+    a.f.idx2 = dst;
+    a.f.idx1_stride = src_stride;
+    a.f.idx2_stride = dst_stride;
+    a.f.num_rows = num_rows;
+    a.f.b = b;
+    a.f.metric_w = metric_w;
+    a.f.scale = scale;
+    a.f.inv_scale_coef = 1.0 / scale_coef;
+    a.f.inv_eps = 1.0 / eps;
+    a.f.out = out;
+    a.f.status = status;
+    a.f.metric = metric;
+    a.f.flags = flags;
+    a.g1 = grad_table;
+    a.g2 = grad_table;
+    a.gw = grad_w;
+    a.gscale = grad_scale;
+    a.graph_dist = graph_dist;
+    a.loss = loss;
+    a.loss_scale = loss_scale;
     return launch_bwd(a, n, model, true, stream);
 }
 

@@ -30,6 +30,35 @@ class Model(nn.Module):
         return sa.model_forward(self.embeddings.embeds, input_triplet, man.model_name, man.metric.kind.value,
                                 weights, self.scale, self.scale_coef)
 
+    def fused_loss_backward(self, input_triplet, graph_distances, loss_scale=1.0):
+        """Extension (not in the reference API): the body of Runner.train_epoch's inner loop
+        (runner.py:101-105: forward, AverageDistortionLoss / grad_accum_steps, loss.backward()) as ONE
+        HIP kernel.  Accumulates into the parameters' .grad exactly like loss.backward() and returns the
+        loss as a 1-element device tensor (no host sync)."""
+        from sympa_amd import ops
+        man = self.manifold
+        table = self.embeddings.embeds
+        dev = table.device
+        if table.grad is None:
+            table.grad = torch.zeros_like(table.data)
+        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
+        weights = gw = None
+        if wsum:
+            weights = man.metric.weights
+            if weights.grad is None:
+                weights.grad = torch.zeros_like(weights.data)
+            gw = weights.grad
+        gs = None
+        if self.scale.requires_grad:
+            if self.scale.grad is None:
+                self.scale.grad = torch.zeros_like(self.scale.data)
+            gs = self.scale.grad
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward(table.data, input_triplet, graph_distances, table.grad, loss, man.model_name,
+                                man.metric.kind.value, None if weights is None else weights.data, gw, self.scale.data,
+                                gs, self.scale_coef, loss_scale)
+        return loss
+
     def distance(self, src_embeds, dst_embeds):   # model.py:32-38
         return self.manifold.dist(src_embeds, dst_embeds)
 

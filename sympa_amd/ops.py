@@ -29,11 +29,14 @@ def set_debug(flag: bool):
 
 
 def _status_buf(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    buf = _status.get(idx)
+    buf = _status.get(device)
     if buf is None:
-        buf = torch.zeros(2, dtype=torch.int32, device=device)
-        _status[idx] = buf
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        buf = _status.get(idx)
+        if buf is None:
+            buf = torch.zeros(2, dtype=torch.int32, device=device)
+            _status[idx] = buf
+        _status[device] = buf
     return buf
 
 
@@ -111,44 +114,54 @@ def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=
 def model_forward(table, triplets, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0,
                   eps=None, out=None, flags=0):
     """Fused Model.forward (C-ABI sympa_model_forward; reference model.py:16-41): gathers table rows
-    triplets[:,0] / triplets[:,1] inside the kernel, returns dist * clamp_min(scale/scale_coef, 0.1)."""
+    triplets[:,0] / triplets[:,1] inside the kernel, returns dist * clamp_min(scale/scale_coef, 0.1).
+    The argument checks are kept cheap: this is called once per batch and the kernel takes ~8 us."""
     lib = _lib.load()
-    _need_gpu(table, "table"); _need_gpu(triplets, "triplets")
+    if not (table.is_cuda and triplets.is_cuda):
+        _need_gpu(table, "table"); _need_gpu(triplets, "triplets")
     if table.dtype != torch.float64:
         raise TypeError("table must be float64")
     if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
         raise TypeError("triplets must be an int64 [b, >=2] tensor (src, dst[, graph_distance])")
-    if table.dim() != 4 or table.shape[1] != 2 or table.shape[2] != table.shape[3]:
-        raise ValueError(f"table must be [N,2,n,n], got {tuple(table.shape)}")
-    tab = table.detach()
-    if not tab.is_contiguous():
-        tab = tab.contiguous()
-    num_rows, _, n, _ = tab.shape
+    shape = table.shape
+    if len(shape) != 4 or shape[1] != 2 or shape[2] != shape[3]:
+        raise ValueError(f"table must be [N,2,n,n], got {tuple(shape)}")
+    tab = table if table.is_contiguous() else table.contiguous()
+    num_rows, n = shape[0], shape[2]
     b = triplets.shape[0]
     if triplets.stride(1) != 1:
         triplets = triplets.contiguous()
     stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    dev = tab.device
     if out is None:
-        out = torch.empty(b, dtype=torch.float64, device=tab.device)
+        out = torch.empty(b, dtype=torch.float64, device=dev)
     if b == 0:
         return out
-    w = _weights(metric, weights, n, tab.device)
-    sc = None
+    w = _weights(metric, weights, n, dev) if metric == "wsum" else None
+    sc_ptr = None
     if scale is not None:
-        sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
-    eps = EPS[torch.float64] if eps is None else float(eps)
-    st = _status_buf(tab.device)
-    src_ptr = ctypes.c_void_p(triplets.data_ptr())
-    dst_ptr = ctypes.c_void_p(triplets.data_ptr() + 8)
-    with torch.cuda.device(tab.device):
-        rc = lib.sympa_model_forward(_ptr(tab), num_rows, n, src_ptr, stride, dst_ptr, stride, b,
-                                     MODEL_IDS[model], METRIC_IDS[metric], _ptr(w), eps, _ptr(sc),
-                                     float(scale_coef), _ptr(out), _ptr(st), int(flags), _stream())
-    _lib.check(rc)
+        sc = scale
+        if sc.device != dev or sc.dtype != torch.float64:
+            sc = sc.detach().to(device=dev, dtype=torch.float64)
+        sc_ptr = sc.data_ptr()
+    eps = 1e-5 if eps is None else float(eps)
+    st = _status_buf(dev)
+    tp = triplets.data_ptr()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = lib.sympa_model_forward(tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, b,
+                                         MODEL_IDS[model], METRIC_IDS[metric], None if w is None else w.data_ptr(),
+                                         eps, sc_ptr, float(scale_coef), out.data_ptr(), st.data_ptr(), int(flags), stream)
+    else:
+        rc = lib.sympa_model_forward(tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, b,
+                                     MODEL_IDS[model], METRIC_IDS[metric], None if w is None else w.data_ptr(),
+                                     eps, sc_ptr, float(scale_coef), out.data_ptr(), st.data_ptr(), int(flags), stream)
+    if rc != 0:
+        _lib.check(rc)
     if _debug:
-        check_status(tab.device)
+        check_status(dev)
     return out
-
 
 def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None):
     """Backward of manifold.dist for pre-gathered points (C-ABI sympa_siegel_dist_bwd).
@@ -214,3 +227,44 @@ def model_backward(table, triplets, grad_out, model="upper", metric="riem", weig
     if _debug:
         check_status(tab.device)
     return grad_table, gw, gs
+
+
+def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="upper", metric="riem", weights=None,
+                        grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None):
+    """Fused training step (C-ABI sympa_model_loss_backward): distances + AverageDistortionLoss + all
+    gradients in one kernel.  `grad_table` [N,2,n,n], `loss` [1] (and `grad_weights` [n], `grad_scale` [1]
+    when given) are ACCUMULATED into, like autograd's .grad."""
+    lib = _lib.load()
+    tab = table if table.is_contiguous() else table.contiguous()
+    num_rows, n = tab.shape[0], tab.shape[2]
+    b = triplets.shape[0]
+    if b == 0:
+        return loss
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    dev = tab.device
+    if not (tab.is_cuda and triplets.is_cuda and graph_dist.is_cuda):
+        _need_gpu(tab, "table"); _need_gpu(triplets, "triplets"); _need_gpu(graph_dist, "graph_dist")
+    gd = graph_dist if (graph_dist.dtype == torch.float64 and graph_dist.is_contiguous()) \
+        else graph_dist.to(torch.float64).contiguous()
+    w = _weights(metric, weights, n, dev) if metric == "wsum" else None
+    sc_ptr = None
+    if scale is not None:
+        sc = scale if (scale.device == dev and scale.dtype == torch.float64) else scale.detach().to(dev, torch.float64)
+        sc_ptr = sc.data_ptr()
+    eps = 1e-5 if eps is None else float(eps)
+    st = _status_buf(dev)
+    tp = triplets.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.sympa_model_loss_backward(
+            tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, gd.data_ptr(), b, MODEL_IDS[model],
+            METRIC_IDS[metric], None if w is None else w.data_ptr(), eps, sc_ptr, float(scale_coef), float(loss_scale),
+            loss.data_ptr(), grad_table.data_ptr(), None if grad_weights is None else grad_weights.data_ptr(),
+            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), 0,
+            torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _lib.check(rc)
+    if _debug:
+        check_status(dev)
+    return loss

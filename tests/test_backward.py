@@ -184,3 +184,42 @@ def test_gpu_model_backward_scatter_and_loss(dev, model):
     assert relmax(out.detach().cpu(), ref.detach()) < 1e-9
     assert relmax(m.embeddings.embeds.grad.cpu(), sym(table.grad)) < 1e-6
     assert relmax(m.scale.grad.cpu(), scale.grad) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,metric", [("upper", "riem"), ("bounded", "wsum")])
+def test_gpu_fused_training_step_equals_autograd_step(dev, model, metric):
+    """Model.fused_loss_backward (one kernel) == Model.forward + AverageDistortionLoss + loss.backward()
+    (the autograd path above), including gradient accumulation over two calls (runner.py:104-118)."""
+    from sympa_amd.losses import AverageDistortionLoss
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, dims, num_points = model, 3, 40
+        scale_coef, scale_init, train_scale = 1.0, 1.3, True
+    A.metric = metric
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(1)
+    m1, m2 = Model(A), Model(A)
+    pts = points(model, 40, 3, 0.3, g)
+    for m in (m1, m2):
+        with torch.no_grad():
+            m.embeddings.embeds.data = pts.clone()
+            if metric == "wsum":
+                m.manifold.metric.weights.copy_(torch.tensor([[0.7, -0.2, 1.1]]))
+    m1, m2 = m1.to(dev), m2.to(dev)
+    total1 = 0.0
+    total2 = torch.zeros(1, dtype=torch.float64, device=dev)
+    for rep in range(2):
+        trip = torch.stack((torch.randint(0, 40, (300,), generator=g), torch.randint(0, 40, (300,), generator=g)), 1)
+        trip = trip[trip[:, 0] != trip[:, 1]].to(dev)
+        gd = torch.randint(1, 9, (trip.shape[0],), generator=g).to(torch.float64).to(dev)
+        loss = AverageDistortionLoss().calculate_loss(gd, m1(trip)) / 2
+        loss.backward()
+        total1 += float(loss)
+        total2 += m2.fused_loss_backward(trip, gd, loss_scale=0.5)
+    assert abs(float(total2) - total1) < 1e-9 * abs(total1)
+    assert relmax(m2.embeddings.embeds.grad.cpu(), m1.embeddings.embeds.grad.cpu()) < 1e-10
+    assert relmax(m2.scale.grad.cpu(), m1.scale.grad.cpu()) < 1e-10
+    if metric == "wsum":
+        assert relmax(m2.manifold.metric.weights.grad.cpu(), m1.manifold.metric.weights.grad.cpu()) < 1e-10
