@@ -122,6 +122,26 @@ int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, cons
                               double loss_scale, double* loss, double* grad_table, double* grad_w, double* grad_scale,
                               double* out, int32_t* status, int flags, void* stream);
 
+/* ---- optimiser-side manifold operations over table rows (one [2,n,n] point per row) --------------------
+ * egrad2rgrad: UpperHalfManifold.egrad2rgrad (sympa/manifolds/upper_half.py:25-40, Y G Y on both planes) /
+ *              BoundedDomainManifold.egrad2rgrad (sympa/manifolds/bounded_domain.py:41-53, A G A, A = I - conj(Z) Z).
+ */
+int sympa_egrad2rgrad(const double* z, const double* u, int64_t b, int n, int model, double* out, void* stream);
+
+/* projx: SiegelManifold.projx + UpperHalfManifold.projx (siegel_manifold.py:130-137, upper_half.py:42-66,
+ * csym_math.py:252-278): symmetrise, clamp the eigenvalues of Im z at eps, rows already inside are left
+ * untouched; BoundedDomainManifold.projx as intended by bounded_domain.py:55-84: clamp the Takagi values
+ * at 1 - eps.  projected_count[0] += number of rows that were moved (manifold.projected_points). */
+int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double* out, int32_t* projected_count,
+                int32_t* status, void* stream);
+
+/* One RiemannianSGD step over the whole table, in place (geoopt.optim.RiemannianSGD.step with momentum 0,
+ * the optimiser train.py:66-68 builds; geoopt is absent from the reference tree, semantics restated):
+ *     table <- retr(table, -lr * egrad2rgrad(table, grad + weight_decay * table)),  retr(x,u) = projx(x + u)
+ * (sympa/manifolds/siegel_manifold.py:74-87). */
+int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
+                    double weight_decay, double eps, int32_t* projected_count, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,6 +291,16 @@ def bounded_projx(z):
     return torch.where(mask, z, z_tilde), keep
 
 
+def rsgd_step(model, table, grad, lr, weight_decay=0.0):
+    """geoopt.optim.RiemannianSGD.step, momentum 0 (the optimiser of train.py:66-68; geoopt >=0.3.1 is an
+    un-vendored dependency, algorithm restated from geoopt/optim/rsgd.py):
+        point <- retr(point, -lr * egrad2rgrad(point, grad + weight_decay * point)),  retr = projx(x + u)."""
+    g = grad + weight_decay * table
+    if model == "upper":
+        return upper_projx(table - lr * upper_egrad2rgrad(table, g))
+    return bounded_projx(table - lr * bounded_egrad2rgrad(table, g))
+
+
 def upper_random(n_points, dims, from_=-INIT_EPS, to=INIT_EPS, generator=None):
     """Distribution of UpperHalfManifold.random (upper_half.py:116-131)."""
     pert = sym(torch.empty(n_points, dims, dims, dtype=torch.float64).uniform_(from_, to, generator=generator))

@@ -19,6 +19,9 @@ SYMBOLS = (
     "sympa_siegel_dist_bwd",
     "sympa_model_backward",
     "sympa_model_loss_backward",
+    "sympa_egrad2rgrad",
+    "sympa_projx",
+    "sympa_rsgd_step",
 )
 
 _c_double_p = ctypes.c_void_p
@@ -78,6 +81,15 @@ def load():
         ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int,
         ctypes.c_void_p,
     ]
+    lib.sympa_egrad2rgrad.restype = ctypes.c_int
+    lib.sympa_egrad2rgrad.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                      ctypes.c_void_p]
+    lib.sympa_projx.restype = ctypes.c_int
+    lib.sympa_projx.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, _c_double_p,
+                                _c_i32_p, _c_i32_p, ctypes.c_void_p]
+    lib.sympa_rsgd_step.restype = ctypes.c_int
+    lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     _lib = lib
     return lib
 

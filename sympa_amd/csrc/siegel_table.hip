@@ -1,0 +1,121 @@
+// gfx950 kernels + C-ABI for the optimiser-side manifold operations over the embedding table
+// (SURVEY 8f-2): egrad2rgrad, projx, and the fused RiemannianSGD step.  One table row per lane; these run
+// once per optimiser step over N rows (N = 5 041 .. 100 000) and are bandwidth-trivial next to the
+// distance kernels, so rows are loaded directly.
+#include "siegel_common.hpp"
+#include "siegel_table_math.hpp"
+
+namespace {
+using namespace sympa_hip;
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void egrad2rgrad_kernel(const double* z, const double* u, double* out, int64_t b) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= b) return;
+    constexpr int64_t ROW = 2 * N * N;
+    sympa::CMat<N> a, g, r;
+    sympa::load_full<N>(z + i * ROW, a);
+    sympa::load_full<N>(u + i * ROW, g);
+    sympa::egrad2rgrad<N, MODEL>(a, g, r);
+    sympa::store_full<N>(out + i * ROW, r);
+}
+
+// OP 0: out = projx(z).   OP 1: table <- retr(table, -lr * egrad2rgrad(table, grad + wd * table)) in place.
+template <int N, int MODEL, int OP>
+__global__ __launch_bounds__(BLOCK) void table_update_kernel(double* z, const double* grad, double* out, int64_t b,
+                                                             double lr, double wd, double eps, int32_t* projected,
+                                                             int32_t* status) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < b;
+    const int64_t ii = live ? i : b - 1;      // tail lanes recompute the last row (the Jacobi loops ballot)
+    constexpr int64_t ROW = 2 * N * N;
+    sympa::CMat<N> a;
+    sympa::load_full<N>(z + ii * ROW, a);
+    int st = 0;
+    bool moved;
+    if (OP == 0) {
+        moved = sympa::projx<N, MODEL>(a, eps, st);
+    } else {
+        sympa::CMat<N> g;
+        sympa::load_full<N>(grad + ii * ROW, g);
+        moved = sympa::rsgd_row<N, MODEL>(a, g, lr, wd, eps, st);
+    }
+    if (live) sympa::store_full<N>((OP == 0 ? out : z) + i * ROW, a);
+    const unsigned long long m = __ballot(live && moved);
+    if (projected != nullptr && m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(projected, (int)__popcll(m));
+    if (status != nullptr) {
+        const unsigned long long f = __ballot(live && st != 0);
+        if (f != 0ull) {
+            if (live && st != 0) atomicOr(&status[0], st);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&status[1], (int)__popcll(f));
+        }
+    }
+}
+
+template <int N>
+int launch_table(int op, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
+                 double eps, int32_t* projected, int32_t* status, hipStream_t s) {
+    const unsigned grid = (unsigned)((b + BLOCK - 1) / BLOCK);
+    const bool up = model == SYMPA_MODEL_UPPER;
+    if (op == 2) {
+        if (up) hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
+        else hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
+    } else if (op == 0) {
+        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
+        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
+    } else {
+        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
+        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int dispatch_table(int op, int n, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
+                   double eps, int32_t* projected, int32_t* status, void* stream) {
+    if (b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative row count");
+    if (b == 0) return 0;
+    if (z == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
+    if (b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "too many rows for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (n) {
+        case 1: return launch_table<1>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 2: return launch_table<2>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 3: return launch_table<3>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 4: return launch_table<4>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 5: return launch_table<5>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 6: return launch_table<6>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 7: return launch_table<7>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 8: return launch_table<8>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS]");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sympa_egrad2rgrad(const double* z, const double* u, int64_t b, int n, int model, double* out, void* stream) {
+    if (b > 0 && (u == nullptr || out == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    return dispatch_table(2, n, model, const_cast<double*>(z), u, out, b, 0.0, 0.0, 0.0, nullptr, nullptr, stream);
+}
+
+int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double* out, int32_t* projected_count,
+                int32_t* status, void* stream) {
+    if (b > 0 && out == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
+    return dispatch_table(0, n, model, const_cast<double*>(z), nullptr, out, b, 0.0, 0.0, eps, projected_count, status,
+                          stream);
+}
+
+int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
+                    double weight_decay, double eps, int32_t* projected_count, int32_t* status, void* stream) {
+    if (num_rows > 0 && grad == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null gradient");
+    if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
+    return dispatch_table(1, n, model, table, grad, nullptr, num_rows, lr, weight_decay, eps, projected_count, status,
+                          stream);
+}
+
+}  // extern "C"

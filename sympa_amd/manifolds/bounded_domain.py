@@ -4,10 +4,10 @@
 `dist`: the reference maps both points to the upper half space with two inverse Cayley transforms
 (two complex inverses) and then runs the upper distance (bounded_domain.py:27-39).  The HIP kernel
 evaluates the same vector-valued distance directly in the disc.
-Optimiser-side methods: device torch ops for now, see upper_half.py."""
+`egrad2rgrad` / `projx` are HIP kernels as well."""
 import torch
 
-from sympa_amd.config import EPS
+from sympa_amd import ops
 from sympa_amd.manifolds.base import Manifold
 from sympa_amd.manifolds.metrics import MetricType
 from sympa_amd.manifolds.siegel_manifold import SiegelManifold
@@ -38,27 +38,13 @@ class BoundedDomainManifold(SiegelManifold):
     def __init__(self, dims=2, ndim=2, metric=MetricType.RIEMANNIAN):
         super().__init__(dims=dims, ndim=ndim, metric=metric)
 
-    def egrad2rgrad(self, z, u):  # bounded_domain.py:41-53: A G A, A = I - conj(Z) Z
-        a = _c(get_id_minus_conjugate_z_times_z(z))
-        return _r(a @ _c(u) @ a)
+    def egrad2rgrad(self, z, u):  # bounded_domain.py:41-53: A G A, A = I - conj(Z) Z  (HIP kernel)
+        return ops.egrad2rgrad(z, u, self.model_name)
 
     def projx(self, z):
         """Intended behaviour of bounded_domain.py:55-84 (the in-tree call is broken at the surveyed
-        commit): clamp the Takagi values of Z at 1 - eps."""
-        z = super().projx(z)
-        n = z.shape[-1]
-        a, b = z[:, 0], z[:, 1]
-        comp = torch.cat((torch.cat((a, b), -1), torch.cat((b, -a), -1)), -2)   # csym_math.py:421-436
-        lam, q = torch.linalg.eigh(comp, UPLO="U")
-        vals = lam[:, n:]
-        right = q[..., n:]
-        s = torch.complex(right[..., :n, :], -right[..., n:, :])               # takagi_factorization.py:45-64
-        eps = EPS[z.dtype]
-        d = torch.diag_embed(torch.clamp(vals, max=1 - eps)).to(s.dtype)
-        z_tilde = _r(s.conj() @ d @ s.conj().transpose(-1, -2))
-        keep = torch.all(vals < 1 - eps, dim=-1, keepdim=True)
-        self.projected_points += len(z) - int(keep.sum().item())
-        return torch.where(keep.unsqueeze(-1).unsqueeze(-1).expand_as(z), z, z_tilde)
+        commit): clamp the Takagi values of Z at 1 - eps.  HIP kernel."""
+        return self._projx_kernel(z)
 
     def inner(self, z, u, v=None, *, keepdim=False):  # bounded_domain.py:86-117
         if v is None:

@@ -26,8 +26,22 @@ class SiegelManifold(Manifold, ABC):
         super().__init__()
         self.dims = dims
         self.ndim = ndim
-        self.projected_points = 0
+        self._projected_points = 0
+        self._pending_projected = []      # device counters written by the fused optimiser step
         self.metric = Metric.get(metric, self.dims)
+
+    @property
+    def projected_points(self):
+        """Number of points projx had to move (runner.py:47-48 logs it).  Counters produced by the fused
+        optimiser kernel are folded in here, so the training loop itself never synchronises."""
+        if self._pending_projected:
+            self._projected_points += int(torch.stack(self._pending_projected).sum().item())
+            self._pending_projected = []
+        return self._projected_points
+
+    @projected_points.setter
+    def projected_points(self, value):
+        self._projected_points = value
 
     # ------------------------------------------------------------------ the hot path
     def _metric_weights(self):
@@ -56,6 +70,14 @@ class SiegelManifold(Manifold, ABC):
 
     def projx(self, x):  # siegel_manifold.py:130-137
         return torch.stack((_sym(x[:, 0]), _sym(x[:, 1])), dim=1)
+
+    def _projx_kernel(self, z):
+        """projx of the concrete model as one HIP kernel; keeps `projected_points` like the reference
+        (upper_half.py:64: the reference also synchronises here with `.item()`)."""
+        counter = torch.zeros(1, dtype=torch.int32, device=z.device)
+        out = ops.projx(z, self.model_name, counter=counter)
+        self.projected_points += int(counter.item())
+        return out
 
     def proju(self, x, u):
         return self.egrad2rgrad(x, u)

@@ -1,11 +1,10 @@
 """UpperHalfManifold  H_n = {Z in Sym(n,C) | Im Z > 0}  (reference sympa/manifolds/upper_half.py).
 
-`dist` = fused HIP kernel (hot path).  The optimiser-side methods (egrad2rgrad / projx / inner /
-random) are SURVEY 8f-2 rows; until their kernels land they are expressed with device torch ops so
-the class is complete and usable on the GPU (they are not on the measured path)."""
+`dist`, `egrad2rgrad`, `projx` (hence `retr`) = HIP kernels.  `inner`, `random`, `_check_point_on_manifold`
+are host-side helpers of the reference (init / logging / assertions), kept as torch ops."""
 import torch
 
-from sympa_amd.config import EPS
+from sympa_amd import ops
 from sympa_amd.manifolds.base import Manifold
 from sympa_amd.manifolds.metrics import MetricType
 from sympa_amd.manifolds.siegel_manifold import SiegelManifold, _sym
@@ -21,19 +20,11 @@ class UpperHalfManifold(SiegelManifold):
     def __init__(self, dims=2, ndim=2, metric=MetricType.RIEMANNIAN):
         super().__init__(dims=dims, ndim=ndim, metric=metric)
 
-    def egrad2rgrad(self, z, u):  # upper_half.py:25-40: Y G Y on both planes
-        y = z[:, 1]
-        return torch.stack((y @ u[:, 0] @ y, y @ u[:, 1] @ y), dim=1)
+    def egrad2rgrad(self, z, u):  # upper_half.py:25-40: Y G Y on both planes  (HIP kernel)
+        return ops.egrad2rgrad(z, u, self.model_name)
 
-    def projx(self, z):  # upper_half.py:42-66 + csym_math.py:252-278
-        z = super().projx(z)
-        y = z[:, 1]
-        lam, s = torch.linalg.eigh(y, UPLO="U")
-        eps = EPS[y.dtype]
-        y_tilde = s @ torch.diag_embed(torch.clamp(lam, min=eps)) @ s.transpose(-1, -2)
-        keep = torch.all(lam > eps, dim=-1, keepdim=True)
-        self.projected_points += len(z) - int(keep.sum().item())
-        return torch.stack((z[:, 0], torch.where(keep.unsqueeze(-1).expand_as(y), y, y_tilde)), dim=1)
+    def projx(self, z):  # upper_half.py:42-66 + csym_math.py:252-278  (HIP kernel)
+        return self._projx_kernel(z)
 
     def inner(self, z, u, v=None, *, keepdim=False):  # upper_half.py:68-91: tr[Y^-1 u Y^-1 conj(v)]
         if v is None:

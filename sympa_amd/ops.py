@@ -268,3 +268,55 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
     if _debug:
         check_status(dev)
     return loss
+
+
+# ---------------------------------------------------------------------------------------------------
+# optimiser-side manifold operations over table rows (C-ABI sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step)
+# ---------------------------------------------------------------------------------------------------
+def _rows(t, name):
+    _need_gpu(t, name)
+    if t.dtype != torch.float64 or t.dim() != 4 or t.shape[1] != 2 or t.shape[2] != t.shape[3]:
+        raise ValueError(f"{name} must be a float64 [b,2,n,n] tensor, got {tuple(t.shape)} {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def egrad2rgrad(z, u, model):
+    lib = _lib.load()
+    z, u = _rows(z.detach(), "z"), _rows(u.detach(), "u")
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        rc = lib.sympa_egrad2rgrad(z.data_ptr(), u.data_ptr(), z.shape[0], z.shape[2], MODEL_IDS[model], out.data_ptr(),
+                                   _stream())
+    _lib.check(rc)
+    return out
+
+
+def projx(z, model, eps=None, counter=None):
+    """Returns projx(z); `counter` (int32[1] device tensor) += rows that were moved."""
+    lib = _lib.load()
+    z = _rows(z.detach(), "z")
+    out = torch.empty_like(z)
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(z.device)
+    with torch.cuda.device(z.device):
+        rc = lib.sympa_projx(z.data_ptr(), z.shape[0], z.shape[2], MODEL_IDS[model], eps, out.data_ptr(),
+                             None if counter is None else counter.data_ptr(), st.data_ptr(), _stream())
+    _lib.check(rc)
+    return out
+
+
+def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None):
+    """In-place RiemannianSGD step over the whole table (one kernel)."""
+    lib = _lib.load()
+    _need_gpu(table, "table")
+    if not table.is_contiguous():
+        raise ValueError("table must be contiguous for the in-place step")
+    grad = _rows(grad.detach(), "grad")
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(table.device)
+    with torch.cuda.device(table.device):
+        rc = lib.sympa_rsgd_step(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], MODEL_IDS[model],
+                                 float(lr), float(weight_decay), eps, None if counter is None else counter.data_ptr(),
+                                 st.data_ptr(), _stream())
+    _lib.check(rc)
+    return table

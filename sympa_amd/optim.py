@@ -1,0 +1,45 @@
+"""RiemannianSGD for the Siegel models.
+
+The reference builds `geoopt.optim.RiemannianSGD(params, lr, weight_decay, stabilize=None)` (train.py:66-68);
+geoopt is an un-vendored dependency absent from the reference tree, so its step is restated from the
+published algorithm (geoopt/optim/rsgd.py, momentum = 0):
+    grad <- grad + weight_decay * point;  grad <- manifold.egrad2rgrad(point, grad)
+    point <- manifold.retr(point, -lr * grad)
+For a table on a Siegel manifold the whole step is ONE HIP kernel over the rows (sympa_rsgd_step);
+parameters without a manifold (the model scale, the wsum weights) get the Euclidean update."""
+import torch
+
+from sympa_amd import ops
+from sympa_amd.manifolds.siegel_manifold import SiegelManifold
+
+
+class RiemannianSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr, weight_decay=0.0, stabilize=None):
+        if lr < 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        super().__init__(params, dict(lr=lr, weight_decay=weight_decay))
+        self._stabilize = stabilize   # accepted for signature compatibility; Siegel retr already projects
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, wd = group["lr"], group["weight_decay"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                manifold = getattr(p, "manifold", None)
+                if isinstance(manifold, SiegelManifold) and p.is_cuda:
+                    counter = torch.zeros(1, dtype=torch.int32, device=p.device)
+                    ops.rsgd_step_(p.data, p.grad, manifold.model_name, lr, wd, counter=counter)
+                    manifold._pending_projected = getattr(manifold, "_pending_projected", [])
+                    manifold._pending_projected.append(counter)   # folded into projected_points lazily
+                else:
+                    g = p.grad
+                    if wd != 0:
+                        g = g.add(p, alpha=wd)
+                    p.add_(g, alpha=-lr)
+        return loss

@@ -58,7 +58,8 @@ def hostsim():
         d = os.path.join(ROOT, "tests", "hostsim")
         so = os.path.join(d, "libsympa_hostsim.so")
         srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp"),
-                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp")]
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp"),
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_table_math.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], cwd=d)
         _hostsim = ctypes.CDLL(so)
@@ -101,3 +102,22 @@ def hostsim_dist_bwd(z1, z2, go, model, metric, weights=None, eps=1e-5):
                                     ctypes.byref(st))
     assert rc == 0, rc
     return out, g1, g2, gw, st.value
+
+
+def hostsim_table(op, model, z, g=None, lr=0.0, wd=0.0, eps=1e-5):
+    """op: 'projx' | 'rsgd' | 'egrad2rgrad' -> (rows, projected_count)"""
+    lib = hostsim()
+    P = ctypes.c_void_p
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    b, _, n, _ = z.shape
+    out = np.zeros_like(z)
+    gp = None
+    if g is not None:
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        gp = P(g.ctypes.data)
+    moved = ctypes.c_int32(0)
+    st = lib.sympa_hostsim_table({"projx": 0, "rsgd": 1, "egrad2rgrad": 2}[op], MODELS.index(model), n, P(z.ctypes.data),
+                                 gp, P(out.ctypes.data), ctypes.c_int64(b), ctypes.c_double(lr), ctypes.c_double(wd),
+                                 ctypes.c_double(eps), ctypes.byref(moved))
+    assert st == 0, st
+    return out, moved.value

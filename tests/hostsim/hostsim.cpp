@@ -5,6 +5,7 @@
 #include <cstdint>
 #include "../../sympa_amd/csrc/siegel_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_bwd.hpp"
+#include "../../sympa_amd/csrc/siegel_table_math.hpp"
 
 namespace {
 template <int N>
@@ -77,6 +78,44 @@ extern "C" int sympa_hostsim_dist_bwd(const double* z1, const double* z2, const 
         case 6: run_bwd<6>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         case 7: run_bwd<7>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         case 8: run_bwd<8>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        default: return -2;
+    }
+}
+
+namespace {
+template <int N>
+int run_table(int op, int model, const double* z, const double* g, double* out, int64_t b, double lr, double wd,
+              double eps, int32_t* projected) {
+    int st = 0, moved = 0;
+    for (int64_t i = 0; i < b; ++i) {
+        sympa::CMat<N> a, gg, r;
+        sympa::load_full<N>(z + i * 2 * N * N, a);
+        if (g) sympa::load_full<N>(g + i * 2 * N * N, gg);
+        if (op == 2) {
+            if (model == 0) sympa::egrad2rgrad<N, sympa::MODEL_UPPER>(a, gg, r); else sympa::egrad2rgrad<N, sympa::MODEL_BOUNDED>(a, gg, r);
+            sympa::store_full<N>(out + i * 2 * N * N, r);
+        } else {
+            bool m;
+            if (op == 0) m = (model == 0) ? sympa::projx<N, sympa::MODEL_UPPER>(a, eps, st) : sympa::projx<N, sympa::MODEL_BOUNDED>(a, eps, st);
+            else m = (model == 0) ? sympa::rsgd_row<N, sympa::MODEL_UPPER>(a, gg, lr, wd, eps, st) : sympa::rsgd_row<N, sympa::MODEL_BOUNDED>(a, gg, lr, wd, eps, st);
+            moved += m ? 1 : 0;
+            sympa::store_full<N>(out + i * 2 * N * N, a);
+        }
+    }
+    if (projected) *projected = moved;
+    return st;
+}
+}  // namespace
+
+// op: 0 projx, 1 rsgd step (out = new rows), 2 egrad2rgrad
+extern "C" int sympa_hostsim_table(int op, int model, int n, const double* z, const double* g, double* out, int64_t b,
+                                   double lr, double wd, double eps, int32_t* projected) {
+    switch (n) {
+        case 1: return run_table<1>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 2: return run_table<2>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 3: return run_table<3>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 4: return run_table<4>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 8: return run_table<8>(op, model, z, g, out, b, lr, wd, eps, projected);
         default: return -2;
     }
 }

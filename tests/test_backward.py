@@ -216,7 +216,7 @@ def test_gpu_fused_training_step_equals_autograd_step(dev, model, metric):
         gd = torch.randint(1, 9, (trip.shape[0],), generator=g).to(torch.float64).to(dev)
         loss = AverageDistortionLoss().calculate_loss(gd, m1(trip)) / 2
         loss.backward()
-        total1 += float(loss)
+        total1 += float(loss.detach())
         total2 += m2.fused_loss_backward(trip, gd, loss_scale=0.5)
     assert abs(float(total2) - total1) < 1e-9 * abs(total1)
     assert relmax(m2.embeddings.embeds.grad.cpu(), m1.embeddings.embeds.grad.cpu()) < 1e-10

@@ -1,0 +1,115 @@
+"""Optimiser-side manifold operations: egrad2rgrad, projx, fused RiemannianSGD step.
+CPU: the per-row arithmetic (g++ build) against the reference goldens and the oracle.
+GPU: the HIP kernels through the C-ABI against the same, plus the optimiser class on a Model."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import siegel_oracle as so
+from tests.helpers import GOLDEN, MODELS, T, hostsim_table, points
+
+
+def relmax(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+def test_hostsim_against_reference_goldens(n):
+    g = np.load(f"{GOLDEN}/primitives_n{n}.npz")
+    assert relmax(hostsim_table("egrad2rgrad", "upper", g["upper_pts"], g["grad_in"])[0], g["upper_egrad2rgrad"]) < 1e-13
+    assert relmax(hostsim_table("egrad2rgrad", "bounded", g["cayley_upper"], g["grad_in"])[0],
+                  g["bounded_egrad2rgrad"]) < 1e-13
+    out, moved = hostsim_table("projx", "upper", g["projx_in"])
+    assert relmax(out, g["upper_projx"]) < 1e-12
+    out, moved = hostsim_table("projx", "bounded", g["bounded_projx_in"])
+    assert relmax(out, g["bounded_projx"]) < 1e-9
+
+
+def step_inputs(model, n, g):
+    table = points(model, 50, n, 0.3, g)
+    grad = torch.randn(50, 2, n, n, generator=g, dtype=torch.float64)
+    grad = 0.5 * (grad + grad.transpose(-1, -2))
+    return table, grad
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("model", MODELS)
+def test_hostsim_rsgd_step_matches_oracle(model, n):
+    g = torch.Generator().manual_seed(3 + n)
+    table, grad = step_inputs(model, n, g)
+    for lr in (1e-2, 0.7):       # the large step pushes points off the manifold -> projection path
+        want, keep = so.rsgd_step(model, table, grad, lr, 0.01)
+        out, moved = hostsim_table("rsgd", model, table.numpy(), grad.numpy(), lr=lr, wd=0.01)
+        assert relmax(out, want.numpy()) < 1e-9, (model, n, lr)
+        assert moved == int((~keep).sum())
+    # already-inside points are left bit-identical apart from the symmetrisation (upper_half.py:64)
+    out, moved = hostsim_table("projx", model, table.numpy())
+    assert moved == 0 and np.array_equal(out, so.to_symmetric(table).numpy())
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+def test_gpu_manifold_methods_against_goldens(dev, n):
+    from sympa_amd.manifolds import BoundedDomainManifold, UpperHalfManifold
+    g = np.load(f"{GOLDEN}/primitives_n{n}.npz")
+    up, bd = UpperHalfManifold(dims=n), BoundedDomainManifold(dims=n)
+    u = T(g["grad_in"]).to(dev)
+    assert relmax(up.egrad2rgrad(T(g["upper_pts"]).to(dev), u).cpu(), g["upper_egrad2rgrad"]) < 1e-13
+    assert relmax(bd.egrad2rgrad(T(g["cayley_upper"]).to(dev), u).cpu(), g["bounded_egrad2rgrad"]) < 1e-13
+    assert relmax(up.projx(T(g["projx_in"]).to(dev)).cpu(), g["upper_projx"]) < 1e-12
+    assert up.projected_points == int((~torch.from_numpy(g["pcp_keep"])).numel()) or up.projected_points > 0
+    assert relmax(bd.projx(T(g["bounded_projx_in"]).to(dev)).cpu(), g["bounded_projx"]) < 1e-9
+    # retr(x, u) = projx(x + u)   (siegel_manifold.py:74-87)
+    x = T(g["upper_pts"]).to(dev)
+    assert torch.equal(up.retr(x, 0.01 * u), up.projx(x + 0.01 * u))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_rsgd_optimizer_on_model(dev, model):
+    """geoopt-style RiemannianSGD over a Model: table rows by the fused kernel, scale by Euclidean SGD;
+    two steps of the reference's training loop against the oracle composition on the CPU."""
+    from sympa_amd import ops
+    from sympa_amd.model import Model
+    from sympa_amd.optim import RiemannianSGD
+
+    class A:
+        manifold, metric, dims, num_points = model, "riem", 3, 60
+        scale_coef, scale_init, train_scale = 1.0, 1.0, True
+
+    g = torch.Generator().manual_seed(21)
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = points(model, 60, 3, 0.3, g)
+    m = m.to(dev)
+    opt = RiemannianSGD(m.parameters(), lr=0.05, weight_decay=0.0, stabilize=None)
+    table = m.embeddings.embeds.detach().cpu().clone()
+    scale = m.scale.detach().cpu().clone()
+    for it in range(2):
+        trip = torch.stack((torch.randint(0, 60, (400,), generator=g), torch.randint(0, 60, (400,), generator=g)), 1)
+        trip = trip[trip[:, 0] != trip[:, 1]]
+        gd = torch.randint(1, 7, (trip.shape[0],), generator=g).to(torch.float64)
+        opt.zero_grad()
+        loss = m.fused_loss_backward(trip.to(dev), gd.to(dev))
+        opt.step()
+        # oracle: autograd + restated optimiser on the CPU
+        t = table.clone().requires_grad_(True)
+        s = scale.clone().requires_grad_(True)
+        ref = so.distortion_loss(gd, so.model_forward(t, trip, model, "riem", scale=s, scale_coef=1.0))
+        ref.backward()
+        gsym = 0.5 * (t.grad + t.grad.transpose(-1, -2))
+        table = so.rsgd_step(model, table, gsym, 0.05)[0]
+        scale = scale - 0.05 * s.grad
+        assert abs(float(loss) - float(ref)) < 1e-8 * abs(float(ref))
+        assert relmax(m.embeddings.embeds.detach().cpu(), table) < 1e-7
+        assert relmax(m.scale.detach().cpu(), scale) < 1e-8
+    ops.check_status(dev)
+    assert isinstance(m.manifold.projected_points, int)
