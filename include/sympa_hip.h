@@ -88,6 +88,14 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
                         const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
                         int32_t* status, int flags, void* stream);
 
+/* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
+ * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):
+ *   out[(i - row_begin) * num_rows + j] = Model.forward((i, j)),  i in [row_begin, row_begin + row_count),  j in [0, N)
+ * The diagonal is exactly 0 (the reference overwrites it with 0, runner.py:152). */
+int sympa_all_pairs_dist(const double* table, int64_t num_rows, int n, int64_t row_begin, int64_t row_count, int model,
+                         int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
+                         double* out, int32_t* status, int flags, void* stream);
+
 /* Backward of manifold.dist for pre-gathered points: what torch autograd computes through
  * siegel_manifold.py:41-72 / bounded_domain.py:27-39 when runner.py:105 calls loss.backward().
  *   grad_out          [b] fp64 dLoss/d(dist)

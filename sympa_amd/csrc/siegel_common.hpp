@@ -32,6 +32,8 @@ struct DistArgs {
     int32_t* status;
     int metric;
     int flags;
+    int64_t ap_cols;       // > 0: all-pairs mode, pair p = (ap_row0 + p / ap_cols, p % ap_cols), idx1/idx2 unused
+    int64_t ap_row0;
 };
 
 // thread-local message behind sympa_last_error()

@@ -46,7 +46,10 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
 
     int st = 0;
     int64_t r1 = ii, r2 = ii;
-    if (a.idx1 != nullptr) {
+    if (a.ap_cols > 0) {          // all-pairs block of the distance matrix (runner.py:142-154)
+        r1 = a.ap_row0 + ii / a.ap_cols;
+        r2 = ii % a.ap_cols;
+    } else if (a.idx1 != nullptr) {
         // index batches and outputs stream through once: non-temporal, so they do not evict table rows from L2
         r1 = __builtin_nontemporal_load(a.idx1 + ii * a.idx1_stride);
         r2 = __builtin_nontemporal_load(a.idx2 + ii * a.idx2_stride);
@@ -190,6 +193,31 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
     a.status = status;
     a.metric = metric;
     a.flags = flags;
+    return launch(a, n, model, stream);
+}
+
+int sympa_all_pairs_dist(const double* table, int64_t num_rows, int n, int64_t row_begin, int64_t row_count, int model,
+                         int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
+                         double* out, int32_t* status, int flags, void* stream) {
+    if (num_rows <= 0 || row_begin < 0 || row_count < 0 || row_begin + row_count > num_rows)
+        return fail(SYMPA_ERR_BAD_ARG, "row block outside the table");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    DistArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.base1 = table;
+    a.base2 = table;
+    a.num_rows = num_rows;
+    a.b = row_count * num_rows;
+    a.metric_w = metric_w;
+    a.scale = scale;
+    a.inv_scale_coef = 1.0 / scale_coef;
+    a.inv_eps = 1.0 / eps;
+    a.out = out;
+    a.status = status;
+    a.metric = metric;
+    a.flags = flags;
+    a.ap_cols = num_rows;
+    a.ap_row0 = row_begin;
     return launch(a, n, model, stream);
 }
 

@@ -59,6 +59,15 @@ class Model(nn.Module):
                                 gs, self.scale_coef, loss_scale)
         return loss
 
+    def distance_matrix(self, row_begin=0, row_count=None):
+        """Extension: the N x N matrix Runner.build_distance_matrix (runner.py:142-154) assembles with N
+        forward calls, as one launch (or one launch per row block).  Diagonal exactly 0."""
+        from sympa_amd import ops
+        man = self.manifold
+        weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
+        return ops.all_pairs_dist(self.embeddings.embeds, man.model_name, man.metric.kind.value, weights, self.scale,
+                                  self.scale_coef, row_begin, row_count)
+
     def distance(self, src_embeds, dst_embeds):   # model.py:32-38
         return self.manifold.dist(src_embeds, dst_embeds)
 

@@ -320,3 +320,32 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None)
                                  st.data_ptr(), _stream())
     _lib.check(rc)
     return table
+
+
+def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0, row_begin=0,
+                   row_count=None, eps=None, out=None):
+    """Rows [row_begin, row_begin + row_count) of the N x N distance matrix (C-ABI sympa_all_pairs_dist;
+    reference Runner.build_distance_matrix, runner.py:142-154).  Returns [row_count, N] fp64."""
+    lib = _lib.load()
+    _need_gpu(table, "table")
+    tab = table.detach()
+    tab = tab if tab.is_contiguous() else tab.contiguous()
+    num_rows, n = tab.shape[0], tab.shape[2]
+    row_count = num_rows - row_begin if row_count is None else int(row_count)
+    if out is None:
+        out = torch.empty(row_count, num_rows, dtype=torch.float64, device=tab.device)
+    w = _weights(metric, weights, n, tab.device) if metric == "wsum" else None
+    sc = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(tab.device)
+    with torch.cuda.device(tab.device):
+        rc = lib.sympa_all_pairs_dist(tab.data_ptr(), num_rows, n, int(row_begin), row_count, MODEL_IDS[model],
+                                      METRIC_IDS[metric], None if w is None else w.data_ptr(), eps,
+                                      None if sc is None else sc.data_ptr(), float(scale_coef), out.data_ptr(),
+                                      st.data_ptr(), 0, _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(tab.device)
+    return out

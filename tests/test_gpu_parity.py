@@ -176,3 +176,39 @@ def test_full_size_properties(dev, model, n, b, N):
     k = 256
     want = so.model_forward(table.cpu(), trip[:k].cpu(), model, "riem")
     assert rel_err(d_xy[:k].cpu(), want) < 1e-8
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_all_pairs_matrix_equals_runner_loop(dev, model):
+    """Model.distance_matrix == the reference's Runner.build_distance_matrix loop (runner.py:142-154):
+    row i = forward of the pairs (i, j) for all j, self pair replaced and overwritten by 0."""
+    from sympa_amd import ops
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = model, "fone", 4, 131
+        scale_coef, scale_init, train_scale = 1.0, 1.7, False
+    A.manifold = model
+    g = torch.Generator().manual_seed(13)
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = points(model, 131, 4, 0.4, g)
+    m = m.to(dev)
+    with torch.no_grad():
+        full = m.distance_matrix()
+        block = m.distance_matrix(row_begin=17, row_count=40)
+    ops.check_status(dev)
+    n_nodes = 131
+    want = torch.zeros(n_nodes, n_nodes, dtype=torch.float64)
+    all_nodes = torch.arange(n_nodes).unsqueeze(1)
+    for node in range(n_nodes):            # the reference loop, with the oracle as forward
+        src = torch.full((n_nodes, 1), node)
+        src[node] = (node + 1) % n_nodes
+        d = so.model_forward(m.embeddings.embeds.detach().cpu(), torch.cat((src, all_nodes), -1), model, "fone",
+                             scale=m.scale.detach().cpu(), scale_coef=1.0)
+        d[node] = 0
+        want[node] = d
+    assert full.shape == (n_nodes, n_nodes) and torch.all(full.diagonal() == 0)
+    assert rel_err(full.cpu(), want) < TOL
+    assert torch.equal(block, full[17:57])
+    assert rel_err(full.cpu(), full.cpu().T) < 1e-10

@@ -65,3 +65,47 @@ def test_two_rank_sharding_over_gloo():
     assert results["union_equal"] and results["dist_equal"]
     assert results["max"] == 2.0
     assert results["sampler_cover"] and results["sampler_sizes"] == [501, 501]
+
+
+def _grad_worker(rank, world, port, results):
+    """Data-parallel training semantics over gloo: per-rank gradients of the rank's shard, one flat
+    all-reduce (mean), must equal DDP's result = gradient of the mean-of-shards loss."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympa_amd.distributed import allreduce_gradients, shard_triplets
+        nodes, n = 40, 2
+        table0 = data.trained_like_table(nodes, n, seed=7)
+        trip = torch.cat((data.sample_pairs(nodes, 128, 0, seed=7), torch.randint(1, 6, (128, 1))), 1)
+        if rank == 0:
+            obj = [trip]
+        else:
+            obj = [None]
+        dist.broadcast_object_list(obj, src=0)
+        trip = obj[0]
+        mine = shard_triplets(trip, rank, world, epoch=1, seed=0)
+
+        def loss_of(table, t):
+            d = so.model_forward(table, t, "upper", "riem")
+            return so.distortion_loss(t[:, 2].to(torch.float64), d)
+
+        table = torch.nn.Parameter(table0.clone())
+        scale = torch.nn.Parameter(torch.ones(1, dtype=torch.float64))
+        loss_of(table, mine).backward()          # scale has no grad on purpose (treated as zeros)
+        allreduce_gradients([table, scale])
+        if rank == 0:
+            ref = torch.nn.Parameter(table0.clone())
+            total = sum(loss_of(ref, shard_triplets(trip, r, world, epoch=1, seed=0)) for r in range(world)) / world
+            total.backward()
+            results["grad_equal"] = bool(torch.allclose(table.grad, ref.grad, rtol=1e-12, atol=1e-14))
+            results["scale_zero"] = bool(torch.all(scale.grad == 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_ddp_mean():
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_grad_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    assert results["grad_equal"] and results["scale_zero"]
