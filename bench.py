@@ -81,14 +81,17 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--workload", default="upper-riem-n4-b65536", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step")
     ap.add_argument("--table", default="trained", choices=["trained", "init"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=16)
+    ap.add_argument("--graph-nodes", type=int, default=128,
+                    help="kernel launches (= steps) captured per hipGraph; one replay costs ~10 us of host/launch "
+                         "overhead whatever its length")
     ap.add_argument("--streams", type=int, default=1,
                     help="graph launch only: capture the steps on this many parallel HIP streams so that "
                          "independent steps (different batches) overlap on the GPU; 1 = strictly sequential")
@@ -143,20 +146,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- launch plan: K steps = K kernel launches, either direct or replayed from a hipGraph whose
-    # nodes are the nb distinct-batch launches (a step is still exactly one kernel over one batch)
-    graph = None
-    if args.launch == "graph":
-        for i in range(nb):
-            step(i)            # warm (allocates the status word etc. outside capture)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
+    # ---- launch plan: K steps = K kernel launches, either direct or replayed from hipGraphs whose nodes are
+    # the launches themselves (a step is still exactly one kernel over one batch).  Two graphs are captured:
+    # a long one (--graph-nodes launches) and a short one (one cycle of the nb distinct batches); K steps =
+    # as many long replays as fit, then short ones, then direct launches for the last < nb steps.
+    def capture(nodes):
+        g_ = torch.cuda.CUDAGraph()
         side = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(g_):
             main = torch.cuda.current_stream()
             for st in side:
                 st.wait_stream(main)                     # fork
-            for i in range(nb):
+            for i in range(nodes):
                 k = i % args.streams
                 if k == 0:
                     step(i)
@@ -165,13 +166,25 @@ def main():
                         step(i)
             for st in side:
                 main.wait_stream(st)                     # join
+        return g_
+
+    graphs = []          # [(nodes, graph)], longest first
+    gn = nb
+    if args.launch == "graph":
+        for i in range(nb):
+            step(i)            # warm (allocates the status word etc. outside capture)
+        torch.cuda.synchronize(dev)
+        gn = max(nb, (min(args.graph_nodes, max(args.steps, nb)) // nb) * nb)   # multiple of nb
+        graphs.append((gn, capture(gn)))
+        if gn != nb:
+            graphs.append((nb, capture(nb)))
 
     def run_steps(k):
         done = 0
-        if graph is not None:
-            while k - done >= nb:
-                graph.replay()
-                done += nb
+        for nodes, g_ in graphs:
+            while k - done >= nodes:
+                g_.replay()
+                done += nodes
         while done < k:
             step(done)
             done += 1
@@ -191,14 +204,15 @@ def main():
     # dominant-kernel duration from HIP events on the launch stream (torch's current stream): events
     # bracket groups of nb back-to-back launches (one graph replay, or nb direct launches); the
     # quotient includes the inter-kernel gaps, so it is an upper bound of the kernel's own duration
-    groups = max(1, args.steps // nb)
+    per_group = gn if graphs else nb
+    groups = max(1, args.steps // per_group)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
     for gidx in range(groups):
         ev[gidx][0].record()
-        run_steps(nb)
+        run_steps(per_group)
         ev[gidx][1].record()
     torch.cuda.synchronize(dev)
-    kernel_ms = sorted(a.elapsed_time(b) / nb for a, b in ev)
+    kernel_ms = sorted(a.elapsed_time(b) / per_group for a, b in ev)
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
     kernel_med_ms = kernel_ms[len(kernel_ms) // 2]
 

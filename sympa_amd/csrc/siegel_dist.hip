@@ -35,7 +35,7 @@ int validate(const DistArgs& a, int model) {
 namespace {
 using namespace sympa_hip;
 
-template <int N, int MODEL, bool LOWLDS>
+template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
 __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     constexpr int WAVE_SLOTS = DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
                                                    : Tile<N>::WAVE_SLOTS;
@@ -102,7 +102,9 @@ int launch_n(const DistArgs& a, int model, hipStream_t s) {
     const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
     // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
     const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256);
-    if (model == SYMPA_MODEL_UPPER) {
+    if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
+        hipLaunchKernelGGL((siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    } else if (model == SYMPA_MODEL_UPPER) {
         if (low) hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER, true>), dim3(grid), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER, false>), dim3(grid), dim3(BLOCK), 0, s, a);
     } else {

@@ -95,6 +95,9 @@ struct DmaTile {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// (Masking the lanes of the 4 chunks per row that hold only lower-triangle entries off the DMA instruction
+// was measured 3 % SLOWER than fetching whole rows -- tools/ab_bench.py, 7.93 vs 7.69 us -- so rows are
+// fetched whole.)
 template <int N>
 __device__ __forceinline__ void dma_issue(const double* __restrict__ base, const int row, v2d* __restrict__ side) {
     constexpr int C = DmaTile<N>::C;
