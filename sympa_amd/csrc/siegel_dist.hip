@@ -35,6 +35,8 @@ int validate(const DistArgs& a, int model) {
 namespace {
 using namespace sympa_hip;
 
+// EXPERIMENT: a spare instantiation selected by flags bit 0x100 for in-process A/B timing (tools/ab_bench.py);
+// identical to the product kernel unless a variant is being measured.
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
 __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     constexpr int WAVE_SLOTS = DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
         if constexpr (DmaTile<N>::ENABLED && LOWLDS)
             gather_pair_dma_low<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
         else if constexpr (DmaTile<N>::ENABLED)
-            gather_pair_dma<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+            gather_pair_dma_split<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
         else
             gather_pair_staged<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
         d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);

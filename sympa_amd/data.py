@@ -140,3 +140,44 @@ def distributed_sampler_indices(dataset_len, num_replicas, rank, epoch=0, seed=0
     else:
         indices = indices[:total]
     return indices[rank:total:num_replicas]
+
+
+# ---------------------------------------------------------------------------------------------------
+# On-disk formats either side of the path
+# ---------------------------------------------------------------------------------------------------
+def save_preprocessed(path, triplets, id2node):
+    """Writes the reference's `preprocessed-data.pt` (preprocess.py:165-171): a torch-pickled dict with
+    "triplets" = a Python set of (src, dst, distance) tuples and "id2node" = {id: node label}."""
+    trip = triplets.tolist() if torch.is_tensor(triplets) else list(triplets)
+    as_set = {(int(i), int(j), (int(d) if float(d).is_integer() else float(d))) for i, j, d in trip}
+    torch.save({"triplets": as_set, "id2node": dict(id2node)}, path)
+
+
+def load_preprocessed(path):
+    """Reads `preprocessed-data.pt` the way train.py:80-97 does, but into canonical (lexicographic) order
+    instead of CPython set-iteration order: returns (src_dst_ids int64 [T,2], distances fp64 [T], id2node)."""
+    blob = torch.load(path, weights_only=False)
+    trip = sorted(blob["triplets"])
+    ids = torch.tensor([(s, d) for s, d, _ in trip], dtype=torch.int64).reshape(-1, 2)
+    dist = torch.tensor([float(w) for _, _, w in trip], dtype=torch.float64)
+    return ids, dist, blob["id2node"]
+
+
+def scale_triplet_distances(distances):
+    """utils.scale_triplets (sympa/utils.py:71-82): squared distances divided by their maximum."""
+    sq = distances.to(torch.float64) ** 2
+    return sq / sq.max()
+
+
+def save_checkpoint(path, model, id2node):
+    """runner.py:156-160: {"model": ddp_model.state_dict(), "id2node": ...}; DDP prefixes keys with "module."."""
+    state = {f"module.{k}": v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save({"model": state, "id2node": dict(id2node)}, path)
+
+
+def load_checkpoint(path, model):
+    """train.py:60-62 (`--load_model`): accepts state dicts with or without DDP's "module." prefix."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in blob["model"].items()}
+    model.load_state_dict(state)
+    return blob.get("id2node")

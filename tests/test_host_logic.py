@@ -75,3 +75,36 @@ def test_tables_are_on_the_manifold():
     assert (torch.linalg.svdvals(wc) < 1).all()
     i = data.init_table(64, 3)
     assert ((i[:, 1] - torch.eye(3)).abs() <= 1e-3).all() and (i[:, 0].abs() <= 1e-3).all()
+
+
+def test_preprocessed_file_round_trip_in_the_reference_format(tmp_path):
+    """preprocess.py:165-171 writes {"triplets": set of (i, j, d), "id2node": dict}; train.py:80-97 reads it."""
+    g = data.named_graph("grid3d-125")
+    trip, id2node = data.graph_triplets(g)
+    path = tmp_path / "preprocessed-data.pt"
+    data.save_preprocessed(path, trip, id2node)
+    raw = torch.load(path, weights_only=False)           # what the reference's train.py would see
+    assert isinstance(raw["triplets"], set) and len(raw["triplets"]) == 7750
+    assert all(isinstance(t, tuple) and len(t) == 3 and isinstance(t[2], int) for t in raw["triplets"])
+    assert raw["id2node"][0] == (0, 0, 0) and len(raw["id2node"]) == 125
+    ids, dist, id2 = data.load_preprocessed(path)
+    assert torch.equal(ids, trip[:, :2]) and torch.equal(dist, trip[:, 2].to(torch.float64)) and id2 == id2node
+    scaled = data.scale_triplet_distances(dist)
+    assert float(scaled.max()) == 1.0 and float(scaled.min()) == pytest.approx(1 / 144)
+
+
+def test_checkpoint_round_trip_with_ddp_prefix(tmp_path):
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "upper", "wsum", 3, 12
+        scale_coef, scale_init, train_scale = 1.0, 1.0, True
+
+    m1, m2 = Model(A), Model(A)
+    path = tmp_path / "ckpt"
+    data.save_checkpoint(path, m1, {i: i for i in range(12)})
+    blob = torch.load(path, weights_only=False)
+    assert set(blob["model"]) == {"module.scale", "module.embeddings.embeds", "module.manifold.metric.weights",
+                                  "module.embeddings.manifold.metric.weights"}      # runner.py:160 layout
+    assert data.load_checkpoint(path, m2) == {i: i for i in range(12)}
+    assert torch.equal(m1.embeddings.embeds.data, m2.embeddings.embeds.data)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Minimal end-to-end harness around the MI355X path (the build's own counterpart of train.py + Runner, not a
+rewrite of them: SURVEY 8f): graph -> triplets -> Model -> fused training step -> RiemannianSGD -> distortion.
+
+    python tools/train_siegel.py --graph grid3d-125 --manifold upper --metric riem --dims 2 --epochs 50
+
+Per batch it runs exactly two kernels: sympa_model_loss_backward (forward + AverageDistortionLoss + backward +
+scatter, runner.py:101-105) and sympa_rsgd_step (geoopt RiemannianSGD, train.py:66-68), plus the gradient clip
+of runner.py:115.  Multi-GPU: launch with torch.distributed.run; triplets are sharded with DistributedSampler
+semantics and the gradients are averaged with one flat RCCL all-reduce (sympa_amd/distributed.py)."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from sympa_amd import data, ops  # noqa: E402
+from sympa_amd.distributed import allreduce_gradients, shard_triplets  # noqa: E402
+from sympa_amd.model import Model  # noqa: E402
+from sympa_amd.optim import RiemannianSGD  # noqa: E402
+
+
+def evaluate(model, ids, gd, batch):
+    """Average distortion |d_manifold - d_graph| / d_graph (sympa/metrics.py:21, runner.py:124-135)."""
+    tot = torch.zeros(1, dtype=torch.float64, device=ids.device)
+    with torch.no_grad():
+        for s in range(0, ids.shape[0], batch):
+            d = model(ids[s:s + batch])
+            tot += ((d - gd[s:s + batch]).abs() / gd[s:s + batch]).sum()
+    return float(tot) / ids.shape[0]
+
+
+def train(args, log=print):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(args.seed)
+    trip, id2node = data.graph_triplets(data.named_graph(args.graph))
+    args.num_points = len(id2node)
+    model = Model(args).to(dev)
+    opt = RiemannianSGD(model.parameters(), lr=args.learning_rate * world, weight_decay=0.0, stabilize=None)
+    ids_all = trip[:, :2].contiguous().to(dev)
+    gd_all = trip[:, 2].to(torch.float64).to(dev)
+    batch = max(1, args.batch_size // world)
+    history = []
+    for epoch in range(1, args.epochs + 1):
+        mine = shard_triplets(trip, rank, world, epoch=epoch, seed=0).to(dev)
+        t0 = time.perf_counter()
+        lr = args.learning_rate * world / (10.0 if epoch < args.burnin else 1.0)   # runner.py:162-170
+        for g in opt.param_groups:
+            g["lr"] = lr
+        loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        for s in range(0, mine.shape[0], batch):
+            b = mine[s:s + batch]
+            opt.zero_grad(set_to_none=False)
+            loss_sum += model.fused_loss_backward(b[:, :2].contiguous(), b[:, 2].to(torch.float64))
+            if world > 1:
+                allreduce_gradients(model.parameters())
+            torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)      # runner.py:115
+            opt.step()
+        if epoch % args.val_every == 0 or epoch == args.epochs:
+            distortion = evaluate(model, ids_all, gd_all, args.batch_size)
+            ops.check_status(dev)
+            history.append((epoch, float(loss_sum) / max(1, mine.shape[0]), distortion))
+            if rank == 0:
+                log(f"epoch {epoch:4d}  loss/triplet {history[-1][1]:.4f}  avg distortion {distortion:.4f}  "
+                    f"{time.perf_counter() - t0:.2f} s/epoch  projected {model.manifold.projected_points}")
+    return model, history
+
+
+def parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", default="grid3d-125")
+    ap.add_argument("--manifold", default="upper")
+    ap.add_argument("--metric", default="riem")
+    ap.add_argument("--dims", type=int, default=2)
+    ap.add_argument("--scale_init", type=float, default=1.0)
+    ap.add_argument("--scale_coef", type=float, default=1.0)
+    ap.add_argument("--train_scale", action="store_true", default=False)
+    ap.add_argument("--learning_rate", type=float, default=1e-2)
+    ap.add_argument("--max_grad_norm", type=float, default=50.0)
+    ap.add_argument("--batch_size", type=int, default=512)
+    ap.add_argument("--epochs", type=int, default=50)
+    ap.add_argument("--burnin", type=int, default=10)
+    ap.add_argument("--val_every", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=42)
+    return ap
+
+
+if __name__ == "__main__":
+    train(parser().parse_args())
