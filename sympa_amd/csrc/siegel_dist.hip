@@ -7,6 +7,7 @@
 // operation is the ballot that ends the Jacobi loop when all 64 pairs have converged.
 // The workload is VALU-fp64 bound: the table rows come out of L2 / Infinity Cache.
 #include "siegel_common.hpp"
+#include "siegel_math_generic.hpp"
 
 namespace sympa_hip {
 
@@ -99,6 +100,39 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
 // through the wave's LDS tile so that one atomic wave-instruction covers whole contiguous rows
 // (64 / 2n^2 rows x 16n^2 B), the access shape the fp64 atomics need to run at rate.
 // ---------------------------------------------------------------------------------------------
+// Runtime-n fallback (9 <= n <= 16): per-lane matrices in scratch, direct loads, 64-thread blocks.
+__global__ __launch_bounds__(64) void siegel_dist_generic_kernel(const DistArgs a, const int n, const int model) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = i < a.b;
+    const int64_t ii = live ? i : a.b - 1;
+    int st = 0;
+    int64_t r1 = ii, r2 = ii;
+    if (a.ap_cols > 0) {
+        r1 = a.ap_row0 + ii / a.ap_cols;
+        r2 = ii % a.ap_cols;
+    } else if (a.idx1 != nullptr) {
+        r1 = a.idx1[ii * a.idx1_stride];
+        r2 = a.idx2[ii * a.idx2_stride];
+        if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { st |= sympa::ST_BAD_INDEX; r1 = 0; r2 = 0; }
+    }
+    const int64_t row = 2 * (int64_t)n * n;
+    sympa::GenericWork w;
+    double* vv = (a.vvd != nullptr && live) ? a.vvd + i * n : nullptr;
+    double d = sympa::pair_distance_generic(w, a.base1 + r1 * row, a.base2 + r2 * row, n, model, a.metric, a.metric_w,
+                                            a.inv_eps, vv, st);
+    if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
+    if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);
+    if (live) a.out[i] = d;
+    if (a.status != nullptr) {
+        const int flagged = (live && st != 0) ? 1 : 0;
+        const unsigned long long m = __ballot(flagged);
+        if (m != 0ull) {
+            if (flagged) atomicOr(&a.status[0], st);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
+        }
+    }
+}
+
 template <int N>
 int launch_n(const DistArgs& a, int model, hipStream_t s) {
     const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
@@ -139,8 +173,15 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
         case 6: return launch_n<6>(a, model, s);
         case 7: return launch_n<7>(a, model, s);
         case 8: return launch_n<8>(a, model, s);
-        default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS]");
+        default: break;
     }
+    if (n > SYMPA_MAX_DIMS && n <= sympa::GENERIC_MAX_N) {
+        hipLaunchKernelGGL(siegel_dist_generic_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0, s, a, n, model);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+        return 0;
+    }
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS_GENERIC]");
 }
 
 }  // namespace

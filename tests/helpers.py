@@ -59,14 +59,15 @@ def hostsim():
         so = os.path.join(d, "libsympa_hostsim.so")
         srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp"),
-                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_table_math.hpp")]
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_table_math.hpp"),
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_generic.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], cwd=d)
         _hostsim = ctypes.CDLL(so)
     return _hostsim
 
 
-def hostsim_dist(z1, z2, model, metric, weights=None, eps=1e-5):
+def hostsim_dist(z1, z2, model, metric, weights=None, eps=1e-5, generic=False):
     lib = hostsim()
     P = ctypes.c_void_p
     z1 = np.ascontiguousarray(z1, dtype=np.float64)
@@ -76,7 +77,8 @@ def hostsim_dist(z1, z2, model, metric, weights=None, eps=1e-5):
     vvd = np.zeros((b, n))
     st = ctypes.c_int32(0)
     w = np.ascontiguousarray(np.ones(n) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1))
-    rc = lib.sympa_hostsim_dist(P(z1.ctypes.data), P(z2.ctypes.data), ctypes.c_int64(b), n,
+    fn = lib.sympa_hostsim_dist_generic if generic else lib.sympa_hostsim_dist
+    rc = fn(P(z1.ctypes.data), P(z2.ctypes.data), ctypes.c_int64(b), n,
                                 MODELS.index(model), METRICS.index(metric), P(w.ctypes.data),
                                 ctypes.c_double(eps), P(out.ctypes.data), P(vvd.ctypes.data), ctypes.byref(st))
     assert rc == 0, rc

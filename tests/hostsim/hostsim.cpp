@@ -6,6 +6,7 @@
 #include "../../sympa_amd/csrc/siegel_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_bwd.hpp"
 #include "../../sympa_amd/csrc/siegel_table_math.hpp"
+#include "../../sympa_amd/csrc/siegel_math_generic.hpp"
 
 namespace {
 template <int N>
@@ -37,6 +38,18 @@ extern "C" int sympa_hostsim_dist(const double* z1, const double* z2, int64_t b,
         case 8: run<8>(z1, z2, b, model, metric, w, eps, out, vvd, status); return 0;
         default: return -2;
     }
+}
+
+extern "C" int sympa_hostsim_dist_generic(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
+                                          const double* w, double eps, double* out, double* vvd, int32_t* status) {
+    if (n < 1 || n > sympa::GENERIC_MAX_N) return -2;
+    int st = 0;
+    sympa::GenericWork work;
+    for (int64_t i = 0; i < b; ++i)
+        out[i] = sympa::pair_distance_generic(work, z1 + i * 2 * n * n, z2 + i * 2 * n * n, n, model, metric, w, 1.0 / eps,
+                                              vvd ? vvd + i * n : nullptr, st);
+    if (status) *status = st;
+    return 0;
 }
 
 namespace {

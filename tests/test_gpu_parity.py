@@ -139,7 +139,7 @@ def test_edge_cases(dev):
     assert torch.all(ops.siegel_dist_forward(table, table) == 0)
     # unsupported dims fail loudly
     with pytest.raises(RuntimeError):
-        ops.siegel_dist_forward(torch.zeros(2, 2, 9, 9, device=dev), torch.zeros(2, 2, 9, 9, device=dev))
+        ops.siegel_dist_forward(torch.zeros(2, 2, 17, 17, device=dev), torch.zeros(2, 2, 17, 17, device=dev))
 
 
 @pytest.mark.parametrize("model,n,b,N", [("upper", 4, 8192, 1093), ("bounded", 4, 65536, 5041),
@@ -212,3 +212,14 @@ def test_all_pairs_matrix_equals_runner_loop(dev, model):
     assert rel_err(full.cpu(), want) < TOL
     assert torch.equal(block, full[17:57])
     assert rel_err(full.cpu(), full.cpu().T) < 1e-10
+
+
+@pytest.mark.parametrize("n", [9, 12, 16])
+@pytest.mark.parametrize("model", MODELS)
+def test_generic_dims_fallback_kernel(dev, model, n):
+    """dims 9..16 run the runtime-n fallback kernel (scratch-resident matrices): parity with the oracle."""
+    g = torch.Generator().manual_seed(300 + n)
+    z1, z2 = points(model, 200, n, 0.2, g), points(model, 200, n, 0.2, g)
+    for metric in ("riem", "fmin"):
+        got = gpu_dist(z1, z2, model, metric)
+        assert rel_err(got, so.manifold_dist(model, z1, z2, metric)) < 1e-8, (model, n, metric)

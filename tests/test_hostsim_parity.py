@@ -62,3 +62,20 @@ def test_same_point_is_exactly_zero():
         z = points(model, 16, 4, 0.5, g)
         out, _, st = hostsim_dist(z.numpy(), z.numpy(), model, "riem")
         assert st == 0 and np.all(out == 0.0)
+
+
+@pytest.mark.parametrize("n", [3, 8, 11, 16])
+@pytest.mark.parametrize("model", MODELS)
+def test_generic_runtime_n_fallback(model, n):
+    """The runtime-n fallback (dims 9..16 on the GPU) against the oracle, and against the specialised code
+    where both exist."""
+    g = torch.Generator().manual_seed(200 + n)
+    z1, z2 = points(model, 12, n, 0.25, g), points(model, 12, n, 0.25, g)
+    for metric in ("riem", "finf", "wsum"):
+        w = torch.linspace(-0.3, 1.2, n)
+        out, vvd, st = hostsim_dist(z1.numpy(), z2.numpy(), model, metric, w.numpy(), generic=True)
+        assert st == 0
+        assert rel_err(out, so.manifold_dist(model, z1, z2, metric, w)) < 1e-8, (model, n, metric)
+        if n <= 8:
+            out2, _, _ = hostsim_dist(z1.numpy(), z2.numpy(), model, metric, w.numpy())
+            assert rel_err(out, out2) < 1e-10
