@@ -395,8 +395,10 @@ SYMPA_HD void herm_norms(const Herm<N>& h, double& off2, double& diag2) {
 // i.e. a certified relative error of the distance below 2e-5 (north_star tolerance: 1e-4).  MEASURED on
 // 4 x 65 536 pairs of each benchmark table (init, trained 0.3, trained 1.0) and on every golden vector:
 // <= 3e-12, typically 1e-15, because after three sweeps t is ~1e-5 on all but a handful of pivots
-// (tools/jacobi_convergence.py reproduces these statistics).  For n > 4 the certificate is tightened to
-// t^2 <= 1e-8, off <= 1e-12 (dropped terms <= 6e-13 ||H||), which in practice means one more full sweep.
+// (tools/jacobi_convergence.py reproduces these statistics).  For n > 4 the third-order term does not vanish
+// and graded spectra (lambda_max / lambda_min ~ 1e10 near the clamp) need the small eigenvalues to RELATIVE
+// accuracy for fone / fmin: a looser pair (t^2 <= 1e-4, off <= 1e-8) measured 8e-8 on the bounded n = 8 golden
+// vectors, so the certificate stays at t^2 <= 1e-8, off <= 1e-12 (dropped terms <= 6e-13 ||H||).
 template <int N>
 SYMPA_HD void jacobi_diag_update(Herm<N>& h, const int p, const int q) {
     const double br = h.re[p][q], bi = h.im[p][q];
@@ -451,7 +453,7 @@ SYMPA_HD bool jacobi_can_finish(const Herm<N>& h) {
 constexpr int JACOBI_MAX_SWEEPS = 16;
 // sweeps run before the first test: no pair of the measured inputs passes the certificate earlier
 template <int N>
-constexpr int jacobi_blind_sweeps() { return N <= 2 ? 1 : 3; }
+constexpr int jacobi_blind_sweeps() { return N <= 2 ? 1 : (N <= 4 ? 3 : 4); }
 
 // Returns false when the sweep cap was hit before the certificate held.
 template <int N>
