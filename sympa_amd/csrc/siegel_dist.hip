@@ -41,7 +41,7 @@ using namespace sympa_hip;
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
 __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     constexpr int WAVE_SLOTS = DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
-                                                   : Tile<N>::WAVE_SLOTS;
+                               : (PassTile<N>::ENABLED ? PassTile<N>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
     __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < a.b;
@@ -65,7 +65,12 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     constexpr int64_t ROW = 2 * N * N;
     double* vv = (a.vvd != nullptr && live) ? a.vvd + i * N : nullptr;
     double d;
-    if constexpr (Tile<N>::STAGED) {
+    if constexpr (PassTile<N>::ENABLED) {
+        sympa::CMat<N> z1, z2;
+        v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
+        gather_pair_passes<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+        d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);
+    } else if constexpr (Tile<N>::STAGED) {
         sympa::CMat<N> z1, z2;
         v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
         if constexpr (DmaTile<N>::ENABLED && LOWLDS)

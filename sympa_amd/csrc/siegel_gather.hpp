@@ -196,3 +196,88 @@ __device__ __forceinline__ void gather_pair_staged(const double* __restrict__ ba
     gather_transpose<N>(v1, tile, z1);
     gather_transpose<N>(v2, tile, z2);
 }
+
+// ---------------------------------------------------------------------------------------------
+// n = 5..8: rows are 400 B .. 1 KiB, a whole wave's tile would not fit in LDS.  The 64 rows of an endpoint
+// are gathered in 4 passes of 16 rows through two ping-pong buffers: one LDS-DMA instruction fetches one row
+// (lane l < C fetches chunk l: a fully coalesced 16 C-byte segment), pass p+1 is in flight while the 16 lanes
+// of pass p read their rows back (row pitch C or C+1 slots, odd, conflict-free).  Measured need: with
+// lane-per-row loads the n = 8 kernel was bound by L1/TA line thrashing (257 us per 262 144 pairs against
+// ~75 us of arithmetic).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct PassTile {
+    static constexpr int C = N * N;
+    static constexpr bool ENABLED = (N >= 5 && N <= 8);
+    static constexpr int PITCH = (C % 2 == 1) ? C : C + 1;
+    static constexpr int ROWS = 16;
+    static constexpr int BUF_SLOTS = ENABLED ? ROWS * PITCH : 1;
+    static constexpr int WAVE_SLOTS = 2 * BUF_SLOTS;
+};
+
+template <int N>
+__device__ __forceinline__ void pass_issue(const double* __restrict__ base, const int row, const int pass,
+                                           v2d* __restrict__ buf) {
+    constexpr int C = PassTile<N>::C;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < PassTile<N>::ROWS; ++j) {
+        const int rr = __shfl(row, 16 * pass + j);
+        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * (lane < C ? lane : 0);
+        if (C == 64 || lane < C)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PassTile<N>::PITCH), 16, 0, 0);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void pass_read(const v2d* __restrict__ buf, const int pass, sympa::CMat<N>& z) {
+    constexpr int C = PassTile<N>::C;
+    const int lane = threadIdx.x & 63;
+    if ((lane >> 4) == pass) {
+        const v2d* mine = buf + (lane & 15) * PassTile<N>::PITCH;
+        v2d q[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[c] = mine[c];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int fr = (i <= j) ? i * N + j : j * N + i;
+                const int fi = N * N + fr;
+                z.re[i][j] = (fr & 1) ? q[fr >> 1].y : q[fr >> 1].x;
+                z.im[i][j] = (fi & 1) ? q[fi >> 1].y : q[fi >> 1].x;
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void gather_pair_passes(const double* __restrict__ base1, const int row1,
+                                                   const double* __restrict__ base2, const int row2,
+                                                   v2d* __restrict__ tile, sympa::CMat<N>& z1, sympa::CMat<N>& z2) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) { z1.re[i][j] = 0.0; z1.im[i][j] = 0.0; z2.re[i][j] = 0.0; z2.im[i][j] = 0.0; }
+    v2d* buf0 = tile;
+    v2d* buf1 = tile + PassTile<N>::BUF_SLOTS;
+    pass_issue<N>(base1, row1, 0, buf0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        v2d* cur = (s & 1) ? buf1 : buf0;
+        v2d* nxt = (s & 1) ? buf0 : buf1;
+        if (s + 1 < 8) {
+            // the buffer being refilled was read two steps ago: make sure those reads have completed
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            wave_lds_fence();
+            if (s + 1 < 4) pass_issue<N>(base1, row1, s + 1, nxt);
+            else pass_issue<N>(base2, row2, s + 1 - 4, nxt);
+            __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): the DMAs of step s have landed
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+        }
+        wave_lds_fence();
+        if (s < 4) pass_read<N>(cur, s, z1);
+        else pass_read<N>(cur, s - 4, z2);
+    }
+}

@@ -457,7 +457,7 @@ constexpr int jacobi_blind_sweeps() { return N <= 2 ? 1 : (N <= 4 ? 3 : 4); }
 
 // Returns false when the sweep cap was hit before the certificate held.
 template <int N>
-SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
+SYMPA_HD bool herm_eigenvalues_jacobi(Herm<N>& h) {
     if (N == 1) return true;
 #pragma unroll
     for (int sweep = 0; sweep < jacobi_blind_sweeps<N>(); ++sweep) jacobi_sweep<N>(h);
@@ -470,6 +470,165 @@ SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
     }
     jacobi_final_sweep<N>(h);
     return conv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// n >= 5: Householder tridiagonalisation + square-root-free QL (Pal-Walker-Kahan, the algorithm of LAPACK's
+// dsterf) instead of Jacobi sweeps.  A Jacobi sweep costs ~3 n^3 * 6 instructions and n = 8 needs 6-7 of them
+// (17 k instructions, 80 % of the kernel); the reduction costs ~8/3 n^3 once and the QL iteration O(n^2) in
+// total.  Only |b_k|^2 of the tridiagonal's off-diagonal enters the eigenvalues, so no phases are fixed.
+// Everything stays in registers: loops are static, the per-lane active block [l, m] of the QL iteration is
+// handled by predication, the iteration ends when every lane of the wave has deflated all off-diagonals.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD void herm_get(const Herm<N>& h, int i, int j, double& re, double& im) {   // element (i, j), i != j
+    if (i < j) { re = h.re[i][j]; im = h.im[i][j]; } else { re = h.re[j][i]; im = -h.im[j][i]; }
+}
+
+template <int N>
+SYMPA_HD void herm_tridiagonalize(Herm<N>& h, double (&a)[N], double (&b2)[N]) {
+#pragma unroll
+    for (int k = 0; k < N - 2; ++k) {
+        constexpr int dummy = 0; (void)dummy;
+        // x_i = H[i][k], i = k+1 .. N-1
+        double vr[N], vi[N];
+        double sig2 = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            herm_get<N>(h, i, k, vr[i], vi[i]);
+            if (i > k + 1) sig2 = d_fma(vr[i], vr[i], d_fma(vi[i], vi[i], sig2));
+        }
+        const double x02 = d_fma(vr[k + 1], vr[k + 1], vi[k + 1] * vi[k + 1]);
+        const double n2 = x02 + sig2;
+        a[k] = h.d[k];
+        b2[k] = n2;
+        const double nx = d_sqrt(n2);                    // ||x||
+        const double ix0 = d_rsqrt(x02 + TINY);
+        const double ax0 = x02 * ix0;                    // |x0|
+        const bool x0zero = !(x02 > 0.0);
+        const double pr = x0zero ? 1.0 : vr[k + 1] * ix0, pi = x0zero ? 0.0 : vi[k + 1] * ix0;   // phase of x0
+        // v = x + phase ||x|| e1 ;  beta = 2 / ||v||^2 = 1 / (||x|| (||x|| + |x0|)); no reflection when sig2 = 0
+        vr[k + 1] = pr * (ax0 + nx);
+        vi[k + 1] = pi * (ax0 + nx);
+        const double beta = (sig2 > 0.0) ? d_rcp(nx * (nx + ax0)) : 0.0;
+        // p = beta A v
+        double qr[N], qi[N];
+        double kk = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            double tr = h.d[i] * vr[i], ti = h.d[i] * vi[i];
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) {
+                if (j == i) continue;
+                double ar, ai;
+                herm_get<N>(h, i, j, ar, ai);
+                tr = d_fma(ar, vr[j], tr); tr = d_fma(-ai, vi[j], tr);
+                ti = d_fma(ar, vi[j], ti); ti = d_fma(ai, vr[j], ti);
+            }
+            qr[i] = beta * tr; qi[i] = beta * ti;
+            kk = d_fma(vr[i], qr[i], kk); kk = d_fma(vi[i], qi[i], kk);     // Re(v^H p)
+        }
+        kk *= 0.5 * beta;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) { qr[i] = d_fma(-kk, vr[i], qr[i]); qi[i] = d_fma(-kk, vi[i], qi[i]); }
+        // A <- A - v q^H - q v^H
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            h.d[i] -= 2.0 * d_fma(vr[i], qr[i], vi[i] * qi[i]);
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) {
+                // v_i conj(q_j) + q_i conj(v_j)
+                double tr = d_fma(vr[i], qr[j], vi[i] * qi[j]);
+                double ti = d_fma(vi[i], qr[j], -vr[i] * qi[j]);
+                tr = d_fma(qr[i], vr[j], d_fma(qi[i], vi[j], tr));
+                ti = d_fma(qi[i], vr[j], d_fma(-qr[i], vi[j], ti));
+                h.re[i][j] -= tr;
+                h.im[i][j] -= ti;
+            }
+        }
+    }
+    a[N - 2] = h.d[N - 2];
+    a[N - 1] = h.d[N - 1];
+    b2[N - 2] = d_fma(h.re[N - 2][N - 1], h.re[N - 2][N - 1], h.im[N - 2][N - 1] * h.im[N - 2][N - 1]);
+    b2[N - 1] = 0.0;
+}
+
+// Eigenvalues of the real symmetric tridiagonal (d, e2 = squared off-diagonals), overwriting d.
+template <int N>
+SYMPA_HD bool tridiag_ql(double (&d)[N], double (&e2)[N]) {
+    constexpr double TOL = 1.3e-32;     // eps^2: dsterf's |e|^2 <= eps^2 |d_i d_{i+1}|
+    int l = 0;
+    bool done = false;
+    for (int iter = 0; iter < 40 * N; ++iter) {
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i)
+            if (e2[i] <= TOL * fabs(d[i] * d[i + 1]) + 1e-290) e2[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i)
+            if (l == i && e2[i] == 0.0) l = i + 1;
+        done = l >= N - 1;
+        if (wave_all(done)) break;
+        int m = N - 1;
+#pragma unroll
+        for (int i = N - 2; i >= 0; --i)
+            if (i >= l && e2[i] == 0.0) m = i;
+        double dl = 0.0, dl1 = 0.0, el = 1.0, dm = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i == l) dl = d[i];
+            if (i == l + 1) dl1 = d[i];
+            if (i == m) dm = d[i];
+            if (i < N - 1 && i == l) el = e2[i];
+        }
+        if (done) el = 1.0;
+        // Wilkinson shift from the leading 2 x 2 of the block
+        const double irte = d_rsqrt(el);
+        const double rte = el * irte;
+        double sg = 0.5 * (dl1 - dl) * irte;
+        const double rr = d_sqrt(d_fma(sg, sg, 1.0));
+        const double sigma = dl - rte * d_rcp(sg + copysign(rr, sg));
+        double c = 1.0, sn = 0.0, gamma = dm - sigma, p = gamma * gamma;
+#pragma unroll
+        for (int i = N - 2; i >= 0; --i) {
+            if (!done && i >= l && i <= m - 1) {
+                const double bb = e2[i];
+                const double r = p + bb;
+                if (i < N - 2 && i != m - 1) e2[i + 1] = sn * r;
+                const double oldc = c;
+                const double ir = d_rcp(r);
+                c = p * ir;
+                sn = bb * ir;
+                const double oldgam = gamma;
+                const double alpha = d[i];
+                gamma = d_fma(c, alpha - sigma, -sn * oldgam);
+                d[i + 1] = oldgam + (alpha - gamma);
+                p = (c != 0.0) ? gamma * gamma * d_rcp(c) : oldc * bb;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if (i == l) d[i] = sigma + gamma;
+                if (i < N - 1 && i == l) e2[i] = sn * p;
+            }
+        }
+    }
+    return done;
+}
+
+// Eigenvalues of H into h.d[]: Jacobi for n <= 4, tridiagonal QL for n >= 5.
+template <int N>
+SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
+    if constexpr (N <= 4) {
+        return herm_eigenvalues_jacobi<N>(h);
+    } else {
+        double a[N], b2[N];
+        herm_tridiagonalize<N>(h, a, b2);
+        const bool ok = tridiag_ql<N>(a, b2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) h.d[i] = a[i];
+        return ok;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
