@@ -151,6 +151,16 @@ int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double
 int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
                     double weight_decay, double eps, int32_t* projected_count, int32_t* status, void* stream);
 
+/* ---- SPD model (manifold "spd": geoopt.manifolds.SymmetricPositiveDefinite, sympa/embeddings.py:6,70-72,142) ----
+ * Points are [n, n] fp64 symmetric positive definite matrices (upper triangle read), n <= 16.
+ * dist = || log(x^-1/2 y x^-1/2) ||_F  (geoopt's default affine-invariant metric; geoopt is absent from the
+ * reference tree: parity unpinned).  sympa_spd_model_forward is Model.forward for that model
+ * (sympa/model.py:16-41) with a [num_rows, n, n] table. */
+int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status, void* stream);
+int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                            const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
+                            double* out, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,3 +311,27 @@ def upper_random(n_points, dims, from_=-INIT_EPS, to=INIT_EPS, generator=None):
 
 def distortion_loss(graph_d, manifold_d):  # losses.py:10-19
     return torch.abs(torch.pow(manifold_d / graph_d, 2) - 1).sum()
+
+
+# --------------------------------------------------------------------------- spd (PARITY UNPINNED)
+def _sym_funcm(x, func):
+    """geoopt.linalg.batch_linalg.sym_funcm: apply `func` to the eigenvalues of a symmetric matrix."""
+    lam, v = torch.linalg.eigh(x, UPLO="U")
+    return v @ torch.diag_embed(func(lam)) @ v.transpose(-1, -2)
+
+
+def spd_dist(x, y):
+    """geoopt.manifolds.SymmetricPositiveDefinite.dist with the default AIM metric, restated from the published
+    source (geoopt/manifolds/symmetric_positive_definite.py): || sym_logm(x^-1/2 y x^-1/2) ||_F with the inverse
+    square root and the logarithm taken through eigh.  geoopt is NOT in the reference tree (un-vendored,
+    >=0.3.1, README.md:40) and not installed: this function is pinned by nothing but its own formula."""
+    inv_sqrt_x = _sym_funcm(x, lambda lam: torch.rsqrt(lam))
+    inner = inv_sqrt_x @ y @ inv_sqrt_x
+    return torch.norm(_sym_funcm(inner, torch.log), dim=[-1, -2])
+
+
+def spd_model_forward(table, triplets, scale=None, scale_coef=1.0):
+    d = spd_dist(table[triplets[:, 0]], table[triplets[:, 1]])
+    if scale is None:
+        scale = torch.tensor([scale_coef * 1.0], dtype=table.dtype)
+    return d * get_scale(scale, scale_coef)

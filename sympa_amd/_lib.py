@@ -23,6 +23,8 @@ SYMBOLS = (
     "sympa_egrad2rgrad",
     "sympa_projx",
     "sympa_rsgd_step",
+    "sympa_spd_dist_fwd",
+    "sympa_spd_model_forward",
 )
 
 _c_double_p = ctypes.c_void_p
@@ -96,6 +98,13 @@ def load():
     lib.sympa_rsgd_step.restype = ctypes.c_int
     lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
+    lib.sympa_spd_dist_fwd.restype = ctypes.c_int
+    lib.sympa_spd_dist_fwd.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, _c_i32_p,
+                                       ctypes.c_void_p]
+    lib.sympa_spd_model_forward.restype = ctypes.c_int
+    lib.sympa_spd_model_forward.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p,
+                                            ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p,
+                                            _c_i32_p, ctypes.c_void_p]
     _lib = lib
     return lib
 

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from sympa_amd import config
-from sympa_amd.manifolds import BoundedDomainManifold, UpperHalfManifold
+from sympa_amd.manifolds import BoundedDomainManifold, SymmetricPositiveDefinite, UpperHalfManifold
 from sympa_amd.manifolds.base import ManifoldParameter
 from sympa_amd.manifolds.metrics import MetricType
 
@@ -47,6 +47,9 @@ class MatrixEmbeddings(Embeddings):
 
     def __init__(self, num_embeddings, dims, manifold):
         _embeds = manifold.random(num_embeddings, dims, dims, from_=-config.INIT_EPS, to=config.INIT_EPS)
+        if isinstance(manifold, SymmetricPositiveDefinite):   # embeddings.py:70-72: near the identity
+            _embeds *= config.INIT_EPS
+            _embeds += torch.diag_embed(torch.ones(num_embeddings, dims))
         super().__init__(num_embeddings, dims, manifold, _embeds)
 
     def norm(self):
@@ -61,14 +64,14 @@ class EmbeddingsFactory:
 
     @classmethod
     def _get_table(cls, model_name: str):
-        if model_name in ManifoldFactory.sympa_manifolds:
+        if model_name in ManifoldFactory.sympa_manifolds or model_name == "spd":
             return MatrixEmbeddings
         raise ValueError(f"Unrecognized embedding model for the Siegel hot path: {model_name}")
 
 
 class ManifoldFactory:
     sympa_manifolds = {"upper": UpperHalfManifold, "bounded": BoundedDomainManifold}   # embeddings.py:145-149
-    out_of_scope = {"dual", "spd", "euclidean", "poincare", "lorentz", "sphere",
+    out_of_scope = {"dual", "euclidean", "poincare", "lorentz", "sphere",
                     "prod-hysph", "prod-hyhy", "prod-hyeu", "prod-sphsph"}
 
     @classmethod
@@ -77,5 +80,7 @@ class ManifoldFactory:
             raise NotImplementedError(
                 f"manifold '{manifold_name}' is outside the MI355X hot path (SURVEY section 2: its "
                 "arithmetic lives in geoopt / xitorch, not in the reference)")
+        if manifold_name == "spd":      # embeddings.py:142
+            return SymmetricPositiveDefinite()
         manifold = cls.sympa_manifolds[manifold_name]
         return manifold(dims=dims, metric=MetricType.from_str(metric_name))

@@ -26,6 +26,11 @@ class Model(nn.Module):
         """input_triplet: int64 [b, 2|3] (src_id, dst_id[, graph_distance]) -> b distances * scale
         (model.py:16-30)."""
         man = self.manifold
+        if man.model_name == "spd":
+            from sympa_amd import ops
+            if torch.is_grad_enabled() and (self.embeddings.embeds.requires_grad or self.scale.requires_grad):
+                raise NotImplementedError("the spd model has a forward kernel only: use torch.no_grad()")
+            return ops.spd_model_forward(self.embeddings.embeds, input_triplet, self.scale, self.scale_coef)
         weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
         return sa.model_forward(self.embeddings.embeds, input_triplet, man.model_name, man.metric.kind.value,
                                 weights, self.scale, self.scale_coef)

@@ -349,3 +349,55 @@ def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None
     if _debug:
         check_status(tab.device)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# SPD model (C-ABI sympa_spd_dist_fwd / sympa_spd_model_forward)
+# ---------------------------------------------------------------------------------------------------
+def spd_dist_forward(x, y):
+    lib = _lib.load()
+    _need_gpu(x, "x"); _need_gpu(y, "y")
+    if x.dtype != torch.float64 or x.shape != y.shape or x.dim() != 3 or x.shape[1] != x.shape[2]:
+        raise ValueError(f"expected two float64 [b,n,n] tensors, got {tuple(x.shape)} and {tuple(y.shape)}")
+    x, y = x.detach().contiguous(), y.detach().contiguous()
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    st = _status_buf(x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.sympa_spd_dist_fwd(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), st.data_ptr(),
+                                    _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(x.device)
+    return out
+
+
+def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None):
+    lib = _lib.load()
+    _need_gpu(table, "table"); _need_gpu(triplets, "triplets")
+    if table.dtype != torch.float64 or table.dim() != 3 or table.shape[1] != table.shape[2]:
+        raise ValueError(f"spd table must be float64 [N,n,n], got {tuple(table.shape)}")
+    if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
+        raise TypeError("triplets must be an int64 [b, >=2] tensor")
+    tab = table.detach()
+    tab = tab if tab.is_contiguous() else tab.contiguous()
+    b = triplets.shape[0]
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    if out is None:
+        out = torch.empty(b, dtype=torch.float64, device=tab.device)
+    if b == 0:
+        return out
+    sc = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
+    st = _status_buf(tab.device)
+    tp = triplets.data_ptr()
+    with torch.cuda.device(tab.device):
+        rc = lib.sympa_spd_model_forward(tab.data_ptr(), tab.shape[0], tab.shape[1], tp, stride, tp + 8, stride, b,
+                                         None if sc is None else sc.data_ptr(), float(scale_coef), out.data_ptr(),
+                                         st.data_ptr(), _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(tab.device)
+    return out

@@ -60,7 +60,8 @@ def hostsim():
         srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_table_math.hpp"),
-                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_generic.hpp")]
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_generic.hpp"),
+                os.path.join(ROOT, "sympa_amd", "csrc", "spd_math.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], cwd=d)
         _hostsim = ctypes.CDLL(so)
@@ -123,3 +124,21 @@ def hostsim_table(op, model, z, g=None, lr=0.0, wd=0.0, eps=1e-5):
                                  ctypes.c_double(eps), ctypes.byref(moved))
     assert st == 0, st
     return out, moved.value
+
+
+def spd_points(b, n, s, g):
+    a = sym(torch.randn(b, n, n, generator=g, dtype=torch.float64) * s)
+    return sym(torch.matrix_exp(a))
+
+
+def hostsim_spd_dist(x, y):
+    lib = hostsim()
+    P = ctypes.c_void_p
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros(x.shape[0])
+    st = ctypes.c_int32(0)
+    rc = lib.sympa_hostsim_spd_dist(P(x.ctypes.data), P(y.ctypes.data), ctypes.c_int64(x.shape[0]), x.shape[1],
+                                    P(out.ctypes.data), ctypes.byref(st))
+    assert rc == 0
+    return out, st.value

@@ -7,6 +7,7 @@
 #include "../../sympa_amd/csrc/siegel_math_bwd.hpp"
 #include "../../sympa_amd/csrc/siegel_table_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_generic.hpp"
+#include "../../sympa_amd/csrc/spd_math.hpp"
 
 namespace {
 template <int N>
@@ -131,4 +132,13 @@ extern "C" int sympa_hostsim_table(int op, int model, int n, const double* z, co
         case 8: return run_table<8>(op, model, z, g, out, b, lr, wd, eps, projected);
         default: return -2;
     }
+}
+
+extern "C" int sympa_hostsim_spd_dist(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status) {
+    if (n < 1 || n > sympa::SPD_MAX_N) return -2;
+    int st = 0;
+    sympa::SpdWork w;
+    for (int64_t i = 0; i < b; ++i) out[i] = sympa::spd_pair_distance(w, x + i * n * n, y + i * n * n, n, st);
+    if (status) *status = st;
+    return 0;
 }

@@ -1,0 +1,61 @@
+"""SPD model (configs[4]).  PARITY UNPINNED: geoopt's SymmetricPositiveDefinite is not in the reference tree and
+not installed; the oracle restates its published AIM formula and these tests check the kernel arithmetic against
+that restatement, against a generalized-eigenvalue evaluation, and through the invariances of the metric."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import siegel_oracle as so
+from tests.helpers import hostsim_spd_dist, rel_err, spd_points
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 8, 11, 16])
+def test_hostsim_spd_against_oracle_and_generalized_eigenvalues(n):
+    g = torch.Generator().manual_seed(400 + n)
+    for s in (1e-3, 0.3, 1.0):
+        x, y = spd_points(64, n, s, g), spd_points(64, n, s, g)
+        out, st = hostsim_spd_dist(x.numpy(), y.numpy())
+        assert st == 0
+        assert rel_err(out, so.spd_dist(x, y)) < 1e-9, (n, s)
+        lam = torch.linalg.eigvals(torch.linalg.solve(x, y)).real          # eig(x^-1 y): self-consistency
+        assert rel_err(out, torch.sqrt((torch.log(lam) ** 2).sum(-1))) < 1e-8
+    out, st = hostsim_spd_dist(x.numpy(), x.numpy())
+    assert st == 0 and np.all(out == 0.0)
+    bad = x.clone(); bad[3] = -bad[3]
+    assert hostsim_spd_dist(bad.numpy(), y.numpy())[1] & 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8, 16])
+def test_gpu_spd_kernel_and_model(n):
+    from sympa_amd import ops
+    from sympa_amd.model import Model
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(500 + n)
+    x, y = spd_points(500, n, 0.4, g), spd_points(500, n, 0.4, g)
+    got = ops.spd_dist_forward(x.to(dev), y.to(dev)).cpu()
+    ops.check_status(dev)
+    assert rel_err(got, so.spd_dist(x, y)) < 1e-9
+    # invariances of the affine-invariant metric: d(AxA^T, AyA^T) = d(x, y) = d(y, x) = d(x^-1, y^-1)
+    a = torch.eye(n, dtype=torch.float64) + 0.3 * torch.randn(n, n, generator=g, dtype=torch.float64)
+    xa, ya = a @ x @ a.T, a @ y @ a.T
+    sym = lambda t: 0.5 * (t + t.transpose(-1, -2))
+    assert rel_err(ops.spd_dist_forward(sym(xa).to(dev), sym(ya).to(dev)).cpu(), got) < 1e-8
+    assert rel_err(ops.spd_dist_forward(y.to(dev), x.to(dev)).cpu(), got) < 1e-10
+    xi, yi = sym(torch.linalg.inv(x)), sym(torch.linalg.inv(y))
+    assert rel_err(ops.spd_dist_forward(xi.to(dev), yi.to(dev)).cpu(), got) < 1e-8
+
+    class A:
+        manifold, metric, dims, num_points = "spd", "riem", n, 50
+        scale_coef, scale_init, train_scale = 1.0, 1.2, False
+
+    m = Model(A)
+    assert m.embeddings.embeds.shape == (50, n, n)
+    with torch.no_grad():
+        m.embeddings.embeds.data = spd_points(50, n, 0.3, g)
+    m = m.to(dev)
+    trip = torch.randint(0, 50, (300, 3), generator=g)
+    with torch.no_grad():
+        out = m(trip.to(dev)).cpu()
+    want = so.spd_model_forward(m.embeddings.embeds.detach().cpu(), trip, m.scale.detach().cpu(), 1.0)
+    assert rel_err(out, want) < 1e-9
