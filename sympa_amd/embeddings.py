@@ -29,13 +29,34 @@ class Embeddings(nn.Module, abc.ABC):
         with torch.no_grad():
             self.embeds.data = self.manifold.projx(self.embeds.data)
 
-    def check_all_points(self):       # embeddings.py:41-47
-        for i in range(len(self.embeds)):
-            point = self.embeds.data[i]
-            ok, reason = self.manifold.check_point_on_manifold(point, explain=True)
-            if not ok:
-                return False, point, reason
-        return True, None, None
+    def check_all_points(self):
+        """embeddings.py:41-47 loops over the N rows in Python (a host sync per row, called once per epoch by
+        runner.py:180-184).  Same verdict from batched device ops with ONE sync; only when some row fails is
+        the reference's per-point check run on that row to produce its (point, reason)."""
+        pts = self.embeds.data
+        bad = self._first_bad_row(pts)
+        if bad is None:
+            return True, None, None
+        point = pts[bad]
+        ok, reason = self.manifold.check_point_on_manifold(point, explain=True)
+        return (True, None, None) if ok else (False, point, reason)
+
+    def _first_bad_row(self, pts, atol=1e-5, rtol=1e-5):
+        from sympa_amd.manifolds import SymmetricPositiveDefinite, UpperHalfManifold
+        diff = (pts - pts.transpose(-1, -2)).abs()
+        tol = atol + rtol * pts.transpose(-1, -2).abs()
+        flat = (diff > tol).reshape(len(pts), -1).any(dim=1)              # torch.allclose, row by row
+        if isinstance(self.manifold, UpperHalfManifold):
+            flat |= ~(torch.linalg.det(pts[:, 1]) > 0)                     # upper_half.py:108-113
+        elif isinstance(self.manifold, SymmetricPositiveDefinite):
+            flat |= ~(torch.linalg.eigvalsh(pts) > -atol).all(dim=-1)
+        else:                                                              # bounded_domain.py:141-149
+            zc = torch.complex(pts[:, 0], pts[:, 1])
+            a = torch.eye(pts.shape[-1], dtype=zc.dtype, device=pts.device) - zc.conj() @ zc
+            d = (a - a.conj().transpose(-1, -2)).abs()
+            flat |= (d > 1e-8 + 1e-5 * a.abs()).reshape(len(pts), -1).any(dim=1)
+        idx = torch.nonzero(flat)
+        return int(idx[0]) if idx.numel() else None
 
     @abc.abstractmethod
     def norm(self):

@@ -108,3 +108,20 @@ def test_checkpoint_round_trip_with_ddp_prefix(tmp_path):
                                   "module.embeddings.manifold.metric.weights"}      # runner.py:160 layout
     assert data.load_checkpoint(path, m2) == {i: i for i in range(12)}
     assert torch.equal(m1.embeddings.embeds.data, m2.embeddings.embeds.data)
+
+
+def test_check_all_points_batched_matches_per_point_loop():
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "upper", "riem", 3, 20
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A)
+    assert m.check_all_points() == (True, None, None)
+    m.embeddings.embeds.data[7, 1] = -m.embeddings.embeds.data[7, 1]          # det(Y) < 0 for odd n
+    ok, point, reason = m.check_all_points()
+    assert not ok and torch.equal(point, m.embeddings.embeds.data[7]) and "determinant" in reason
+    m.embeddings.embeds.data[3, 0, 0, 1] += 1.0                                # asymmetric row comes first
+    ok, point, reason = m.check_all_points()
+    assert not ok and torch.equal(point, m.embeddings.embeds.data[3]) and "symmetric" in reason
