@@ -98,17 +98,34 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // (Masking the lanes of the 4 chunks per row that hold only lower-triangle entries off the DMA instruction
 // was measured 3 % SLOWER than fetching whole rows -- tools/ab_bench.py, 7.93 vs 7.69 us -- so rows are
 // fetched whole.)
+// Row index of pair (j + C r) for the lanes of group r = lane / C: the source lane C r + j sits in the same
+// group, so this is a broadcast inside a row of 16 lanes (C = 16: DPP row_newbcast:j) or inside a quad
+// (C = 4: DPP quad_perm [j,j,j,j]) -- one VALU move instead of a ds_bpermute round trip through the LDS.
+template <int C, int J>
+__device__ __forceinline__ int group_bcast(const int v) {
+    if constexpr (C == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);
+    else if constexpr (C == 4) return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+    else return __shfl(v, J + C * ((int)(threadIdx.x & 63) / C));
+}
+
+template <int N, int J>
+struct DmaIssue {
+    static __device__ __forceinline__ void run(const double* __restrict__ base, const int row, const int c,
+                                               v2d* __restrict__ side) {
+        constexpr int C = DmaTile<N>::C;
+        const int rr = group_bcast<C, J>(row);
+        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * c;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(side + J * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
+        if constexpr (J + 1 < C) DmaIssue<N, J + 1>::run(base, row, c, side);
+    }
+};
+
 template <int N>
 __device__ __forceinline__ void dma_issue(const double* __restrict__ base, const int row, v2d* __restrict__ side) {
     constexpr int C = DmaTile<N>::C;
     const int lane = threadIdx.x & 63;
-    const int r = lane / C, c = lane - r * C;
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const int rr = __shfl(row, j + C * r);
-        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * c;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(side + j * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
-    }
+    const int c = lane % C;
+    DmaIssue<N, 0>::run(base, row, c, side);
 }
 
 template <int N>
