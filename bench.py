@@ -135,7 +135,7 @@ def main():
         batches.append(glob[rank::world].contiguous().to(dev))
     outs = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(nb)]
     out = outs[0]
-    flags = ops.FLAG_LOW_LDS if args.streams > 1 else 0
+    flags = ops.FLAG_LOW_LDS if (args.streams > 1 and not os.environ.get('SYMPA_BENCH_FULL_LDS')) else 0
 
     def step(i):
         ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb], flags=flags)

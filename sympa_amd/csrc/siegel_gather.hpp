@@ -183,6 +183,11 @@ __device__ __forceinline__ void gather_pair_dma_split(const double* __restrict__
     dma_read<N>(side2, z2);
 }
 
+// (A packed shadow table -- 20 doubles per row, upper triangles only, 37 % fewer bytes -- was measured SLOWER,
+// 7.26 vs 7.04 us per launch (tools/ab_packed.py at commit "packed experiment"): the gather is bound by the
+// number of DMA instructions and the L2 round trip, not by bytes, and partially masked DMA instructions cost
+// more than full ones.  Rows are fetched whole from the reference layout.)
+
 // Low-LDS form: one endpoint at a time through one side buffer.  Exposes one more L2 round trip per
 // wave but halves the LDS footprint, so twice as many waves fit on a CU (used when launches overlap or
 // the grid is several waves per SIMD deep: the other wave's arithmetic hides the round trip).

@@ -20,7 +20,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 __global__ __launch_bounds__(256) void timeline(const double* table, const long long* idx, long long b, double* out,
                                                  unsigned long long* stamps) {
-    __shared__ v2d lds[4 * Tile<4>::WAVE_SLOTS];
+    __shared__ v2d lds[4 * DmaTile<4>::WAVE_SLOTS];
     constexpr int N = 4;
     unsigned long long t[NST];
     t[0] = stamp();
@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void timeline(const double* table, const long 
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
     t[1] = stamp();
     CMat<N> z1, z2, e;
-    v2d* tile = lds + (threadIdx.x >> 6) * Tile<4>::WAVE_SLOTS;
-    gather_pair_staged<N>(table, (int)r1, table, (int)r2, tile, z1, z2);
+    v2d* tile = lds + (threadIdx.x >> 6) * DmaTile<4>::WAVE_SLOTS;
+    gather_pair_dma_split<N>(table, (int)r1, table, (int)r2, tile, z1, z2);
     for (int a = 0; a < N; ++a) for (int c = a; c < N; ++c) asm volatile("" :: "v"(z1.re[a][c]), "v"(z1.im[a][c]), "v"(z2.re[a][c]), "v"(z2.im[a][c]));
     __builtin_amdgcn_sched_barrier(0);
     t[2] = stamp();
