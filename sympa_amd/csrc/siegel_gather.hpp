@@ -148,20 +148,6 @@ __device__ __forceinline__ void dma_read(const v2d* __restrict__ side, sympa::CM
     }
 }
 
-template <int N>
-__device__ __forceinline__ void gather_pair_dma(const double* __restrict__ base1, const int row1,
-                                                const double* __restrict__ base2, const int row2,
-                                                v2d* __restrict__ tile, sympa::CMat<N>& z1, sympa::CMat<N>& z2) {
-    v2d* side1 = tile;
-    v2d* side2 = tile + DmaTile<N>::SIDE_SLOTS;
-    dma_issue<N>(base1, row1, side1);
-    dma_issue<N>(base2, row2, side2);
-    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): LDS-DMA is counted like a load; the compiler does not track it
-    wave_lds_fence();
-    dma_read<N>(side1, z1);
-    dma_read<N>(side2, z2);
-}
-
 // Default for shallow grids (measured -1.9 % against waiting for both endpoints, tools/ab_bench.py; a
 // 64-thread block instead of 256 was worth another 1 % and was not adopted): wait for the first endpoint only (vmcnt counts the 16 younger DMAs of the second endpoint),
 // read it, let the caller's arithmetic on it start while the second endpoint is still landing.
