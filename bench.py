@@ -92,9 +92,11 @@ def main():
     ap.add_argument("--graph-nodes", type=int, default=128,
                     help="kernel launches (= steps) captured per hipGraph; one replay costs ~10 us of host/launch "
                          "overhead whatever its length")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="graph launch only: capture the steps on this many parallel HIP streams so that "
-                         "independent steps (different batches) overlap on the GPU; 1 = strictly sequential")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="graph launch only: the steps of the timed region are captured on this many parallel HIP "
+                         "streams, so that independent steps (different batches, different outputs) overlap on the "
+                         "GPU: the next step gathers while the previous one computes (low-LDS kernel form, two "
+                         "blocks per CU); 1 = strictly sequential launches")
     ap.add_argument("--launch", default="graph", choices=["graph", "direct"],
                     help="graph: the steps are replayed from a captured hipGraph of --distinct-batches kernel "
                          "nodes (one node = one step); direct: one Python->C-ABI call per step")
@@ -135,10 +137,13 @@ def main():
         batches.append(glob[rank::world].contiguous().to(dev))
     outs = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(nb)]
     out = outs[0]
+    if args.launch == "direct":
+        args.streams = 1
     flags = ops.FLAG_LOW_LDS if (args.streams > 1 and not os.environ.get('SYMPA_BENCH_FULL_LDS')) else 0
 
-    def step(i):
-        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb], flags=flags)
+    def step(i, fl=None):
+        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb],
+                          flags=flags if fl is None else fl)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -150,20 +155,21 @@ def main():
     # the launches themselves (a step is still exactly one kernel over one batch).  Two graphs are captured:
     # a long one (--graph-nodes launches) and a short one (one cycle of the nb distinct batches); K steps =
     # as many long replays as fit, then short ones, then direct launches for the last < nb steps.
-    def capture(nodes):
+    def capture(nodes, streams=None, fl=None):
+        streams = args.streams if streams is None else streams
         g_ = torch.cuda.CUDAGraph()
-        side = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
+        side = [torch.cuda.Stream(device=dev) for _ in range(max(0, streams - 1))]
         with torch.cuda.graph(g_):
             main = torch.cuda.current_stream()
             for st in side:
                 st.wait_stream(main)                     # fork
             for i in range(nodes):
-                k = i % args.streams
+                k = i % streams
                 if k == 0:
-                    step(i)
+                    step(i, fl)
                 else:
                     with torch.cuda.stream(side[k - 1]):
-                        step(i)
+                        step(i, fl)
             for st in side:
                 main.wait_stream(st)                     # join
         return g_
@@ -201,15 +207,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant-kernel duration from HIP events on the launch stream (torch's current stream): events
-    # bracket groups of nb back-to-back launches (one graph replay, or nb direct launches); the
-    # quotient includes the inter-kernel gaps, so it is an upper bound of the kernel's own duration
+    # Dominant-kernel duration for the roofline object: the SAME launches, strictly sequential on the launch
+    # stream (torch's current stream), bracketed by HIP events per group of back-to-back launches (one graph
+    # replay or nb direct launches).  The quotient includes the inter-kernel gaps, so it is an upper bound of
+    # the kernel's own duration; it is what `rocprofv3 --kernel-trace --stats` reports for the sequential
+    # kernel (`siegel_dist_kernel<..., false, false>`).  When the timed region overlaps steps on several
+    # streams its kernels live longer individually; that is why the roofline is taken on the sequential pass.
     per_group = gn if graphs else nb
-    groups = max(1, args.steps // per_group)
+    seq_graph = None
+    if graphs and args.streams > 1:
+        seq_graph = capture(per_group, streams=1, fl=0)
+
+    def run_group():
+        if seq_graph is not None:
+            seq_graph.replay()
+        else:
+            run_steps(per_group)
+
+    for _ in range(2):
+        run_group()
+    torch.cuda.synchronize(dev)
+    groups = max(2, min(16, args.steps // per_group))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
     for gidx in range(groups):
         ev[gidx][0].record()
-        run_steps(per_group)
+        run_group()
         ev[gidx][1].record()
     torch.cuda.synchronize(dev)
     kernel_ms = sorted(a.elapsed_time(b) / per_group for a, b in ev)
@@ -246,7 +268,11 @@ def main():
                          "kernel": "siegel_dist_kernel", "kernel_avg_us": kernel_avg_ms * 1e3,
                          "kernel_median_us": kernel_med_ms * 1e3,
                          "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": batch,
-                         "pairs_per_s_kernel_only": batch / (kernel_avg_ms * 1e-3)},
+                         "pairs_per_s_kernel_only": batch / (kernel_avg_ms * 1e-3),
+                         "mode": "sequential launches of the same steps on one stream (rocprof-comparable)"},
+            # whole-job throughput of the timed region expressed against the same roof (steps overlap on
+            # --streams streams, so this exceeds roofline.frac, which is a per-kernel figure)
+            "throughput_frac_of_hbm_roof": value * bpp / (HBM_PEAK_GBS * 1e9),
         }
         del rec["config"]["model"]
         if world == 1 and not args.no_cpu_baseline:

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 64 --warmup 16 --no-cpu-baseline"
+ARGS="bench.py --steps 64 --warmup 16 --no-cpu-baseline --streams 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 $ARGS > $OUT/tcc.log 2>&1
