@@ -92,10 +92,10 @@ def main():
     ap.add_argument("--graph-nodes", type=int, default=128,
                     help="kernel launches (= steps) captured per hipGraph; one replay costs ~10 us of host/launch "
                          "overhead whatever its length")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="graph launch only: the steps of the timed region are captured on this many parallel HIP "
                          "streams, so that independent steps (different batches, different outputs) overlap on the "
-                         "GPU: the next step gathers while the previous one computes (low-LDS kernel form, two "
+                         "GPU: the next steps gather while the previous ones compute (minimum-LDS kernel form, three "
                          "blocks per CU); 1 = strictly sequential launches")
     ap.add_argument("--launch", default="graph", choices=["graph", "direct"],
                     help="graph: the steps are replayed from a captured hipGraph of --distinct-batches kernel "
@@ -140,6 +140,7 @@ def main():
     if args.launch == "direct":
         args.streams = 1
     flags = ops.FLAG_LOW_LDS if (args.streams > 1 and not os.environ.get('SYMPA_BENCH_FULL_LDS')) else 0
+    flags |= int(os.environ.get('SYMPA_BENCH_FLAGS', '0'), 0)
 
     def step(i, fl=None):
         ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb],
@@ -195,6 +196,12 @@ def main():
             step(done)
             done += 1
 
+    # clock / cache pre-warm (not part of the W warmup steps or the K timed steps): ~0.2 s of the same launches,
+    # so that a GPU coming out of idle has reached its sustained clock before the contractually timed region
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.2:
+        run_steps(max(gn, nb))
+        torch.cuda.synchronize(dev)
     run_steps(args.warmup)
     sync_all()
     t0 = time.perf_counter()

@@ -40,7 +40,9 @@ using namespace sympa_hip;
 // identical to the product kernel unless a variant is being measured.
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
 __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
-    constexpr int WAVE_SLOTS = DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
+    constexpr bool PASS4 = (N == 4) && LOWLDS;   // minimum-LDS gather: three blocks of different launches per CU
+    constexpr int WAVE_SLOTS = PASS4 ? PASS4_WAVE_SLOTS
+                               : DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
                                : (PassTile<N>::ENABLED ? PassTile<N>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
     __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -73,7 +75,9 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
     } else if constexpr (Tile<N>::STAGED) {
         sympa::CMat<N> z1, z2;
         v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
-        if constexpr (DmaTile<N>::ENABLED && LOWLDS)
+        if constexpr (PASS4)
+            gather_pair_pass4(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+        else if constexpr (DmaTile<N>::ENABLED && LOWLDS)
             gather_pair_dma_low<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
         else if constexpr (DmaTile<N>::ENABLED)
             gather_pair_dma_split<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);

@@ -193,6 +193,80 @@ __device__ __forceinline__ void gather_pair_dma_low(const double* __restrict__ b
     dma_read<N>(tile, z2);
 }
 
+// Minimum-LDS form (n = 4): the 64 rows of an endpoint are gathered in 4 passes of 16 pairs -- pass p takes the
+// pairs whose lane%16 is in [4p, 4p+4), so the row index still comes from the lane's own DPP row -- through two
+// ping-pong buffers of 4 DMA instructions (4 160 B) each: 8.3 KB of LDS per wave instead of 16.6 / 33 KB, so that
+// three blocks of different launches fit on a CU (the register budget, 140 VGPRs, allows three waves per SIMD; forcing 128 VGPRs for four waves cost 36 B of
+// scratch and was slower: 11.13 vs 11.63 G pairs/s).  Measured with steps overlapped on 4 streams: 11.63 G pairs/s
+// against 10.84 for the one-endpoint-at-a-time form on 2 streams.
+template <int P, int J>
+struct DmaIssuePass4 {
+    static __device__ __forceinline__ void run(const double* __restrict__ base, const int row, const int c,
+                                               v2d* __restrict__ buf) {
+        const int rr = group_bcast<16, 4 * P + J>(row);
+        const double* src = base + (int64_t)rr * 32 + 2 * c;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + J * DmaTile<4>::INSTR_SLOTS), 16, 0, 0);
+        if constexpr (J + 1 < 4) DmaIssuePass4<P, J + 1>::run(base, row, c, buf);
+    }
+};
+
+template <int P>
+__device__ __forceinline__ void pass4_read(const v2d* __restrict__ buf, sympa::CMat<4>& z) {
+    const int lane = threadIdx.x & 63;
+    const int j = (lane & 15) - 4 * P;
+    if (j >= 0 && j < 4) {
+        const v2d* mine = buf + j * DmaTile<4>::INSTR_SLOTS + (lane >> 4) * 16;
+        v2d q[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) q[c] = mine[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fr = (i <= k) ? i * 4 + k : k * 4 + i;
+                const int fi = 16 + fr;
+                z.re[i][k] = (fr & 1) ? q[fr >> 1].y : q[fr >> 1].x;
+                z.im[i][k] = (fi & 1) ? q[fi >> 1].y : q[fi >> 1].x;
+            }
+    }
+}
+
+constexpr int PASS4_BUF_SLOTS = 4 * 65;
+constexpr int PASS4_WAVE_SLOTS = 2 * PASS4_BUF_SLOTS;
+
+template <int S>
+__device__ __forceinline__ void pass4_step(const double* __restrict__ base1, const int row1,
+                                           const double* __restrict__ base2, const int row2, v2d* __restrict__ buf0,
+                                           v2d* __restrict__ buf1, const int c, sympa::CMat<4>& z1, sympa::CMat<4>& z2) {
+    v2d* cur = (S & 1) ? buf1 : buf0;
+    v2d* nxt = (S & 1) ? buf0 : buf1;
+    if constexpr (S + 1 < 8) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): reads of the buffer being refilled are complete
+        wave_lds_fence();
+        if constexpr (S + 1 < 4) DmaIssuePass4<S + 1, 0>::run(base1, row1, c, nxt);
+        else DmaIssuePass4<S + 1 - 4, 0>::run(base2, row2, c, nxt);
+        __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): the 4 DMAs of step S have landed
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0070);
+    }
+    wave_lds_fence();
+    if constexpr (S < 4) pass4_read<S>(cur, z1);
+    else pass4_read<S - 4>(cur, z2);
+    if constexpr (S + 1 < 8) pass4_step<S + 1>(base1, row1, base2, row2, buf0, buf1, c, z1, z2);
+}
+
+__device__ __forceinline__ void gather_pair_pass4(const double* __restrict__ base1, const int row1,
+                                                  const double* __restrict__ base2, const int row2,
+                                                  v2d* __restrict__ tile, sympa::CMat<4>& z1, sympa::CMat<4>& z2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { z1.re[i][j] = 0.0; z1.im[i][j] = 0.0; z2.re[i][j] = 0.0; z2.im[i][j] = 0.0; }
+    const int c = (threadIdx.x & 63) & 15;
+    DmaIssuePass4<0, 0>::run(base1, row1, c, tile);
+    pass4_step<0>(base1, row1, base2, row2, tile, tile + PASS4_BUF_SLOTS, c, z1, z2);
+}
+
 // Both endpoints: all global loads are in flight before the first transpose starts.
 template <int N>
 __device__ __forceinline__ void gather_pair_staged(const double* __restrict__ base1, const int row1,
