@@ -28,6 +28,8 @@ int validate(const DistArgs& a, int model) {
     if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
+    if (a.num_rows * 256 >= ((int64_t)1 << 32))   // conservative for every dims <= 4
+        return fail(SYMPA_ERR_BAD_ARG, "tables are limited to 2^24 rows (32-bit row offsets in the gather)");
     return 0;
 }
 
@@ -172,6 +174,8 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
+    if (n <= 4 && a.num_rows * 16 * n * n >= ((int64_t)1 << 32))
+        return fail(SYMPA_ERR_BAD_ARG, "tables of dims <= 4 are limited to 4 GiB (32-bit row offsets in the gather)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
         case 1: return launch_n<1>(a, model, s);

@@ -114,7 +114,10 @@ struct DmaIssue {
                                                v2d* __restrict__ side) {
         constexpr int C = DmaTile<N>::C;
         const int rr = group_bcast<C, J>(row);
-        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * c;
+        // 32-bit byte offset from the (wave-uniform) table base: scalar base + vector offset addressing, no 64-bit
+        // address arithmetic per instruction (tables of n <= 4 are limited to 4 GiB, checked on the host)
+        const unsigned off = (unsigned)rr * (unsigned)(16 * N * N) + (unsigned)(16 * c);
+        const char* src = reinterpret_cast<const char*>(base) + off;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(side + J * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
         if constexpr (J + 1 < C) DmaIssue<N, J + 1>::run(base, row, c, side);
     }
@@ -204,7 +207,8 @@ struct DmaIssuePass4 {
     static __device__ __forceinline__ void run(const double* __restrict__ base, const int row, const int c,
                                                v2d* __restrict__ buf) {
         const int rr = group_bcast<16, 4 * P + J>(row);
-        const double* src = base + (int64_t)rr * 32 + 2 * c;
+        const unsigned off = (unsigned)rr * 256u + (unsigned)(16 * c);
+        const char* src = reinterpret_cast<const char*>(base) + off;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + J * DmaTile<4>::INSTR_SLOTS), 16, 0, 0);
         if constexpr (J + 1 < 4) DmaIssuePass4<P, J + 1>::run(base, row, c, buf);
     }
