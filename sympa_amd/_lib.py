@@ -100,11 +100,11 @@ def load():
                                     ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_spd_dist_fwd.restype = ctypes.c_int
     lib.sympa_spd_dist_fwd.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, _c_i32_p,
-                                       ctypes.c_void_p]
+                                       ctypes.c_int, ctypes.c_void_p]
     lib.sympa_spd_model_forward.restype = ctypes.c_int
     lib.sympa_spd_model_forward.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p,
                                             ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p,
-                                            _c_i32_p, ctypes.c_void_p]
+                                            _c_i32_p, ctypes.c_int, ctypes.c_void_p]
     _lib = lib
     return lib
 

@@ -1,5 +1,6 @@
 // gfx950 kernel + C-ABI of the SPD model (spd_math.hpp): runtime-n, per-lane scratch, 64-thread blocks.
 #include "siegel_common.hpp"
+#include "spd_coop.hpp"
 #include "spd_math.hpp"
 
 namespace {
@@ -35,14 +36,131 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
     }
 }
 
+// n = 16: sixteen lanes per pair for the O(n^3) part, one lane per pair for the QL iteration (spd_coop.hpp).
+// One wave per block, 64 pairs per wave, 32 KB of LDS: one wave per SIMD.
+__global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
+    using namespace spd_coop;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    char* const tile = lds;
+    char* const stage = lds + TILE_BYTES;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, r = lane & 15;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < a.b;
+    const int64_t ii = live ? i : a.b - 1;
+    int st = 0;
+    int64_t r1 = ii, r2 = ii;
+    if (a.ap_cols > 0) {
+        r1 = a.ap_row0 + ii / a.ap_cols;
+        r2 = ii % a.ap_cols;
+    } else if (a.idx1 != nullptr) {
+        r1 = a.idx1[ii * a.idx1_stride];
+        r2 = a.idx2[ii * a.idx2_stride];
+        if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { st |= sympa::ST_BAD_INDEX; r1 = 0; r2 = 0; }
+    }
+    const int row1 = (int)r1, row2 = (int)r2;      // num_rows < 2^31 (checked on the host)
+
+    // DMA: instruction q of a round fills LDS slots [64 q, 64 q + 64) = half h = q & 1 of matrix image q >> 1;
+    // slot s of an image holds columns {2c, 2c+1} of row s / 8 with c = (s & 7) ^ swizzle(row)  (tile_slot)
+    unsigned voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rr = h * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((rr >> 1) & 7);
+        voff[h] = (unsigned)(rr * 128 + c * 16);
+    }
+    // byte offset of element (r, j) of my pair's X image (upper triangle only: (min, max))
+    int eoff[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int lo = r < j ? r : j, hi = r < j ? j : r;
+        eoff[j] = g * 4096 + tile_slot(lo, hi >> 1) * 16 + (hi & 1) * 8;
+    }
+    auto issue = [&](const int t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int gg = q >> 2, side = (q >> 1) & 1, h = q & 1;
+            const int row = __builtin_amdgcn_readlane(side ? row2 : row1, 4 * t + gg);
+            const char* src = reinterpret_cast<const char*>(side ? a.base2 : a.base1) + (size_t)(unsigned)row * 2048u + voff[h];
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+    for (int t = 0; t < ROUNDS; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this round's images have landed
+        wave_lds_fence();
+        double x[N], y[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            x[j] = *reinterpret_cast<const double*>(tile + eoff[j]);
+            y[j] = *reinterpret_cast<const double*>(tile + 2048 + eoff[j]);
+        }
+        double rd[N], m[N];
+        bool pd = true;
+        if (!(a.flags & 0x400)) pd = reduce_pair_front(x, y, rd, m, reinterpret_cast<double*>(tile + g * 2048), r);
+        else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { m[j] = x[j] + y[j]; rd[j] = y[j]; }
+        }
+        // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        wave_lds_fence();
+        if (t + 1 < ROUNDS) issue(t + 1);
+        RoundOut o{m[0], m[1]};
+        if (!(a.flags & 0x200)) o = reduce_pair_back(m, x, rd, pd, r);
+        v2d de;
+        de.x = o.d;
+        de.y = o.e2;
+        *reinterpret_cast<v2d*>(stage + ((4 * t + g) * N + r) * 16) = de;
+    }
+    wave_lds_fence();
+    // one pair per lane: QL on the tridiagonal forms, then the norm of the logarithms
+    double d[N], e2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const v2d de = *reinterpret_cast<const v2d*>(stage + (lane * N + k) * 16);
+        d[k] = de.x;
+        e2[k] = de.y;
+    }
+    bool ok = (e2[N - 1] == 0.0);
+    e2[N - 1] = 0.0;
+    const bool conv = (a.flags & 0x100) ? true : sympa::tridiag_ql_lockstep<N>(d, e2);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        ok = ok && (d[k] > -1.0);
+        const double lg = sympa::d_log1p_signed(d[k]);
+        acc = sympa::d_fma(lg, lg, acc);
+    }
+    double out = sympa::d_sqrt(acc);
+    if (!ok) st |= sympa::ST_NOT_PD;
+    if (!conv) st |= sympa::ST_NO_CONVERGENCE;
+    if (!(out == out) || !(fabs(out) <= 1.79e308)) st |= sympa::ST_NONFINITE;
+    if (st & sympa::ST_BAD_INDEX) out = __builtin_nan("");
+    if (a.scale != nullptr) out *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);
+    if (live) a.out[i] = out;
+    if (a.status != nullptr) {
+        const int flagged = (live && st != 0) ? 1 : 0;
+        const unsigned long long mk = __ballot(flagged);
+        if (mk != 0ull) {
+            if (flagged) atomicOr(&a.status[0], st);
+            if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(mk));
+        }
+    }
+}
+
 int launch_spd(const DistArgs& a, int n, void* stream) {
     if (a.b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (a.b == 0) return 0;
     if (a.base1 == nullptr || a.base2 == nullptr || a.out == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
     if (n < 1 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: dims outside [1, 16]");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
-    hipLaunchKernelGGL(spd_dist_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
-                       reinterpret_cast<hipStream_t>(stream), a, n);
+    if (n == spd_coop::N && !(a.flags & SYMPA_FLAG_GENERIC))
+        hipLaunchKernelGGL(spd16_coop_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(spd_dist_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a, n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
@@ -52,7 +170,8 @@ int launch_spd(const DistArgs& a, int n, void* stream) {
 
 extern "C" {
 
-int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status, void* stream) {
+int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status, int flags,
+                       void* stream) {
     DistArgs a;
     std::memset(&a, 0, sizeof(a));
     a.base1 = x;
@@ -62,12 +181,13 @@ int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, doubl
     a.inv_scale_coef = 1.0;
     a.out = out;
     a.status = status;
+    a.flags = flags;
     return launch_spd(a, n, stream);
 }
 
 int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                             const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
-                            double* out, int32_t* status, void* stream) {
+                            double* out, int32_t* status, int flags, void* stream) {
     if (b > 0 && (src == nullptr || dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null index buffer");
     if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
     if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
@@ -85,6 +205,7 @@ int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const 
     a.inv_scale_coef = 1.0 / scale_coef;
     a.out = out;
     a.status = status;
+    a.flags = flags;
     return launch_spd(a, n, stream);
 }
 

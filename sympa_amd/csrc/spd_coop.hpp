@@ -1,0 +1,165 @@
+// SPD model, n = 16 (BASELINE.json configs[4]): sixteen lanes per pair, four pairs per wavefront.
+//
+// One lane per pair (spd_math.hpp) needs two 16 x 16 working matrices per lane: 4 KB of scratch per lane, and the
+// kernel runs at the speed of scratch memory.  Here lane r of a group of 16 lanes owns ROW r of every matrix of its
+// pair (16 doubles = 32 VGPRs per matrix), so everything up to the tridiagonal form stays in registers:
+//
+//   - elements of another row are read with the DPP modifier row_newbcast:j -- the only DPP mode the double-precision
+//     ALU has, and exactly "lane j of my group of 16" -- fused into the FMA:  v_fmac_f64_dpp acc, x(lane j), y
+//     is one instruction for  acc += X[j][.] * y;
+//   - the symmetric matrices are staged through the LDS by whole-row DMA (global_load_lds_dwordx4: 1 KB per
+//     instruction, 16 instructions per round of 4 pairs), one round ahead of the arithmetic;
+//   - Cholesky X = L L^T (right-looking), W = (Y - X) L^-T, a transpose through the LDS, M = W^T L^-T
+//     (= L^-1 (Y - X) L^-T), Householder tridiagonalisation with the reflector broadcast from lane k;
+//   - the tridiagonal (d, e^2) of each pair goes to the LDS; after 16 rounds the wave holds 64 of them and runs
+//     the sequential part -- PWK QL (dsterf), log1p, norm -- ONE PAIR PER LANE, all 64 lanes busy.
+//
+// Same arithmetic as spd_math.hpp (same formula, same QL, same log1p), different order of summation: the two kernels
+// agree to ~1e-14 and the tests check the one against the other and both against the oracle.
+#pragma once
+
+#include <type_traits>
+
+#include "siegel_gather.hpp"
+#include "spd_math.hpp"
+
+namespace spd_coop {
+
+constexpr int N = 16;
+constexpr int ROUNDS = 16;                       // 4 pairs per round, 64 pairs per wave
+constexpr int TILE_BYTES = 4 * 2 * N * N * 8;    // one round: 4 pairs x {X, Y} x 2 KB
+constexpr int STAGE_BYTES = 64 * N * 16;         // 64 pairs x 16 x {d, e2}
+constexpr int LDS_BYTES = TILE_BYTES + STAGE_BYTES;
+
+template <int I, int E, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, E>(f);
+    }
+}
+
+// value of lane J of my group of 16 lanes
+template <int J>
+__device__ __forceinline__ double bcast(const double v) {
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, false));
+}
+
+// acc += x(lane J of my group) * y  /  acc -= ...   in one DP-ALU DPP instruction.  The DPP source must not have been
+// written by the two preceding VALU instructions (the assembler's hazard table knows this for compiler-generated DPP
+// but not inside inline asm): the s_nop covers it.
+template <int J>
+__device__ __forceinline__ void fmac_bc(double& acc, const double x, const double y) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+template <int J>
+__device__ __forceinline__ void fnmac_bc(double& acc, const double x, const double y) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+
+// sum over the 16 lanes of my group, result in every lane (32-bit DPP rotations: the DP ALU has no row_ror)
+__device__ __forceinline__ double group_sum(double v) {
+#define SPD_COOP_ROR(CTRL)                                                                          \
+    {                                                                                               \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);    \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);    \
+        v += __hiloint2double(hi, lo);                                                              \
+    }
+    SPD_COOP_ROR(0x128) SPD_COOP_ROR(0x124) SPD_COOP_ROR(0x122) SPD_COOP_ROR(0x121)
+#undef SPD_COOP_ROR
+    return v;
+}
+
+// LDS slot (16 bytes = 2 doubles) of the pair of columns c = col / 2 of row r inside a 2 KB matrix image: the XOR makes
+// the sixteen lanes that read one column hit sixteen different slots
+__device__ __forceinline__ int tile_slot(const int r, const int c) { return r * 8 + (c ^ ((r >> 1) & 7)); }
+
+// a <- a L^-T for the rows held one per lane:  a[j] = (a[j] - sum_{k<j} a[k] L[j][k]) / L[j][j];
+// L[j][k] is register k of lane j.
+__device__ __forceinline__ void solve_right_lt(double (&a)[N], const double (&l)[N], const double (&rd)[N]) {
+    sfor<0, N>([&](auto J) {
+        constexpr int j = J;
+        sfor<0, j>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<j>(a[j], l[k], a[k]);
+        });
+        a[j] *= rd[j];
+    });
+}
+
+struct RoundOut {
+    double d, e2;    // lane r of the group: d_r and e2_r of the tridiagonal form (e2_15 carries the not-PD flag)
+};
+
+// First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
+// W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
+__device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N], double (&rd)[N], double (&m)[N],
+                                                  double* __restrict__ tbuf, const int r) {
+    // D = Y - X
+    sfor<0, N>([&](auto J) { y[J] -= x[J]; });
+    // Cholesky, right-looking, in place: after step j, register j of lane i >= j holds L[i][j]
+    bool pd = true;
+    sfor<0, N>([&](auto J) {
+        constexpr int j = J;
+        const double piv = bcast<j>(x[j]);
+        pd = pd && (piv > 0.0);
+        const double rr = sympa::d_rsqrt(piv);
+        rd[j] = rr;
+        x[j] *= rr;
+        sfor<j + 1, N>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<k>(x[k], x[j], x[j]);      // X[i][k] -= L[k][j] L[i][j]
+        });
+    });
+    // W = D L^-T, transposed through the LDS
+    solve_right_lt(y, x, rd);
+    wave_lds_fence();
+    sfor<0, N>([&](auto J) { tbuf[r * N + J] = y[J]; });
+    wave_lds_fence();
+    sfor<0, N>([&](auto J) { m[J] = tbuf[J * N + r]; });
+    return pd;
+}
+
+// Second half: M = W^T L^-T = L^-1 (Y - X) L^-T, then its tridiagonal form.
+__device__ __forceinline__ RoundOut reduce_pair_back(double (&m)[N], const double (&x)[N], const double (&rd)[N],
+                                                     const bool pd, const int r) {
+    solve_right_lt(m, x, rd);
+
+    // Householder tridiagonalisation.  The reflector of step k is taken from COLUMN k, one element per lane (my
+    // own register k), and broadcast from there for every use: with a single source for v the update is an exact
+    // similarity whatever rounding-level asymmetry M carries.  (Mixing row k of lane k with my own column element
+    // is inconsistent by that asymmetry RELATIVE TO |v|, which is large when the eliminated column is small.)
+    RoundOut o{0.0, 0.0};
+    sfor<0, N - 2>([&](auto K) {
+        constexpr int k = K;
+        const double col = m[k];
+        const double x0 = bcast<k + 1>(col);
+        const double dk = bcast<k>(col);
+        const double tail = (r > k + 1) ? col : 0.0;
+        const double s2 = group_sum(tail * tail);
+        const double n2 = sympa::d_fma(x0, x0, s2);
+        o.d = (r == k) ? dk : o.d;
+        o.e2 = (r == k) ? n2 : o.e2;
+        const double nx = sympa::d_sqrt(n2);
+        const double v0 = x0 + copysign(nx, x0);
+        const double den = sympa::d_fma(v0, v0, s2);
+        const double beta = (den > 0.0) ? 2.0 * sympa::d_rcp(den) : 0.0;
+        const double vi = (r <= k) ? 0.0 : ((r == k + 1) ? v0 : col);
+        double p = 0.0;
+        sfor<k + 1, N>([&](auto J) { fmac_bc<J>(p, vi, m[J]); });      // p_i = sum_j M[i][j] v_j
+        p = (r <= k) ? 0.0 : beta * p;
+        const double kk = 0.5 * beta * group_sum(vi * p);
+        const double q = sympa::d_fma(-kk, vi, p);
+        // M <- M - q v^T - v q^T on the trailing block (lanes <= k have v = q = 0 and keep their rows)
+        sfor<k + 1, N>([&](auto J) {
+            constexpr int j = J;
+            fnmac_bc<j>(m[j], vi, q);       // - v_j q_i
+            fnmac_bc<j>(m[j], q, vi);       // - q_j v_i
+        });
+    });
+    o.d = (r == N - 2) ? m[N - 2] : ((r == N - 1) ? m[N - 1] : o.d);
+    o.e2 = (r == N - 2) ? m[N - 1] * m[N - 1] : ((r == N - 1) ? (pd ? 0.0 : 1.0) : o.e2);
+    return o;
+}
+
+}  // namespace spd_coop

@@ -83,6 +83,7 @@ def _weights(metric, weights, n, device):
 
 
 FLAG_LOW_LDS = 1
+FLAG_GENERIC = 2      # spd: force the runtime-n one-lane-per-pair kernel
 
 
 def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=None, return_vvd=False, flags=0):
@@ -354,7 +355,7 @@ def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None
 # ---------------------------------------------------------------------------------------------------
 # SPD model (C-ABI sympa_spd_dist_fwd / sympa_spd_model_forward)
 # ---------------------------------------------------------------------------------------------------
-def spd_dist_forward(x, y):
+def spd_dist_forward(x, y, flags=0):
     lib = _lib.load()
     _need_gpu(x, "x"); _need_gpu(y, "y")
     if x.dtype != torch.float64 or x.shape != y.shape or x.dim() != 3 or x.shape[1] != x.shape[2]:
@@ -364,14 +365,14 @@ def spd_dist_forward(x, y):
     st = _status_buf(x.device)
     with torch.cuda.device(x.device):
         rc = lib.sympa_spd_dist_fwd(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), st.data_ptr(),
-                                    _stream())
+                                    int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(x.device)
     return out
 
 
-def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None):
+def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, flags=0):
     lib = _lib.load()
     _need_gpu(table, "table"); _need_gpu(triplets, "triplets")
     if table.dtype != torch.float64 or table.dim() != 3 or table.shape[1] != table.shape[2]:
@@ -396,7 +397,7 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None):
     with torch.cuda.device(tab.device):
         rc = lib.sympa_spd_model_forward(tab.data_ptr(), tab.shape[0], tab.shape[1], tp, stride, tp + 8, stride, b,
                                          None if sc is None else sc.data_ptr(), float(scale_coef), out.data_ptr(),
-                                         st.data_ptr(), _stream())
+                                         st.data_ptr(), int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(tab.device)

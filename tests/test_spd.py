@@ -59,3 +59,45 @@ def test_gpu_spd_kernel_and_model(n):
         out = m(trip.to(dev)).cpu()
     want = so.spd_model_forward(m.embeddings.embeds.detach().cpu(), trip, m.scale.detach().cpu(), 1.0)
     assert rel_err(out, want) < 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_spd16_cooperative_kernel_against_oracle_and_generic_kernel():
+    """n = 16 runs sixteen lanes per pair (csrc/spd_coop.hpp); FLAG_GENERIC forces the one-lane-per-pair kernel."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1616)
+    for b, s in ((1, 0.3), (63, 1e-3), (64, 0.3), (65, 1.0), (1000, 0.3), (4099, 1e-3)):
+        x, y = spd_points(b, 16, s, g), spd_points(b, 16, s, g)
+        coop = ops.spd_dist_forward(x.to(dev), y.to(dev)).cpu()
+        ops.check_status(dev)
+        gen = ops.spd_dist_forward(x.to(dev), y.to(dev), flags=ops.FLAG_GENERIC).cpu()
+        ops.check_status(dev)
+        # s = 1.0: cond(x) reaches 1e5-1e6 at n = 16 and every fp64 evaluation is conditioning-limited near 1e-9
+        tol = 1e-7 if s >= 1.0 else 1e-12
+        assert rel_err(coop, so.spd_dist(x, y)) < tol, (b, s)
+        assert rel_err(coop, gen) < tol, (b, s)
+    # only the upper triangle is read (include/sympa_hip.h), by both kernels
+    junk = x.clone()
+    il = torch.tril_indices(16, 16, -1)
+    junk[:, il[0], il[1]] = 7.0
+    assert torch.equal(ops.spd_dist_forward(junk.to(dev), y.to(dev)).cpu(), coop)
+    # d(x, x) = 0 exactly; a non-PD operand raises the status bit
+    assert torch.all(ops.spd_dist_forward(x.to(dev), x.to(dev)) == 0)
+    ops.check_status(dev)
+    bad = x.clone()
+    bad[77] = -bad[77]
+    ops.spd_dist_forward(bad.to(dev), y.to(dev))
+    with pytest.raises(Exception):
+        ops.check_status(dev)
+    # gathered form, with an index outside the table
+    table = spd_points(300, 16, 0.3, g)
+    trip = torch.randint(0, 300, (777, 3), generator=g)
+    out = ops.spd_model_forward(table.to(dev), trip.to(dev)).cpu()
+    ops.check_status(dev)
+    assert rel_err(out, so.spd_dist(table[trip[:, 0]], table[trip[:, 1]])) < 1e-9
+    trip[5, 1] = 300
+    out = ops.spd_model_forward(table.to(dev), trip.to(dev)).cpu()
+    assert torch.isnan(out[5]) and not torch.isnan(out[4])
+    with pytest.raises(Exception):
+        ops.check_status(dev)

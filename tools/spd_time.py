@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Times the SPD distance kernels: python tools/spd_time.py [n] [batch] [num_rows]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+
+from sympa_amd import ops
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+rows = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1)
+a = torch.randn(rows, n, n, generator=g, dtype=torch.float64) * 0.05
+a = 0.5 * (a + a.transpose(-1, -2))
+table = (torch.eye(n, dtype=torch.float64) + a + a @ a * 0.5).to(dev)
+trip = torch.randint(0, rows, (b, 3), generator=g).to(dev)
+out = torch.empty(b, dtype=torch.float64, device=dev)
+for name, fl in (("specialised", 0), ("noQL", 0x100), ("noQL-noBack", 0x300), ("loadsOnly", 0x700), ("generic", ops.FLAG_GENERIC)):
+    if fl and n != 16:
+        continue
+    for _ in range(2):
+        ops.spd_model_forward(table, trip, out=out, flags=fl)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.spd_model_forward(table, trip, out=out, flags=fl)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    bytes_per_pair = 2 * n * n * 8 + 16 + 8
+    print(f"spd n={n} b={b} rows={rows} {name}: {dt * 1e3:.3f} ms  {b / dt / 1e6:.1f} M pairs/s  "
+          f"{b * bytes_per_pair / dt / 1e9:.0f} GB/s algorithmic ({b * bytes_per_pair / dt / 8e12:.3f} of the HBM roof)")
