@@ -623,21 +623,44 @@ SYMPA_HD bool tridiag_ql(double (&d)[N], double (&e2)[N]) {
 // ~1000 instructions per iteration at N = 16, ~50 iterations for the slowest of 64 lanes), its length shrinks with
 // l, and the instruction count drops ~5x.  Interior off-diagonals that become negligible are simply rotated
 // through (c = 1, s = 0); p + b = 0 is the only new case and means "no rotation".
+// Lanes that are through with position L do not idle until the slowest one is: they take their shift from the
+// first position in {L+1, L+2} that still has a non-negligible off-diagonal (a deflated e^2 = 0 makes the
+// sweep pass through that position with c = 1, s = 0: an identity), so they arrive at the next stages converged.
+SYMPA_HD bool ql_negligible(double e2, double da, double db) { return e2 <= 1.3e-32 * fabs(da * db) + 1e-290; }
+
 template <int N, int L>
 SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
-    constexpr double TOL = 1.3e-32;
     bool conv = false;
     for (int it = 0; it < 60; ++it) {
-        conv = e2[L] <= TOL * fabs(d[L] * d[L + 1]) + 1e-290;
+        conv = ql_negligible(e2[L], d[L], d[L + 1]);
         if (wave_all(conv)) break;
-        const double el = conv ? 1.0 : e2[L];
+        double dl = d[L], dl1 = d[L + 1], el = e2[L];
+        bool idle = conv;
+        e2[L] = conv ? 0.0 : e2[L];
+        if constexpr (L + 1 <= N - 2) {
+            const bool c1 = ql_negligible(e2[L + 1], d[L + 1], d[L + 2]);
+            dl = idle ? d[L + 1] : dl;
+            dl1 = idle ? d[L + 2] : dl1;
+            el = idle ? e2[L + 1] : el;
+            idle = idle && c1;
+            e2[L + 1] = idle ? 0.0 : e2[L + 1];
+            if constexpr (L + 2 <= N - 2) {
+                const bool c2 = ql_negligible(e2[L + 2], d[L + 2], d[L + 3]);
+                dl = idle ? d[L + 2] : dl;
+                dl1 = idle ? d[L + 3] : dl1;
+                el = idle ? e2[L + 2] : el;
+                idle = idle && c2;
+                e2[L + 2] = idle ? 0.0 : e2[L + 2];
+            }
+        }
+        // Wilkinson shift from the 2 x 2 at the lane's position; an idle lane sweeps with the eigenvalue itself
+        el = idle ? 1.0 : el;
         const double irte = d_rsqrt(el);
         const double rte = el * irte;
-        const double sg = 0.5 * (d[L + 1] - d[L]) * irte;
+        const double sg = 0.5 * (dl1 - dl) * irte;
         const double rr = d_sqrt(d_fma(sg, sg, 1.0));
-        double sigma = d[L] - rte * d_rcp(sg + copysign(rr, sg));
-        sigma = conv ? d[L] : sigma;
-        e2[L] = conv ? 0.0 : e2[L];
+        double sigma = dl - rte * d_rcp(sg + copysign(rr, sg));
+        sigma = idle ? dl : sigma;
         double c = 1.0, sn = 0.0, gamma = d[N - 1] - sigma, p = gamma * gamma;
 #pragma unroll
         for (int i = N - 2; i >= L; --i) {
@@ -645,15 +668,19 @@ SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
             const double r = p + bb;
             if (i != N - 2) e2[i + 1] = sn * r;
             const double oldc = c;
-            const bool none = !(r > 0.0);
-            const double ir = d_rcp(none ? 1.0 : r);
-            c = none ? 1.0 : p * ir;
+            // r = 0 (p = b = 0: decoupled and converged) must give c = 1, s = 0: with rs = max(r, tiny),
+            // c = (p + (rs - r)) / rs is p / r whenever r > tiny and tiny / tiny = 1 for r = 0
+            const double rs = fmax(r, TINY);
+            const double ir = d_rcp(rs);
+            c = (p + (rs - r)) * ir;
             sn = bb * ir;
             const double oldgam = gamma;
             const double alpha = d[i];
             gamma = d_fma(c, alpha - sigma, -sn * oldgam);
             d[i + 1] = oldgam + (alpha - gamma);
-            p = (c != 0.0) ? gamma * gamma * d_rcp(c) : oldc * bb;
+            const double pn = gamma * gamma * d_rcp(c);
+            const double pz = oldc * bb;
+            p = (c != 0.0) ? pn : pz;
         }
         e2[L] = sn * p;
         d[L] = sigma + gamma;

@@ -37,15 +37,13 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
 }
 
 // n = 16: sixteen lanes per pair for the O(n^3) part, one lane per pair for the QL iteration (spd_coop.hpp).
-// One wave per block, 64 pairs per wave, 32 KB of LDS: one wave per SIMD.
+// One wave per block, 64 pairs per wave, 16 KB of LDS.  Lane 16 g + t owns pair 4 t + g of the wave's 64.
 __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
     using namespace spd_coop;
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    char* const tile = lds;
-    char* const stage = lds + TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char tile[LDS_BYTES];
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = (int64_t)blockIdx.x * 64 + 4 * r + g;
     const bool live = i < a.b;
     const int64_t ii = live ? i : a.b - 1;
     int st = 0;
@@ -80,11 +78,15 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int gg = q >> 2, side = (q >> 1) & 1, h = q & 1;
-            const int row = __builtin_amdgcn_readlane(side ? row2 : row1, 4 * t + gg);
+            const int row = __builtin_amdgcn_readlane(side ? row2 : row1, 16 * gg + t);
             const char* src = reinterpret_cast<const char*>(side ? a.base2 : a.base1) + (size_t)(unsigned)row * 2048u + voff[h];
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 1024), 16, 0, 0);
         }
     };
+    double d[N], e2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { d[k] = 0.0; e2[k] = 0.0; }
+    bool ok = true;
     issue(0);
     for (int t = 0; t < ROUNDS; ++t) {
         __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this round's images have landed
@@ -96,35 +98,17 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
             y[j] = *reinterpret_cast<const double*>(tile + 2048 + eoff[j]);
         }
         double rd[N], m[N];
-        bool pd = true;
-        if (!(a.flags & 0x400)) pd = reduce_pair_front(x, y, rd, m, reinterpret_cast<double*>(tile + g * 2048), r);
-        else {
-#pragma unroll
-            for (int j = 0; j < N; ++j) { m[j] = x[j] + y[j]; rd[j] = y[j]; }
-        }
+        const bool pd = reduce_pair_front(x, y, rd, m, reinterpret_cast<double*>(tile + g * 2048), r);
         // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
         __builtin_amdgcn_s_waitcnt(0xC07F);
         wave_lds_fence();
         if (t + 1 < ROUNDS) issue(t + 1);
-        RoundOut o{m[0], m[1]};
-        if (!(a.flags & 0x200)) o = reduce_pair_back(m, x, rd, pd, r);
-        v2d de;
-        de.x = o.d;
-        de.y = o.e2;
-        *reinterpret_cast<v2d*>(stage + ((4 * t + g) * N + r) * 16) = de;
+        const bool keep = (r == t);
+        ok = keep ? pd : ok;
+        reduce_pair_back(m, x, rd, r, keep, d, e2);
     }
-    wave_lds_fence();
     // one pair per lane: QL on the tridiagonal forms, then the norm of the logarithms
-    double d[N], e2[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const v2d de = *reinterpret_cast<const v2d*>(stage + (lane * N + k) * 16);
-        d[k] = de.x;
-        e2[k] = de.y;
-    }
-    bool ok = (e2[N - 1] == 0.0);
-    e2[N - 1] = 0.0;
-    const bool conv = (a.flags & 0x100) ? true : sympa::tridiag_ql_lockstep<N>(d, e2);
+    const bool conv = sympa::tridiag_ql_lockstep<N>(d, e2);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {

@@ -11,8 +11,10 @@
 //     instruction, 16 instructions per round of 4 pairs), one round ahead of the arithmetic;
 //   - Cholesky X = L L^T (right-looking), W = (Y - X) L^-T, a transpose through the LDS, M = W^T L^-T
 //     (= L^-1 (Y - X) L^-T), Householder tridiagonalisation with the reflector broadcast from lane k;
-//   - the tridiagonal (d, e^2) of each pair goes to the LDS; after 16 rounds the wave holds 64 of them and runs
-//     the sequential part -- PWK QL (dsterf), log1p, norm -- ONE PAIR PER LANE, all 64 lanes busy.
+//   - d_k and e_k^2 of the tridiagonal form come out of step k as group-uniform values (every lane of the group has
+//     them): in round t lane t of the group keeps them, so after 16 rounds EVERY lane holds one complete tridiagonal
+//     matrix in registers and the wave runs the sequential part -- PWK QL (dsterf), log1p, norm -- ONE PAIR PER
+//     LANE, all 64 lanes busy.  Lane 16 g + t therefore owns pair 4 t + g of the wave's 64.
 //
 // Same arithmetic as spd_math.hpp (same formula, same QL, same log1p), different order of summation: the two kernels
 // agree to ~1e-14 and the tests check the one against the other and both against the oracle.
@@ -28,8 +30,7 @@ namespace spd_coop {
 constexpr int N = 16;
 constexpr int ROUNDS = 16;                       // 4 pairs per round, 64 pairs per wave
 constexpr int TILE_BYTES = 4 * 2 * N * N * 8;    // one round: 4 pairs x {X, Y} x 2 KB
-constexpr int STAGE_BYTES = 64 * N * 16;         // 64 pairs x 16 x {d, e2}
-constexpr int LDS_BYTES = TILE_BYTES + STAGE_BYTES;
+constexpr int LDS_BYTES = TILE_BYTES;            // the transpose of a round reuses the (consumed) tile
 
 template <int I, int E, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -42,27 +43,33 @@ __device__ __forceinline__ void sfor(F&& f) {
 // value of lane J of my group of 16 lanes
 template <int J>
 __device__ __forceinline__ double bcast(const double v) {
-    return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, false));
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, true));
 }
 
-// acc += x(lane J of my group) * y  /  acc -= ...   in one DP-ALU DPP instruction.  The DPP source must not have been
-// written by the two preceding VALU instructions (the assembler's hazard table knows this for compiler-generated DPP
-// but not inside inline asm): the s_nop covers it.
+// acc += x(lane J of my group) * y  /  acc -= ...   in one DP-ALU DPP instruction.
+// Hazard: a DPP source VGPR must not have been written by the two preceding VALU instructions.  The assembler's
+// hazard recogniser inserts the wait states for compiler-generated DPP but sees neither the DPP read nor the VGPR
+// write inside inline asm, so every value that is used as a DPP source is passed through settle() after its last
+// write: an s_nop that the value "depends on", which therefore sits between the write and every DPP read.
+__device__ __forceinline__ double settle(double v) {
+    asm("s_nop 1" : "+v"(v));
+    return v;
+}
 template <int J>
 __device__ __forceinline__ void fmac_bc(double& acc, const double x, const double y) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
 }
 template <int J>
 __device__ __forceinline__ void fnmac_bc(double& acc, const double x, const double y) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
 }
 
 // sum over the 16 lanes of my group, result in every lane (32-bit DPP rotations: the DP ALU has no row_ror)
 __device__ __forceinline__ double group_sum(double v) {
 #define SPD_COOP_ROR(CTRL)                                                                          \
     {                                                                                               \
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);    \
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);    \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);    \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);    \
         v += __hiloint2double(hi, lo);                                                              \
     }
     SPD_COOP_ROR(0x128) SPD_COOP_ROR(0x124) SPD_COOP_ROR(0x122) SPD_COOP_ROR(0x121)
@@ -87,10 +94,6 @@ __device__ __forceinline__ void solve_right_lt(double (&a)[N], const double (&l)
     });
 }
 
-struct RoundOut {
-    double d, e2;    // lane r of the group: d_r and e2_r of the tridiagonal form (e2_15 carries the not-PD flag)
-};
-
 // First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
 // W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
 __device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N], double (&rd)[N], double (&m)[N],
@@ -101,11 +104,11 @@ __device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N]
     bool pd = true;
     sfor<0, N>([&](auto J) {
         constexpr int j = J;
-        const double piv = bcast<j>(x[j]);
+        const double piv = bcast<j>(settle(x[j]));
         pd = pd && (piv > 0.0);
         const double rr = sympa::d_rsqrt(piv);
         rd[j] = rr;
-        x[j] *= rr;
+        x[j] = settle(x[j] * rr);
         sfor<j + 1, N>([&](auto K) {
             constexpr int k = K;
             fnmac_bc<k>(x[k], x[j], x[j]);      // X[i][k] -= L[k][j] L[i][j]
@@ -120,36 +123,37 @@ __device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N]
     return pd;
 }
 
-// Second half: M = W^T L^-T = L^-1 (Y - X) L^-T, then its tridiagonal form.
-__device__ __forceinline__ RoundOut reduce_pair_back(double (&m)[N], const double (&x)[N], const double (&rd)[N],
-                                                     const bool pd, const int r) {
+// Second half: M = W^T L^-T = L^-1 (Y - X) L^-T, then its tridiagonal form (d, e2), kept by the lane with keep = true.
+__device__ __forceinline__ void reduce_pair_back(double (&m)[N], const double (&x)[N], const double (&rd)[N],
+                                                 const int r, const bool keep, double (&d)[N], double (&e2)[N]) {
     solve_right_lt(m, x, rd);
 
     // Householder tridiagonalisation.  The reflector of step k is taken from COLUMN k, one element per lane (my
     // own register k), and broadcast from there for every use: with a single source for v the update is an exact
     // similarity whatever rounding-level asymmetry M carries.  (Mixing row k of lane k with my own column element
     // is inconsistent by that asymmetry RELATIVE TO |v|, which is large when the eliminated column is small.)
-    RoundOut o{0.0, 0.0};
     sfor<0, N - 2>([&](auto K) {
         constexpr int k = K;
-        const double col = m[k];
+        const double col = settle(m[k]);
         const double x0 = bcast<k + 1>(col);
         const double dk = bcast<k>(col);
         const double tail = (r > k + 1) ? col : 0.0;
         const double s2 = group_sum(tail * tail);
         const double n2 = sympa::d_fma(x0, x0, s2);
-        o.d = (r == k) ? dk : o.d;
-        o.e2 = (r == k) ? n2 : o.e2;
+        d[k] = keep ? dk : d[k];
+        e2[k] = keep ? n2 : e2[k];
         const double nx = sympa::d_sqrt(n2);
         const double v0 = x0 + copysign(nx, x0);
         const double den = sympa::d_fma(v0, v0, s2);
         const double beta = (den > 0.0) ? 2.0 * sympa::d_rcp(den) : 0.0;
-        const double vi = (r <= k) ? 0.0 : ((r == k + 1) ? v0 : col);
-        double p = 0.0;
-        sfor<k + 1, N>([&](auto J) { fmac_bc<J>(p, vi, m[J]); });      // p_i = sum_j M[i][j] v_j
+        const double vi = settle((r <= k) ? 0.0 : ((r == k + 1) ? v0 : col));
+        // p_i = sum_j M[i][j] v_j, four partial sums: the chain is the latency of the step
+        double ps[4] = {0.0, 0.0, 0.0, 0.0};
+        sfor<k + 1, N>([&](auto J) { fmac_bc<J>(ps[J % 4], vi, m[J]); });
+        double p = (ps[0] + ps[1]) + (ps[2] + ps[3]);
         p = (r <= k) ? 0.0 : beta * p;
         const double kk = 0.5 * beta * group_sum(vi * p);
-        const double q = sympa::d_fma(-kk, vi, p);
+        const double q = settle(sympa::d_fma(-kk, vi, p));
         // M <- M - q v^T - v q^T on the trailing block (lanes <= k have v = q = 0 and keep their rows)
         sfor<k + 1, N>([&](auto J) {
             constexpr int j = J;
@@ -157,9 +161,13 @@ __device__ __forceinline__ RoundOut reduce_pair_back(double (&m)[N], const doubl
             fnmac_bc<j>(m[j], q, vi);       // - q_j v_i
         });
     });
-    o.d = (r == N - 2) ? m[N - 2] : ((r == N - 1) ? m[N - 1] : o.d);
-    o.e2 = (r == N - 2) ? m[N - 1] * m[N - 1] : ((r == N - 1) ? (pd ? 0.0 : 1.0) : o.e2);
-    return o;
+    const double last = settle(m[N - 1]);
+    const double dm = bcast<N - 2>(settle(m[N - 2]));
+    const double dn = bcast<N - 1>(last);
+    const double en = bcast<N - 2>(last);
+    d[N - 2] = keep ? dm : d[N - 2];
+    d[N - 1] = keep ? dn : d[N - 1];
+    e2[N - 2] = keep ? en * en : e2[N - 2];
 }
 
 }  // namespace spd_coop

@@ -19,7 +19,7 @@ a = 0.5 * (a + a.transpose(-1, -2))
 table = (torch.eye(n, dtype=torch.float64) + a + a @ a * 0.5).to(dev)
 trip = torch.randint(0, rows, (b, 3), generator=g).to(dev)
 out = torch.empty(b, dtype=torch.float64, device=dev)
-for name, fl in (("specialised", 0), ("noQL", 0x100), ("noQL-noBack", 0x300), ("loadsOnly", 0x700), ("generic", ops.FLAG_GENERIC)):
+for name, fl in (("specialised", 0), ("generic", ops.FLAG_GENERIC)):
     if fl and n != 16:
         continue
     for _ in range(2):
