@@ -30,15 +30,17 @@ WORKLOADS = {
     "grid-upper-riem-n2-b512": ("upper", "riem", 2, 125, 512),     # configs[0]
     "margulis-bounded-finf-n4-b65536": ("bounded", "finf", 4, 5041, 65536),  # configs[2]
     "cartesian-upper-riem-n8-b262144": ("upper", "riem", 8, 45500, 262144),  # configs[3], per-GPU shard 32768 at 8 GPUs
+    "custom-spd-n16-b1048576": ("spd", "riem", 16, 100000, 1048576),         # configs[4] (parity unpinned: geoopt absent)
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # AMD datasheet (vector fp64); reported as the honest second roof
 
 
-def algorithmic_bytes_per_pair(n):
-    """2 int64 indices + two fp64 [2,n,n] points + one fp64 output, no reuse credit."""
-    return 2 * 8 + 2 * (2 * n * n * 8) + 8
+def algorithmic_bytes_per_pair(n, model="upper"):
+    """2 int64 indices + two fp64 points ([2,n,n] Siegel, [n,n] spd) + one fp64 output, no reuse credit."""
+    planes = 1 if model == "spd" else 2
+    return 2 * 8 + 2 * (planes * n * n * 8) + 8
 
 
 def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
@@ -46,7 +48,16 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
     import torch
     from oracle import siegel_oracle as so
     from sympa_amd import data
-    table = data.trained_like_table(nodes, n, model=model, seed=seed)
+    if model == "spd":
+        table = data.spd_table(nodes, n, seed=seed)
+        batch = min(batch, 65536)
+        one = torch.ones(1, dtype=torch.float64)
+
+        def oracle_forward(tab, pr, _model, _metric):
+            return so.spd_model_forward(tab, pr, one, 1.0)
+    else:
+        table = data.trained_like_table(nodes, n, model=model, seed=seed)
+        oracle_forward = so.model_forward
     pairs = data.sample_pairs(nodes, batch, 0, seed)
     # batched LAPACK eigh on tiny matrices does not scale with threads and collapses
     # when oversubscribed: pick the fastest of a few thread counts on a small probe, report that one
@@ -56,9 +67,9 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
     with torch.no_grad():
         for threads in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
             torch.set_num_threads(threads)
-            so.model_forward(table, probe[:1024], model, metric)     # warm
+            oracle_forward(table, probe[:1024], model, metric)     # warm
             t0 = time.perf_counter()
-            so.model_forward(table, probe, model, metric)
+            oracle_forward(table, probe, model, metric)
             rate = len(probe) / (time.perf_counter() - t0)
             if rate > best[1]:
                 best = (threads, rate)
@@ -67,14 +78,15 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
         done, t0 = 0, time.perf_counter()
         iters = 0
         while True:
-            so.model_forward(table, pairs, model, metric)
+            oracle_forward(table, pairs, model, metric)
             done += batch
             iters += 1
             el = time.perf_counter() - t0
             if el > budget_s or iters >= 50:
                 break
     return {"value": done / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} x batch {batch} of the same workload, oracle/siegel_oracle.py model_forward, "
+            "sample": f"{iters} x batch {batch} of the same workload, oracle/siegel_oracle.py "
+                      f"{'spd_model_forward' if model == 'spd' else 'model_forward'}, "
                       f"{el:.1f} s"}
 
 
@@ -123,8 +135,11 @@ def main():
     model, metric, n, nodes, batch = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    table_cpu = (data.trained_like_table(nodes, n, model=model, seed=args.seed) if args.table == "trained"
-                 else data.init_table(nodes, n, seed=args.seed))
+    if model == "spd":
+        table_cpu = data.spd_table(nodes, n, seed=args.seed)
+    else:
+        table_cpu = (data.trained_like_table(nodes, n, model=model, seed=args.seed) if args.table == "trained"
+                     else data.init_table(nodes, n, seed=args.seed))
     if args.table == "init" and model == "bounded":
         raise SystemExit("init table is defined for the upper model")
     table = table_cpu.to(dev)
@@ -143,6 +158,9 @@ def main():
     flags |= int(os.environ.get('SYMPA_BENCH_FLAGS', '0'), 0)
 
     def step(i, fl=None):
+        if model == "spd":
+            ops.spd_model_forward(table, batches[i % nb], scale, 1.0, out=outs[i % nb])
+            return
         ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb],
                           flags=flags if fl is None else fl)
 
@@ -251,7 +269,7 @@ def main():
     if rank == 0:
         pairs_total = batch * world * args.steps
         value = pairs_total / elapsed
-        bpp = algorithmic_bytes_per_pair(n)
+        bpp = algorithmic_bytes_per_pair(n, model)
         achieved = bpp * batch / (kernel_avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -262,7 +280,8 @@ def main():
                 traffic = None
         rec = {
             "metric": "pairwise Siegel distances/sec (upper, riem, n=4)" if args.workload == "upper-riem-n4-b65536"
-                      else f"pairwise Siegel distances/sec ({model}, {metric}, n={n})",
+                      else (f"pairwise SPD affine-invariant distances/sec (n={n})" if model == "spd"
+                            else f"pairwise Siegel distances/sec ({model}, {metric}, n={n})"),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -272,7 +291,7 @@ def main():
                        "parallelism": f"pairs sharded rank::{world}, table replicated, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "siegel_dist_kernel", "kernel_avg_us": kernel_avg_ms * 1e3,
+                         "kernel": "spd16_coop_kernel" if model == "spd" else "siegel_dist_kernel", "kernel_avg_us": kernel_avg_ms * 1e3,
                          "kernel_median_us": kernel_med_ms * 1e3,
                          "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": batch,
                          "pairs_per_s_kernel_only": batch / (kernel_avg_ms * 1e-3),

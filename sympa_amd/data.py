@@ -74,6 +74,14 @@ def trained_like_table(num_points, dims, scale=0.3, seed=42, model="upper"):
     return torch.from_numpy(np.stack((w.real, w.imag), 1))
 
 
+def spd_table(num_points, dims, scale=0.1, seed=42):
+    """[N, n, n] SPD points expm(sym(N*s)) for the `spd` model (configs[4]); same keyed RNG as the Siegel tables."""
+    cnt = np.arange(num_points * dims * dims, dtype=np.uint64)
+    a = _sym((keyed_normal(seed, 5, cnt) * scale).reshape(num_points, dims, dims))
+    lam, vec = np.linalg.eigh(a)
+    return torch.from_numpy(_sym((vec * np.exp(lam)[:, None, :]) @ np.swapaxes(vec, -1, -2)))
+
+
 def sample_pairs(num_points, batch, batch_id=0, seed=42):
     """int64 [batch,2]: pair k of batch `batch_id` is (i, (i + 1 + U[0, N-2]) mod N), i != j."""
     base = np.uint64(batch_id) * np.uint64(batch)
