@@ -15,3 +15,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof --
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -3 | tee $OUT/kernel_stats_head.txt
 bash tools/pmc_collect.sh $TAG > $OUT/pmc.log 2>&1
 tail -25 $OUT/pmc.log
+echo "== secondary workloads (rocprof kernel trace of each)"
+for W in margulis-bounded-finf-n4-b65536 cartesian-upper-riem-n8-b262144 custom-spd-n16-b1048576; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --steps 64 --warmup 8 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
+  tail -1 $OUT/bench_$W.json | cut -c1-400
+  find $OUT/prof_$W -name "*kernel_stats.csv" | head -1 | xargs -r head -2
+done
