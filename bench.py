@@ -128,9 +128,12 @@ def main():
     _lib.load()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SYMPA_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL process group, barriers, max-over-ranks) on one GPU
+    use_dist = world > 1 or bool(os.environ.get("SYMPA_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     model, metric, n, nodes, batch = WORKLOADS[args.workload]
     if args.batch:
@@ -166,7 +169,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -178,7 +181,9 @@ def main():
         streams = args.streams if streams is None else streams
         g_ = torch.cuda.CUDAGraph()
         side = [torch.cuda.Stream(device=dev) for _ in range(max(0, streams - 1))]
-        with torch.cuda.graph(g_):
+        # thread_local: with N > 1 the RCCL watchdog thread polls events while we capture; only THIS thread's calls
+        # belong to the capture
+        with torch.cuda.graph(g_, capture_error_mode="thread_local"):
             main = torch.cuda.current_stream()
             for st in side:
                 st.wait_stream(main)                     # fork
@@ -199,15 +204,17 @@ def main():
         for i in range(nb):
             step(i)            # warm (allocates the status word etc. outside capture)
         torch.cuda.synchronize(dev)
-        gn = max(nb, (min(args.graph_nodes, max(args.steps, nb)) // nb) * nb)   # multiple of nb
+        gn = max(1, min(args.graph_nodes, args.steps))
         graphs.append((gn, capture(gn)))
-        if gn != nb:
-            graphs.append((nb, capture(nb)))
+        # exact-size graphs for what is left of K and of W after the long replays: no step of the timed region is
+        # launched from Python (a direct call is host-bound at ~15 us), whatever K the caller asks for
+        for rem in sorted({args.steps % gn, args.warmup % gn} - {0, gn}, reverse=True):
+            graphs.append((rem, capture(rem)))
 
     def run_steps(k):
         done = 0
         for nodes, g_ in graphs:
-            while k - done >= nodes:
+            while k - done >= nodes and (nodes == gn or k - done == nodes):
                 g_.replay()
                 done += nodes
         while done < k:
@@ -227,7 +234,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     ops.check_status(dev)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -305,10 +312,18 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, batch, args.seed)
         else:
             rec["cpu_baseline"] = None
-        print(json.dumps(rec), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: flush whatever native libraries (RCCL's version banner) still hold
+        # in C stdio buffers first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
