@@ -55,7 +55,7 @@ extern "C" {
                                 (n = 16); the tests cross-check the two */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
-#define SYMPA_MAX_DIMS_BACKWARD 6 /* largest n with a backward kernel in this build */
+#define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] runs a runtime-n fallback kernel (scratch) */
 
 /* Library / build identification. */

@@ -1,0 +1,220 @@
+// Backward kernel template shared by the translation units siegel_bwd.hip (n <= 6) and
+// siegel_bwd_n{7,8}_{upper,bounded}.hip.
+#pragma once
+#include "siegel_common.hpp"
+#include "siegel_gather.hpp"
+#include "siegel_math_bwd.hpp"
+
+namespace sympa_hip {
+
+struct BwdArgs {
+    DistArgs f;              // forward arguments (f.out may be null)
+    const double* go;        // [b] dLoss/d(out)
+    double* g1;              // dense [b,2,n,n] or the grad table
+    double* g2;              // dense [b,2,n,n] or the grad table
+    double* gw;              // [n] accumulated, or null
+    double* gscale;          // [1] accumulated, or null
+    const double* graph_dist;   // fused loss: [b] graph distances (then `go` is ignored), or null
+    double* loss;               // fused loss: [1] accumulated sum |(d/g)^2 - 1| * loss_scale
+    double loss_scale;
+};
+
+// (Scattering only the n(n+1) upper-triangle entries of the symmetric rows and mirroring afterwards was
+// measured SLOWER, 43.7 vs 38.5 us per 65 536 pairs: the atomic wave-instructions lose their contiguous
+// whole-row shape, which matters more than the 37 % fewer bytes.)
+template <int N>
+struct ScatterTile {
+    static constexpr int ROWD = 2 * N * N;           // doubles per row
+    static constexpr int PITCH = ROWD + 1;           // odd pitch: conflict-free ds_write_b64 per lane
+    static constexpr int WAVE_DOUBLES = 64 * PITCH;
+};
+
+template <int N>
+__device__ __forceinline__ void scatter_add_rows(const sympa::CMat<N>& g, const int row, double* __restrict__ grad,
+                                                 double* __restrict__ tile, const bool live) {
+    constexpr int ROWD = ScatterTile<N>::ROWD, PITCH = ScatterTile<N>::PITCH;
+    const int lane = threadIdx.x & 63;
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            tile[lane * PITCH + i * N + j] = live ? g.re[i][j] : 0.0;
+            tile[lane * PITCH + N * N + i * N + j] = live ? g.im[i][j] : 0.0;
+        }
+    wave_lds_fence();
+#pragma unroll 4
+    for (int t = 0; t < ROWD; ++t) {
+        const int gidx = t * 64 + lane;
+        const int p = gidx / ROWD, e = gidx - p * ROWD;
+        const double val = tile[p * PITCH + e];
+        const int r = __shfl(row, p);
+        if (val != 0.0) atomicAdd(grad + (int64_t)r * ROWD + e, val);
+    }
+}
+
+// n >= 7: the scatter tile of a wave is 50-66 KB, so a block is one wave (two blocks per CU); the adjoint's working
+// set (E, H, its eigenvectors, the adjoints of all of them) does not fit the register file and spills to scratch.
+template <int N>
+constexpr int bwd_block() { return N >= 7 ? 64 : BLOCK; }
+
+// n >= 7: the scatter is a separate (not inlined) device function.  Inlined into the 8 x 8 adjoint it made the backend
+// take 7 minutes on the n = 7 kernel (418 s against 48 s for the same kernel without the scatter).
+template <int N>
+__device__ __attribute__((noinline)) void scatter_add_rows_outlined(const sympa::CMat<N>& g, const int row, double* __restrict__ grad,
+                                                                    double* __restrict__ tile, const bool live) {
+    scatter_add_rows<N>(g, row, grad, tile, live);
+}
+
+template <int N, int MODEL, bool SCATTER>
+__global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArgs a) {
+    constexpr int BLOCK = bwd_block<N>();
+    constexpr int GATHER_SLOTS = DmaTile<N>::ENABLED ? DmaTile<N>::WAVE_SLOTS_LOW : Tile<N>::WAVE_SLOTS;
+    constexpr int SCATTER_SLOTS = SCATTER ? (ScatterTile<N>::WAVE_DOUBLES + 1) / 2 : 1;
+    constexpr int WAVE_SLOTS = GATHER_SLOTS > SCATTER_SLOTS ? GATHER_SLOTS : SCATTER_SLOTS;
+    __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
+    const DistArgs& f = a.f;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < f.b;
+    const int64_t ii = live ? i : f.b - 1;
+
+    int st = 0;
+    int64_t r1 = ii, r2 = ii;
+    if (f.idx1 != nullptr) {
+        r1 = f.idx1[ii * f.idx1_stride];
+        r2 = f.idx2[ii * f.idx2_stride];
+        if (r1 < 0 || r1 >= f.num_rows || r2 < 0 || r2 >= f.num_rows) {
+            st |= sympa::ST_BAD_INDEX;
+            r1 = 0;
+            r2 = 0;
+        }
+    }
+    constexpr int64_t ROW = 2 * N * N;
+    v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
+    sympa::CMat<N> z1, z2;
+    if constexpr (DmaTile<N>::ENABLED) {
+        gather_pair_dma_low<N>(f.base1, (int)r1, f.base2, (int)r2, tile, z1, z2);
+    } else if constexpr (Tile<N>::STAGED) {
+        gather_pair_staged<N>(f.base1, (int)r1, f.base2, (int)r2, tile, z1, z2);
+    } else {
+        sympa::load_point<N>(f.base1 + r1 * ROW, z1);
+        sympa::load_point<N>(f.base2 + r2 * ROW, z2);
+    }
+    // out = dist * sc,  sc = max(scale / coef, 0.1)   (model.py:40-41)
+    double sc = 1.0;
+    bool sc_active = false;
+    if (f.scale != nullptr) {
+        const double raw = f.scale[0] * f.inv_scale_coef;
+        sc_active = raw > 0.1;
+        sc = sc_active ? raw : 0.1;
+    }
+    sympa::CMat<N> g1, g2;
+    double gw[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) gw[k] = 0.0;
+    // every gradient is linear in go: run the adjoint with go = 1 and scale afterwards (the fused loss
+    // needs the distance before it knows go)
+    const double dist = sympa::pair_backward<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, 1.0, g1, g2, gw, st);
+    const bool bad = (st & sympa::ST_BAD_INDEX) != 0;
+    double go = 0.0, loss_i = 0.0;
+    if (a.graph_dist != nullptr) {   // AverageDistortionLoss (losses.py:10-19): sum |(d/g)^2 - 1|
+        const double gd = live ? a.graph_dist[i] : 1.0;
+        const double ratio = dist * sc / gd;
+        const double e = ratio * ratio - 1.0;
+        loss_i = (live && !bad) ? fabs(e) * a.loss_scale : 0.0;
+        go = (e > 0.0 ? 1.0 : (e < 0.0 ? -1.0 : 0.0)) * 2.0 * ratio / gd * a.loss_scale;
+        if (!live) go = 0.0;
+    } else {
+        go = live ? a.go[i] : 0.0;
+    }
+    {
+        const double gs_ = go * sc;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                g1.re[r][c] *= gs_; g1.im[r][c] *= gs_;
+                g2.re[r][c] *= gs_; g2.im[r][c] *= gs_;
+            }
+#pragma unroll
+        for (int k = 0; k < N; ++k) gw[k] *= gs_;
+    }
+    if (live && f.out != nullptr) f.out[i] = bad ? __builtin_nan("") : dist * sc;
+
+    if constexpr (SCATTER) {
+        double* dtile = reinterpret_cast<double*>(tile);
+        if constexpr (N >= 7) {
+            scatter_add_rows_outlined<N>(g1, (int)r1, a.g1, dtile, live && !bad);
+            scatter_add_rows_outlined<N>(g2, (int)r2, a.g2, dtile, live && !bad);
+        } else {
+            scatter_add_rows<N>(g1, (int)r1, a.g1, dtile, live && !bad);
+            scatter_add_rows<N>(g2, (int)r2, a.g2, dtile, live && !bad);
+        }
+    } else if (live) {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                a.g1[i * ROW + r * N + c] = g1.re[r][c];
+                a.g1[i * ROW + N * N + r * N + c] = g1.im[r][c];
+                a.g2[i * ROW + r * N + c] = g2.re[r][c];
+                a.g2[i * ROW + N * N + r * N + c] = g2.im[r][c];
+            }
+    }
+    // reductions over the wave, one atomic per wave
+    if (a.gw != nullptr && f.metric == sympa::METRIC_WSUM) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double x = (live && !bad) ? gw[k] : 0.0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.gw + k, x);
+        }
+    }
+    if (a.gscale != nullptr && f.scale != nullptr) {
+        double x = (live && !bad && sc_active) ? go * dist * f.inv_scale_coef : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.gscale, x);
+    }
+    if (a.loss != nullptr && a.graph_dist != nullptr) {
+        double x = loss_i;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.loss, x);
+    }
+    if (f.status != nullptr) {
+        const int flagged = (live && st != 0) ? 1 : 0;
+        const unsigned long long m = __ballot(flagged);
+        if (m != 0ull) {
+            if (flagged) atomicOr(&f.status[0], st);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&f.status[1], (int)__popcll(m));
+        }
+    }
+}
+
+template <int N, int MODEL>
+int launch_bwd_nm(const BwdArgs& a, bool scatter, hipStream_t s) {
+    constexpr int BLOCK = bwd_block<N>();
+    const unsigned grid = (unsigned)((a.f.b + BLOCK - 1) / BLOCK);
+    if (scatter) hipLaunchKernelGGL((siegel_bwd_kernel<N, MODEL, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((siegel_bwd_kernel<N, MODEL, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+template <int N>
+int launch_bwd_n(const BwdArgs& a, int model, bool scatter, hipStream_t s) {
+    return model == SYMPA_MODEL_UPPER ? launch_bwd_nm<N, sympa::MODEL_UPPER>(a, scatter, s)
+                                      : launch_bwd_nm<N, sympa::MODEL_BOUNDED>(a, scatter, s);
+}
+
+// n = 7, 8: one translation unit per (n, model) -- siegel_bwd_n{7,8}_{upper,bounded}.hip -- because the fully
+// unrolled adjoint of an 8 x 8 pair takes minutes to compile; the build compiles the units in parallel.
+int launch_bwd_n7_upper(const BwdArgs& a, bool scatter, hipStream_t s);
+int launch_bwd_n7_bounded(const BwdArgs& a, bool scatter, hipStream_t s);
+int launch_bwd_n8_upper(const BwdArgs& a, bool scatter, hipStream_t s);
+int launch_bwd_n8_bounded(const BwdArgs& a, bool scatter, hipStream_t s);
+
+}  // namespace sympa_hip

@@ -116,7 +116,7 @@ def test_gpu_backward_golden(dev, model, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_autograd_function_vs_cpu_build_and_oracle(dev, model, n):
     """manifold.dist under torch autograd on the GPU: (a) equals the g++ build of the same arithmetic to
@@ -151,22 +151,24 @@ def test_gpu_autograd_function_vs_cpu_build_and_oracle(dev, model, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims", [4, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
-def test_gpu_model_backward_scatter_and_loss(dev, model):
+def test_gpu_model_backward_scatter_and_loss(dev, model, dims):
     """Model.forward -> AverageDistortionLoss -> backward == the reference's training step gradient
     (runner.py:98-105): dense table gradient, scale gradient, repeated rows accumulate."""
     from sympa_amd.losses import AverageDistortionLoss
     from sympa_amd.model import Model
 
     class A:
-        manifold, metric, dims, num_points = model, "riem", 4, 30
+        manifold, metric, num_points = model, "riem", 30
         scale_coef, scale_init, train_scale = 2.0, 1.5, True
+    A.dims = dims
 
     torch.manual_seed(0)
     m = Model(A)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
-        m.embeddings.embeds.data = points(model, 30, 4, 0.3, g)
+        m.embeddings.embeds.data = points(model, 30, dims, 0.3, g)
     m = m.to(dev)
     trip = torch.stack((torch.randint(0, 30, (500,), generator=g), torch.randint(0, 30, (500,), generator=g),
                         torch.randint(1, 9, (500,), generator=g)), 1)
