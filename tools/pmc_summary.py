@@ -11,11 +11,12 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+kernel = sys.argv[2] if len(sys.argv) > 2 else "siegel_dist_kernel"
 acc = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "siegel_dist_kernel" not in row.get("Kernel_Name", ""):
+            if kernel not in row.get("Kernel_Name", ""):
                 continue
             a = acc[row["Counter_Name"]]
             a[0] += float(row["Counter_Value"])
