@@ -25,7 +25,9 @@ struct BwdArgs {
 template <int N>
 struct ScatterTile {
     static constexpr int ROWD = 2 * N * N;           // doubles per row
-    static constexpr int PITCH = ROWD + 1;           // odd pitch: conflict-free ds_write_b64 per lane
+    static constexpr bool BY_PLANE = N >= 7;         // n >= 7: Re plane, then Im plane through half the tile
+    static constexpr int CHUNK = BY_PLANE ? N * N : ROWD;
+    static constexpr int PITCH = CHUNK + 1;          // odd pitch: conflict-free ds_write_b64 per lane
     static constexpr int WAVE_DOUBLES = 64 * PITCH;
 };
 
@@ -34,6 +36,28 @@ __device__ __forceinline__ void scatter_add_rows(const sympa::CMat<N>& g, const 
                                                  double* __restrict__ tile, const bool live) {
     constexpr int ROWD = ScatterTile<N>::ROWD, PITCH = ScatterTile<N>::PITCH;
     const int lane = threadIdx.x & 63;
+    if constexpr (ScatterTile<N>::BY_PLANE) {
+        constexpr int NN = N * N;
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    tile[lane * PITCH + i * N + j] = live ? (plane == 0 ? g.re[i][j] : g.im[i][j]) : 0.0;
+            wave_lds_fence();
+#pragma unroll 4
+            for (int t = 0; t < NN; ++t) {
+                const int gidx = t * 64 + lane;
+                const int p = gidx / NN, e = gidx - p * NN;
+                const double val = tile[p * PITCH + e];
+                const int r = __shfl(row, p);
+                if (val != 0.0) atomicAdd(grad + (int64_t)r * ROWD + plane * NN + e, val);
+            }
+        }
+        return;
+    }
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -53,7 +77,8 @@ __device__ __forceinline__ void scatter_add_rows(const sympa::CMat<N>& g, const 
     }
 }
 
-// n >= 7: the scatter tile of a wave is 50-66 KB, so a block is one wave (two blocks per CU); the adjoint's working
+// n >= 7: the scatter tile of a wave is 25-33 KB (one plane at a time), so a block is one wave and four blocks share
+// a CU; the adjoint's working
 // set (E, H, its eigenvectors, the adjoints of all of them) does not fit the register file and spills to scratch.
 template <int N>
 constexpr int bwd_block() { return N >= 7 ? 64 : BLOCK; }
