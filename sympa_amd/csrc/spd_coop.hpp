@@ -10,7 +10,8 @@
 //   - the symmetric matrices are staged through the LDS by whole-row DMA (global_load_lds_dwordx4: 1 KB per
 //     instruction, 16 instructions per round of 4 pairs), one round ahead of the arithmetic;
 //   - Cholesky X = L L^T (right-looking), W = (Y - X) L^-T, a transpose through the LDS, M = W^T L^-T
-//     (= L^-1 (Y - X) L^-T), Householder tridiagonalisation with the reflector broadcast from lane k;
+//     (= L^-1 (Y - X) L^-T), Householder tridiagonalisation with the reflector of step k taken from column k (one
+//     element per lane) and broadcast from there;
 //   - d_k and e_k^2 of the tridiagonal form come out of step k as group-uniform values (every lane of the group has
 //     them): in round t lane t of the group keeps them, so after 16 rounds EVERY lane holds one complete tridiagonal
 //     matrix in registers and the wave runs the sequential part -- PWK QL (dsterf), log1p, norm -- ONE PAIR PER
