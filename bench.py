@@ -93,8 +93,8 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--workload", default="upper-riem-n4-b65536", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step")
     ap.add_argument("--table", default="trained", choices=["trained", "init"])
