@@ -18,7 +18,7 @@ def relmax(got, want):
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
 
 
-@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("n", [2, 3, 4, 6, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_hostsim_backward_matches_reference_autograd(model, n):
     g = np.load(f"{GOLDEN}/autograd_{model}_n{n}.npz")
@@ -100,7 +100,7 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("n", [2, 3, 4, 6, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_backward_golden(dev, model, n):
     from sympa_amd import ops

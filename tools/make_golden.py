@@ -276,5 +276,41 @@ def main():
         print(f"  {fn}  {os.path.getsize(os.path.join(OUT, fn))} B")
 
 
+def autograd_goldens_large(dims=(6, 8)):
+    """autograd_{model}_n{6,8}.npz: the same blobs as the n <= 4 autograd goldens, from their own generator (added after
+    the first set was committed; `python tools/make_golden.py --autograd-large` writes only these files)."""
+    torch.set_default_dtype(torch.float64)
+    sm, cay, tak, UH, BD, met = ref_shim.import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for n in dims:
+        g = torch.Generator().manual_seed(20261002 + 1000 * n)
+        for model in ("upper", "bounded"):
+            blob = {}
+            for metric in METRICS:
+                z1 = upper_points(10, n, 0.3, g)
+                z2 = upper_points(10, n, 0.3, g)
+                if model == "bounded":
+                    z1 = sm.to_symmetric(cay.cayley_transform(z1))
+                    z2 = sm.to_symmetric(cay.cayley_transform(z2))
+                z1.requires_grad_(True); z2.requires_grad_(True)
+                man = (UH if model == "upper" else BD)(dims=n, metric=met.MetricType.from_str(metric))
+                coeff = torch.rand(10, generator=g) + 0.5
+                out = man.dist(z1, z2)
+                (out * coeff).sum().backward()
+                blob[f"{metric}__z1"] = z1.detach().numpy(); blob[f"{metric}__z2"] = z2.detach().numpy()
+                blob[f"{metric}__coeff"] = coeff.numpy()
+                blob[f"{metric}__out"] = out.detach().numpy()
+                blob[f"{metric}__g1"] = z1.grad.numpy(); blob[f"{metric}__g2"] = z2.grad.numpy()
+                if metric == "wsum":
+                    blob["wsum__gw"] = man.metric.weights.grad.numpy()
+            path = os.path.join(OUT, f"autograd_{model}_n{n}.npz")
+            np.savez_compressed(path, **blob)
+            print(f"  {os.path.basename(path)}  {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
-    main()
+    if "--autograd-large" in sys.argv:
+        autograd_goldens_large()
+    else:
+        main()
+        autograd_goldens_large()
