@@ -51,8 +51,8 @@ extern "C" {
 #define SYMPA_FLAG_LOW_LDS 1 /* stage one endpoint at a time: half the LDS per block, so blocks of two launches
                                 that overlap (different streams / independent graph nodes) share a CU */
 
-#define SYMPA_FLAG_GENERIC 2 /* spd: run the runtime-n one-lane-per-pair kernel even where a specialised one exists
-                                (n = 16); the tests cross-check the two */
+#define SYMPA_FLAG_GENERIC 2 /* spd: run the runtime-n one-lane-per-pair kernel even where the sixteen-lanes-per-pair
+                                one applies (n >= 6); the tests cross-check the two */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
@@ -159,7 +159,8 @@ int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, 
  * dist = || log(x^-1/2 y x^-1/2) ||_F  (geoopt's default affine-invariant metric; geoopt is absent from the
  * reference tree: parity unpinned).  sympa_spd_model_forward is Model.forward for that model
  * (sympa/model.py:16-41) with a [num_rows, n, n] table.  flags: 0 or SYMPA_FLAG_GENERIC.
- * n = 16 runs the sixteen-lanes-per-pair kernel (csrc/spd_coop.hpp), other n the runtime-n kernel. */
+ * 6 <= n <= 16 run the sixteen-lanes-per-pair kernel (csrc/spd_coop.hpp; n < 16 padded with the identity),
+ * n <= 5 the runtime-n one-lane-per-pair kernel. */
 int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status, int flags,
                        void* stream);
 int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,

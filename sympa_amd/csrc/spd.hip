@@ -38,7 +38,11 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
 
 // n = 16: sixteen lanes per pair for the O(n^3) part, one lane per pair for the QL iteration (spd_coop.hpp).
 // One wave per block, 64 pairs per wave, 16 KB of LDS.  Lane 16 g + t owns pair 4 t + g of the wave's 64.
-__global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
+// PADDED (6 <= n < 16): the same arithmetic on diag(X, I), diag(Y, I) -- the extra eigenvalues of
+// L^-1 (Y - X) L^-T are exact zeros and add nothing to the distance.  Rows are n*n*8 bytes then, not the 2 KB image
+// the DMA tile is made for, so each lane loads the elements of its row itself (upper triangle: (min, max)).
+template <bool PADDED>
+__global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a, const int n) {
     using namespace spd_coop;
     __shared__ __attribute__((aligned(16))) char tile[LDS_BYTES];
     const int lane = threadIdx.x;
@@ -87,22 +91,39 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
 #pragma unroll
     for (int k = 0; k < N; ++k) { d[k] = 0.0; e2[k] = 0.0; }
     bool ok = true;
-    issue(0);
+    if constexpr (!PADDED) issue(0);
     for (int t = 0; t < ROUNDS; ++t) {
-        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this round's images have landed
-        wave_lds_fence();
         double x[N], y[N];
+        if constexpr (PADDED) {
+            const int rowx = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row1);     // rows of my group's pair
+            const int rowy = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row2);
+            const double* px = a.base1 + (size_t)(unsigned)rowx * (unsigned)(n * n);
+            const double* py = a.base2 + (size_t)(unsigned)rowy * (unsigned)(n * n);
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            x[j] = *reinterpret_cast<const double*>(tile + eoff[j]);
-            y[j] = *reinterpret_cast<const double*>(tile + 2048 + eoff[j]);
+            for (int j = 0; j < N; ++j) {
+                const int lo = r < j ? r : j, hi = r < j ? j : r;
+                const bool inside = hi < n;
+                const int e = inside ? lo * n + hi : 0;
+                const double ident = (r == j) ? 1.0 : 0.0;
+                const double vx = px[e], vy = py[e];
+                x[j] = inside ? vx : ident;
+                y[j] = inside ? vy : ident;
+            }
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this round's images have landed
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                x[j] = *reinterpret_cast<const double*>(tile + eoff[j]);
+                y[j] = *reinterpret_cast<const double*>(tile + 2048 + eoff[j]);
+            }
         }
         double rd[N], m[N];
         const bool pd = reduce_pair_front(x, y, rd, m, reinterpret_cast<double*>(tile + g * 2048), r);
         // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
         __builtin_amdgcn_s_waitcnt(0xC07F);
         wave_lds_fence();
-        if (t + 1 < ROUNDS) issue(t + 1);
+        if constexpr (!PADDED) if (t + 1 < ROUNDS) issue(t + 1);
         const bool keep = (r == t);
         ok = keep ? pd : ok;
         reduce_pair_back(m, x, rd, r, keep, d, e2);
@@ -140,8 +161,11 @@ int launch_spd(const DistArgs& a, int n, void* stream) {
     if (n < 1 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: dims outside [1, 16]");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
     if (n == spd_coop::N && !(a.flags & SYMPA_FLAG_GENERIC))
-        hipLaunchKernelGGL(spd16_coop_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
-                           reinterpret_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL(spd16_coop_kernel<false>, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a, n);
+    else if (n >= 6 && n < spd_coop::N && !(a.flags & SYMPA_FLAG_GENERIC))     // measured crossover: n = 6
+        hipLaunchKernelGGL(spd16_coop_kernel<true>, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a, n);
     else
         hipLaunchKernelGGL(spd_dist_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
                            reinterpret_cast<hipStream_t>(stream), a, n);

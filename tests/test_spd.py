@@ -104,6 +104,38 @@ def test_gpu_spd16_cooperative_kernel_against_oracle_and_generic_kernel():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 7, 8, 11, 12, 15])
+def test_gpu_spd_padded_cooperative_kernel(n):
+    """6 <= n < 16 runs the sixteen-lanes-per-pair kernel on diag(X, I), diag(Y, I); FLAG_GENERIC forces the runtime-n
+    kernel.  Both read only the upper triangle."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(900 + n)
+    for b, s in ((1, 0.3), (67, 1e-3), (1000, 0.3)):
+        x, y = spd_points(b, n, s, g), spd_points(b, n, s, g)
+        coop = ops.spd_dist_forward(x.to(dev), y.to(dev)).cpu()
+        ops.check_status(dev)
+        gen = ops.spd_dist_forward(x.to(dev), y.to(dev), flags=ops.FLAG_GENERIC).cpu()
+        assert rel_err(coop, so.spd_dist(x, y)) < 1e-12, (n, b, s)
+        assert rel_err(coop, gen) < 1e-12, (n, b, s)
+    junk = x.clone()
+    il = torch.tril_indices(n, n, -1)
+    junk[:, il[0], il[1]] = 7.0
+    assert torch.equal(ops.spd_dist_forward(junk.to(dev), y.to(dev)).cpu(), coop)
+    assert torch.all(ops.spd_dist_forward(x.to(dev), x.to(dev)) == 0)
+    table = spd_points(200, n, 0.3, g)
+    trip = torch.randint(0, 200, (555, 3), generator=g)
+    out = ops.spd_model_forward(table.to(dev), trip.to(dev)).cpu()
+    ops.check_status(dev)
+    assert rel_err(out, so.spd_dist(table[trip[:, 0]], table[trip[:, 1]])) < 1e-12
+    bad = x.clone()
+    bad[3] = -bad[3]
+    ops.spd_dist_forward(bad.to(dev), y.to(dev))
+    with pytest.raises(Exception):
+        ops.check_status(dev)
+
+
+@pytest.mark.gpu
 def test_gpu_spd_full_size_properties():
     """BASELINE.json configs[4] at full size (n = 16, 100 000 points, 1 048 576 pairs), through properties that need no
     CPU reference: symmetry, d(x, x) = 0, invariance under the congruence x -> a x a^T, and a sample against the oracle."""
