@@ -115,6 +115,11 @@ def main():
     args = ap.parse_args()
 
     import torch
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 -- RCCL prints its version
+    # banner and its warnings there from native code -- is sent to stderr for the lifetime of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch.distributed as dist
     from sympa_amd import _lib, data, ops
 
@@ -316,14 +321,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # the JSON line is the LAST thing on stdout: flush whatever native libraries (RCCL's version banner) still hold
-        # in C stdio buffers first
         import ctypes
         try:
-            ctypes.CDLL(None).fflush(None)
+            ctypes.CDLL(None).fflush(None)      # native stdio buffers go where fd 1 points now (stderr)
         except Exception:  # noqa: BLE001
             pass
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
 
 
 if __name__ == "__main__":
