@@ -95,13 +95,9 @@ __device__ __forceinline__ void solve_right_lt(double (&a)[N], const double (&l)
     });
 }
 
-// First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
-// W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
-__device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N], double (&rd)[N], double (&m)[N],
-                                                  double* __restrict__ tbuf, const int r) {
-    // D = Y - X
-    sfor<0, N>([&](auto J) { y[J] -= x[J]; });
-    // Cholesky, right-looking, in place: after step j, register j of lane i >= j holds L[i][j]
+// Cholesky X = L L^T of the matrix held one row per lane, right-looking, in place: after step j, register j of
+// lane i >= j holds L[i][j]; rd[j] = 1 / L[j][j] (group-uniform).  Returns "all pivots positive".
+__device__ __forceinline__ bool cholesky_rows(double (&x)[N], double (&rd)[N]) {
     bool pd = true;
     sfor<0, N>([&](auto J) {
         constexpr int j = J;
@@ -115,12 +111,25 @@ __device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N]
             fnmac_bc<k>(x[k], x[j], x[j]);      // X[i][k] -= L[k][j] L[i][j]
         });
     });
-    // W = D L^-T, transposed through the LDS
-    solve_right_lt(y, x, rd);
+    return pd;
+}
+
+// m <- y^T for the rows held one per lane, through 2 KB of LDS private to my group
+__device__ __forceinline__ void transpose_rows(const double (&y)[N], double (&m)[N], double* __restrict__ tbuf, const int r) {
     wave_lds_fence();
     sfor<0, N>([&](auto J) { tbuf[r * N + J] = y[J]; });
     wave_lds_fence();
     sfor<0, N>([&](auto J) { m[J] = tbuf[J * N + r]; });
+}
+
+// First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
+// W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
+__device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N], double (&rd)[N], double (&m)[N],
+                                                  double* __restrict__ tbuf, const int r) {
+    sfor<0, N>([&](auto J) { y[J] -= x[J]; });      // D = Y - X
+    const bool pd = cholesky_rows(x, rd);
+    solve_right_lt(y, x, rd);                        // W = D L^-T
+    transpose_rows(y, m, tbuf, r);
     return pd;
 }
 
