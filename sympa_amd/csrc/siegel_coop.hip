@@ -32,25 +32,36 @@ __global__ __launch_bounds__(64) void upper_coop_kernel(const DistArgs a, const 
 #pragma unroll
     for (int k = 0; k < N; ++k) { d[k] = 0.0; e2[k] = 0.0; }
     bool ok = true;
-    for (int t = 0; t < spd_coop::ROUNDS; ++t) {
+    // rows of round t + 1 are fetched while round t computes (raw elements kept in registers: one wave per SIMD, the
+    // register file has the room and nothing else hides the latency of the 64 loads)
+    double fa[N], fb[N], fc[N], fd[N];
+    auto fetch = [&](const int t) {
         const int ra = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row1);     // the rows of my group's pair
         const int rb = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row2);
         const double* pa = a.base1 + (size_t)(unsigned)ra * (size_t)(2 * nn);
         const double* pb = a.base2 + (size_t)(unsigned)rb * (size_t)(2 * nn);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int lo = r < j ? r : j, hi = r < j ? j : r;
+            const int e = (hi < n) ? lo * n + hi : 0;
+            fa[j] = pa[e]; fb[j] = pa[nn + e]; fc[j] = pb[e]; fd[j] = pb[nn + e];
+        }
+    };
+    fetch(0);
+    for (int t = 0; t < spd_coop::ROUNDS; ++t) {
         // my row of X1, Y1, X2, Y2 (upper triangle only: element (min, max)); padding = the point i I
         double dr[N], di[N], y1[N], y2[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const int lo = r < j ? r : j, hi = r < j ? j : r;
+            const int hi = r < j ? j : r;
             const bool inside = hi < n;
-            const int e = inside ? lo * n + hi : 0;
             const double ident = (r == j) ? 1.0 : 0.0;
-            const double ax = pa[e], ay = pa[nn + e], bx = pb[e], by = pb[nn + e];
-            dr[j] = inside ? bx - ax : 0.0;
-            di[j] = inside ? by - ay : 0.0;
-            y1[j] = inside ? ay : ident;
-            y2[j] = inside ? by : ident;
+            dr[j] = inside ? fc[j] - fa[j] : 0.0;
+            di[j] = inside ? fd[j] - fb[j] : 0.0;
+            y1[j] = inside ? fb[j] : ident;
+            y2[j] = inside ? fd[j] : ident;
         }
+        if (t + 1 < spd_coop::ROUNDS) fetch(t + 1);
         double rd1[N], rd2[N];
         const bool pd1 = spd_coop::cholesky_rows(y1, rd1);
         const bool pd2 = spd_coop::cholesky_rows(y2, rd2);
