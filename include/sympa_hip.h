@@ -52,12 +52,12 @@ extern "C" {
                                 that overlap (different streams / independent graph nodes) share a CU */
 
 #define SYMPA_FLAG_GENERIC 2 /* run the runtime-n one-lane-per-pair kernel even where a sixteen-lanes-per-pair one applies
-                                (spd n >= 6, upper n >= 9); the tests cross-check the two */
+                                (spd n >= 6, upper / bounded n >= 9); the tests cross-check the two */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
-#define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16]: upper model sixteen lanes per pair
-                                     (csrc/siegel_coop.hpp), bounded model a runtime-n fallback kernel (scratch) */
+#define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] run sixteen lanes per pair
+                                     (csrc/siegel_coop.hpp); SYMPA_FLAG_GENERIC selects the runtime-n fallback (scratch) */
 
 /* Library / build identification. */
 const char* sympa_version(void);

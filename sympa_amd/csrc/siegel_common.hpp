@@ -41,7 +41,7 @@ char* last_error_buffer();
 int fail(int code, const char* msg);
 int validate(const DistArgs& a, int model);
 
-// siegel_coop.hip: upper model, 9 <= n <= 16, sixteen lanes per pair
-int launch_upper_coop(const DistArgs& a, int n, hipStream_t s);
+// siegel_coop.hip: 9 <= n <= 16, sixteen lanes per pair
+int launch_siegel_coop(const DistArgs& a, int n, int model, hipStream_t s);
 
 }  // namespace sympa_hip

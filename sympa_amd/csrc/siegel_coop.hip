@@ -1,4 +1,4 @@
-// gfx950 kernel of the upper-half model for 9 <= n <= 16: sixteen lanes per pair (siegel_coop.hpp).
+// gfx950 kernels of the upper and bounded models for 9 <= n <= 16: sixteen lanes per pair (siegel_coop.hpp).
 #include "siegel_common.hpp"
 #include "siegel_coop.hpp"
 
@@ -6,7 +6,8 @@ namespace sympa_hip {
 namespace {
 
 // One wave per block, 64 pairs per wave in 16 rounds of 4; lane 16 g + t owns pair 4 t + g (see spd.hip).
-__global__ __launch_bounds__(64) void upper_coop_kernel(const DistArgs a, const int n) {
+template <int MODEL>
+__global__ __launch_bounds__(64) void siegel_coop_kernel(const DistArgs a, const int n) {
     using namespace siegel_coop;
     __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
     const int lane = threadIdx.x;
@@ -49,30 +50,59 @@ __global__ __launch_bounds__(64) void upper_coop_kernel(const DistArgs a, const 
     };
     fetch(0);
     for (int t = 0; t < spd_coop::ROUNDS; ++t) {
-        // my row of X1, Y1, X2, Y2 (upper triangle only: element (min, max)); padding = the point i I
-        double dr[N], di[N], y1[N], y2[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const int hi = r < j ? j : r;
-            const bool inside = hi < n;
-            const double ident = (r == j) ? 1.0 : 0.0;
-            dr[j] = inside ? fc[j] - fa[j] : 0.0;
-            di[j] = inside ? fd[j] - fb[j] : 0.0;
-            y1[j] = inside ? fb[j] : ident;
-            y2[j] = inside ? fd[j] : ident;
-        }
-        if (t + 1 < spd_coop::ROUNDS) fetch(t + 1);
-        double rd1[N], rd2[N];
-        const bool pd1 = spd_coop::cholesky_rows(y1, rd1);
-        const bool pd2 = spd_coop::cholesky_rows(y2, rd2);
-        // W = D L2^-T (both planes), E^T = W^T L1^-T
-        spd_coop::solve_right_lt(dr, y2, rd2);
-        spd_coop::solve_right_lt(di, y2, rd2);
         double er[N], ei[N];
-        spd_coop::transpose_rows(dr, er, tbuf, r);
-        spd_coop::transpose_rows(di, ei, tbuf, r);
-        spd_coop::solve_right_lt(er, y1, rd1);
-        spd_coop::solve_right_lt(ei, y1, rd1);
+        bool pd1, pd2;
+        if constexpr (MODEL == sympa::MODEL_UPPER) {
+            // my row of X1, Y1, X2, Y2 (upper triangle only: element (min, max)); padding = the point i I
+            double dr[N], di[N], y1[N], y2[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int hi = r < j ? j : r;
+                const bool inside = hi < n;
+                const double ident = (r == j) ? 1.0 : 0.0;
+                dr[j] = inside ? fc[j] - fa[j] : 0.0;
+                di[j] = inside ? fd[j] - fb[j] : 0.0;
+                y1[j] = inside ? fb[j] : ident;
+                y2[j] = inside ? fd[j] : ident;
+            }
+            if (t + 1 < spd_coop::ROUNDS) fetch(t + 1);
+            double rd1[N], rd2[N];
+            pd1 = spd_coop::cholesky_rows(y1, rd1);
+            pd2 = spd_coop::cholesky_rows(y2, rd2);
+            // W = D L2^-T (both planes), E^T = W^T L1^-T
+            spd_coop::solve_right_lt(dr, y2, rd2);
+            spd_coop::solve_right_lt(di, y2, rd2);
+            spd_coop::transpose_rows(dr, er, tbuf, r);
+            spd_coop::transpose_rows(di, ei, tbuf, r);
+            spd_coop::solve_right_lt(er, y1, rd1);
+            spd_coop::solve_right_lt(ei, y1, rd1);
+        } else {
+            // my row of W1, W2 (Re, Im); padding = the point 0.  E = C1^-1 (W2 - W1) C2^-T,  I - W_k W_k^H = C_k C_k^H
+            double w1r[N], w1i[N], w2r[N], w2i[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int hi = r < j ? j : r;
+                const bool inside = hi < n;
+                w1r[j] = inside ? fa[j] : 0.0;
+                w1i[j] = inside ? fb[j] : 0.0;
+                w2r[j] = inside ? fc[j] : 0.0;
+                w2i[j] = inside ? fd[j] : 0.0;
+            }
+            if (t + 1 < spd_coop::ROUNDS) fetch(t + 1);
+            double dr[N], di[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) { dr[j] = w2r[j] - w1r[j]; di[j] = w2i[j] - w1i[j]; }
+            double c2r[N], c2i[N], rd2[N];
+            id_minus_wwh_rows(w2r, w2i, c2r, c2i, r);
+            pd2 = ccholesky_rows(c2r, c2i, rd2);
+            csolve_right_lt(dr, di, c2r, c2i, rd2);              // W = D C2^-T
+            spd_coop::transpose_rows(dr, er, tbuf, r);
+            spd_coop::transpose_rows(di, ei, tbuf, r);
+            double c1r[N], c1i[N], rd1[N];
+            id_minus_wwh_rows(w1r, w1i, c1r, c1i, r);
+            pd1 = ccholesky_rows(c1r, c1i, rd1);
+            csolve_right_lt(er, ei, c1r, c1i, rd1);              // E^T = W^T C1^-T
+        }
         double hr[N], hi[N];
         gram_columns(er, ei, hr, hi);
         const bool keep = (r == t);
@@ -82,8 +112,9 @@ __global__ __launch_bounds__(64) void upper_coop_kernel(const DistArgs a, const 
     // one pair per lane: eigenvalues of H = E^H E, vector-valued distance, metric
     const bool conv = sympa::tridiag_ql_lockstep<N>(d, e2);
     double v[N];
+    constexpr double quarter = (MODEL == sympa::MODEL_UPPER) ? 0.25 : 1.0;      // sinh(v/2) = sigma / 2 (upper), sigma (bounded)
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = sympa::vvd_from_sinh2(fmax(d[k], 0.0) * 0.25, a.inv_eps);
+    for (int k = 0; k < N; ++k) v[k] = sympa::vvd_from_sinh2(fmax(d[k], 0.0) * quarter, a.inv_eps);
     sympa::sort_ascending<N>(v);
     const int pad = N - n;
     if (a.vvd != nullptr && live) {
@@ -110,8 +141,10 @@ __global__ __launch_bounds__(64) void upper_coop_kernel(const DistArgs a, const 
 
 }  // namespace
 
-int launch_upper_coop(const DistArgs& a, int n, hipStream_t s) {
-    hipLaunchKernelGGL(upper_coop_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0, s, a, n);
+int launch_siegel_coop(const DistArgs& a, int n, int model, hipStream_t s) {
+    const dim3 grid((unsigned)((a.b + 63) / 64));
+    if (model == SYMPA_MODEL_UPPER) hipLaunchKernelGGL(siegel_coop_kernel<sympa::MODEL_UPPER>, grid, dim3(64), 0, s, a, n);
+    else hipLaunchKernelGGL(siegel_coop_kernel<sympa::MODEL_BOUNDED>, grid, dim3(64), 0, s, a, n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

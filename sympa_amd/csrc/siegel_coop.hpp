@@ -48,6 +48,67 @@ __device__ __forceinline__ void gram_columns(double (&sr)[N], double (&si)[N], d
     });
 }
 
+// ---- bounded model: A = I - W W^H = C C^H with complex factors -------------------------------------------------
+// A = I - W W^H from the rows of the complex-symmetric W held one per lane:  A[i][j] = delta_ij - sum_l W[i][l] conj(W[j][l])
+__device__ __forceinline__ void id_minus_wwh_rows(double (&wr)[N], double (&wi)[N], double (&ar)[N], double (&ai)[N],
+                                                  const int r) {
+    sfor<0, N>([&](auto L) { wr[L] = settle(wr[L]); wi[L] = settle(wi[L]); });
+    sfor<0, N>([&](auto J) {
+        constexpr int j = J;
+        double a0 = (r == j) ? 1.0 : 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        sfor<0, N>([&](auto L) {
+            constexpr int l = L;
+            fnmac_bc<j>(a0, wr[l], wr[l]);      // - wr_i wr_j
+            fnmac_bc<j>(a1, wi[l], wi[l]);      // - wi_i wi_j
+            fnmac_bc<j>(b0, wr[l], wi[l]);      // - wi_i wr_j
+            fmac_bc<j>(b1, wi[l], wr[l]);       // + wr_i wi_j
+        });
+        ar[j] = a0 + a1;
+        ai[j] = b0 + b1;
+    });
+}
+
+// Cholesky A = C C^H of the Hermitian matrix held one row per lane (complex, right-looking, in place): after step j,
+// registers j of lane i >= j hold C[i][j]; the diagonal is real, rd[j] = 1 / C[j][j].
+__device__ __forceinline__ bool ccholesky_rows(double (&xr)[N], double (&xi)[N], double (&rd)[N]) {
+    bool pd = true;
+    sfor<0, N>([&](auto J) {
+        constexpr int j = J;
+        const double piv = bcast<j>(settle(xr[j]));
+        pd = pd && (piv > 0.0);
+        const double rr = sympa::d_rsqrt(piv);
+        rd[j] = rr;
+        xr[j] = settle(xr[j] * rr);
+        xi[j] = settle(xi[j] * rr);
+        sfor<j + 1, N>([&](auto K) {
+            constexpr int k = K;
+            // X[i][k] -= C[i][j] conj(C[k][j])
+            fnmac_bc<k>(xr[k], xr[j], xr[j]);
+            fnmac_bc<k>(xr[k], xi[j], xi[j]);
+            fnmac_bc<k>(xi[k], xr[j], xi[j]);
+            fmac_bc<k>(xi[k], xi[j], xr[j]);
+        });
+    });
+    return pd;
+}
+
+// a <- a C^-T (plain transpose) for complex rows held one per lane:  a[j] = (a[j] - sum_{k<j} a[k] C[j][k]) / C[j][j]
+__device__ __forceinline__ void csolve_right_lt(double (&ar)[N], double (&ai)[N], const double (&cr)[N], const double (&ci)[N],
+                                                const double (&rd)[N]) {
+    sfor<0, N>([&](auto J) {
+        constexpr int j = J;
+        sfor<0, j>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<j>(ar[j], cr[k], ar[k]);
+            fmac_bc<j>(ar[j], ci[k], ai[k]);
+            fnmac_bc<j>(ai[j], ci[k], ar[k]);
+            fnmac_bc<j>(ai[j], cr[k], ai[k]);
+        });
+        ar[j] *= rd[j];
+        ai[j] *= rd[j];
+    });
+}
+
 // Complex Householder tridiagonalisation of the Hermitian H held one row per lane (hr[j] + i hi[j] = H[me][j]).
 // d_k and |b_k|^2 are group-uniform; the lane with keep = true stores them.
 __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[N], double (&hi)[N], const int r, const bool keep,

@@ -189,7 +189,7 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
         default: break;
     }
     if (n > SYMPA_MAX_DIMS && n <= sympa::GENERIC_MAX_N) {
-        if (model == SYMPA_MODEL_UPPER && !(a.flags & SYMPA_FLAG_GENERIC)) return launch_upper_coop(a, n, s);
+        if (!(a.flags & SYMPA_FLAG_GENERIC)) return launch_siegel_coop(a, n, model, s);
         hipLaunchKernelGGL(siegel_dist_generic_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0, s, a, n, model);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));

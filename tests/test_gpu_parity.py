@@ -226,36 +226,40 @@ def test_generic_dims_fallback_kernel(dev, model, n):
 
 
 @pytest.mark.parametrize("n", [9, 10, 13, 16])
-def test_upper_dims_9_to_16_cooperative_kernel(dev, n):
-    """Upper model, 9 <= n <= 16: sixteen lanes per pair (csrc/siegel_coop.hpp), n < 16 padded with the point i I.
+@pytest.mark.parametrize("model", MODELS)
+def test_dims_9_to_16_cooperative_kernel(dev, model, n):
+    """9 <= n <= 16: sixteen lanes per pair (csrc/siegel_coop.hpp), n < 16 padded with the point i I (upper) / 0 (bounded).
     Against the oracle, against the runtime-n kernel (FLAG_GENERIC), every metric, the vector-valued distance, ragged
     batch sizes, the gathered form with scale, and the status word."""
     from sympa_amd import ops
     g = torch.Generator().manual_seed(1300 + n)
     w = torch.linspace(-0.4, 1.3, n, dtype=torch.float64)
     for b, s in ((1, 0.2), (65, 1e-3), (300, 0.2)):
-        z1, z2 = points("upper", b, n, s, g), points("upper", b, n, s, g)
+        z1, z2 = points(model, b, n, s, g), points(model, b, n, s, g)
         for metric in METRICS:
-            coop, vv = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), "upper", metric, w.to(dev), return_vvd=True)
+            coop, vv = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), model, metric, w.to(dev), return_vvd=True)
             ops.check_status(dev)
-            gen, vg = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), "upper", metric, w.to(dev), return_vvd=True,
+            gen, vg = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), model, metric, w.to(dev), return_vvd=True,
                                               flags=ops.FLAG_GENERIC)
             ops.check_status(dev)
-            want = so.manifold_dist("upper", z1, z2, metric, w)
+            want = so.manifold_dist(model, z1, z2, metric, w)
             # the oracle follows the reference's own chain (sqrt, inverses, 2n x 2n eigh): it carries ~1e-8 itself
             # (tests/golden *__vvd_exact50); the two kernels evaluate the same formula
             assert rel_err(coop.cpu(), want) < 1e-7, (n, b, s, metric)
             assert rel_err(coop.cpu(), gen.cpu()) < 1e-10, (n, b, s, metric)
             assert rel_err(vv.cpu(), vg.cpu()) < 1e-9 and vv.shape == (b, n)
-    assert torch.all(ops.siegel_dist_forward(z1.to(dev), z1.to(dev), "upper", "riem") == 0)
-    table = points("upper", 90, n, 0.2, g)
+    assert torch.all(ops.siegel_dist_forward(z1.to(dev), z1.to(dev), model, "riem") == 0)
+    table = points(model, 90, n, 0.2, g)
     trip = torch.randint(0, 90, (333, 3), generator=g)
     scale = torch.tensor([1.7], dtype=torch.float64)
-    out = ops.model_forward(table.to(dev), trip.to(dev), "upper", "fone", None, scale.to(dev), 2.0).cpu()
+    out = ops.model_forward(table.to(dev), trip.to(dev), model, "fone", None, scale.to(dev), 2.0).cpu()
     ops.check_status(dev)
-    assert rel_err(out, so.model_forward(table, trip, "upper", "fone", scale=scale, scale_coef=2.0)) < 1e-9
+    assert rel_err(out, so.model_forward(table, trip, model, "fone", scale=scale, scale_coef=2.0)) < 1e-9
     bad = z1.clone()
-    bad[7, 1] = -bad[7, 1]                   # Im z not positive definite
-    ops.siegel_dist_forward(bad.to(dev), z2.to(dev), "upper", "riem")
+    if model == "upper":
+        bad[7, 1] = -bad[7, 1]               # Im z not positive definite
+    else:
+        bad[7] = 3.0 * bad[7] + torch.eye(n, dtype=torch.float64)        # outside the bounded domain
+    ops.siegel_dist_forward(bad.to(dev), z2.to(dev), model, "riem")
     with pytest.raises(AssertionError):
         ops.check_status(dev)
