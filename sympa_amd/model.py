@@ -69,6 +69,17 @@ class Model(nn.Module):
         forward calls, as one launch (or one launch per row block).  Diagonal exactly 0."""
         from sympa_amd import ops
         man = self.manifold
+        if man.model_name == "spd":
+            # the same pairs (i, j) the reference's loop feeds to forward(), through the spd kernel
+            emb = self.embeddings.embeds
+            n_pts = emb.shape[0]
+            row_count = n_pts - row_begin if row_count is None else row_count
+            rows = torch.arange(row_begin, row_begin + row_count, device=emb.device)
+            cols = torch.arange(n_pts, device=emb.device)
+            pairs = torch.stack((rows.repeat_interleave(n_pts), cols.repeat(row_count)), 1)
+            out = ops.spd_model_forward(emb, pairs, self.scale, self.scale_coef).reshape(row_count, n_pts)
+            out[torch.arange(row_count, device=emb.device), rows] = 0.0      # runner.py:152
+            return out
         weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
         return ops.all_pairs_dist(self.embeddings.embeds, man.model_name, man.metric.kind.value, weights, self.scale,
                                   self.scale_coef, row_begin, row_count)

@@ -59,6 +59,15 @@ def test_gpu_spd_kernel_and_model(n):
         out = m(trip.to(dev)).cpu()
     want = so.spd_model_forward(m.embeddings.embeds.detach().cpu(), trip, m.scale.detach().cpu(), 1.0)
     assert rel_err(out, want) < 1e-9
+    with torch.no_grad():
+        full = m.distance_matrix().cpu()
+        block = m.distance_matrix(row_begin=7, row_count=11).cpu()
+    ii, jj = torch.meshgrid(torch.arange(50), torch.arange(50), indexing="ij")
+    ref = so.spd_model_forward(m.embeddings.embeds.detach().cpu(), torch.stack((ii.reshape(-1), jj.reshape(-1)), 1),
+                               m.scale.detach().cpu(), 1.0).reshape(50, 50)
+    assert rel_err(full, ref) < 1e-9 and torch.all(torch.diagonal(full) == 0)
+    # not bit-equal: how many (harmless) QL sweeps a pair gets depends on the slowest pair of its wave
+    assert rel_err(block, full[7:18]) < 1e-13
 
 
 @pytest.mark.gpu
