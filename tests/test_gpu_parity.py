@@ -178,21 +178,23 @@ def test_full_size_properties(dev, model, n, b, N):
     assert rel_err(d_xy[:k].cpu(), want) < 1e-8
 
 
+@pytest.mark.parametrize("dims", [4, 6, 10])
 @pytest.mark.parametrize("model", MODELS)
-def test_all_pairs_matrix_equals_runner_loop(dev, model):
+def test_all_pairs_matrix_equals_runner_loop(dev, model, dims):
     """Model.distance_matrix == the reference's Runner.build_distance_matrix loop (runner.py:142-154):
     row i = forward of the pairs (i, j) for all j, self pair replaced and overwritten by 0."""
     from sympa_amd import ops
     from sympa_amd.model import Model
 
     class A:
-        manifold, metric, dims, num_points = model, "fone", 4, 131
+        manifold, metric, num_points = model, "fone", 131
         scale_coef, scale_init, train_scale = 1.0, 1.7, False
     A.manifold = model
+    A.dims = dims
     g = torch.Generator().manual_seed(13)
     m = Model(A)
     with torch.no_grad():
-        m.embeddings.embeds.data = points(model, 131, 4, 0.4, g)
+        m.embeddings.embeds.data = points(model, 131, dims, 0.4 if dims <= 6 else 0.2, g)
     m = m.to(dev)
     with torch.no_grad():
         full = m.distance_matrix()
@@ -209,8 +211,9 @@ def test_all_pairs_matrix_equals_runner_loop(dev, model):
         d[node] = 0
         want[node] = d
     assert full.shape == (n_nodes, n_nodes) and torch.all(full.diagonal() == 0)
-    assert rel_err(full.cpu(), want) < TOL
-    assert torch.equal(block, full[17:57])
+    assert rel_err(full.cpu(), want) < (TOL if dims <= 6 else 1e-7)
+    # n >= 5: the lockstep QL makes the last bits depend on the pairs that share a wave
+    assert torch.equal(block, full[17:57]) if dims <= 4 else rel_err(block.cpu(), full[17:57].cpu()) < 1e-12
     assert rel_err(full.cpu(), full.cpu().T) < 1e-10
 
 
