@@ -34,6 +34,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MEASURED_COPY_GBS = 6290.0   # same guide, chip table: measured copy bandwidth
 FP64_VALU_PEAK_TFLOPS = 78.6   # AMD datasheet (vector fp64); reported as the honest second roof
 
 
@@ -284,10 +285,15 @@ def main():
         bpp = algorithmic_bytes_per_pair(n, model)
         achieved = bpp * batch / (kernel_avg_ms * 1e-3) / 1e9
         traffic = None
+        valu_per_wave = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                rec_pmc = json.load(open(pmc)).get(args.workload, {})
+                traffic = rec_pmc.get("hbm_bytes_per_launch")
+                c = rec_pmc.get("counters_avg_per_launch", {})
+                if c.get("SQ_WAVES"):
+                    valu_per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
             except Exception:  # noqa: BLE001
                 traffic = None
         rec = {
@@ -312,6 +318,12 @@ def main():
             # --streams streams, so this exceeds roofline.frac, which is a per-kernel figure)
             "throughput_frac_of_hbm_roof": value * bpp / (HBM_PEAK_GBS * 1e9),
         }
+        # SURVEY 8d's "honest second roofs": the measured copy bandwidth of the chip table, and the fp64 VALU issue
+        # slots the whole job occupies (VALU instructions per wave from the committed PMC pass; one wave = 64 pairs;
+        # a wave instruction occupies its SIMD for 4 cycles; 1024 SIMDs at the 2.4 GHz peak clock)
+        rec["roofline"]["frac_of_measured_copy_bw"] = achieved / MEASURED_COPY_GBS
+        if valu_per_wave:
+            rec["valu_issue_fraction"] = (value / world) / 64.0 * valu_per_wave * 4.0 / (1024 * 2.4e9)
         del rec["config"]["model"]
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, batch, args.seed)
