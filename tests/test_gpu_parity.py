@@ -187,20 +187,20 @@ def test_all_pairs_matrix_equals_runner_loop(dev, model, dims):
     from sympa_amd.model import Model
 
     class A:
-        manifold, metric, num_points = model, "fone", 131
+        manifold, metric = model, "fone"
         scale_coef, scale_init, train_scale = 1.0, 1.7, False
     A.manifold = model
     A.dims = dims
+    A.num_points = n_nodes = 131 if dims <= 6 else 71      # the CPU oracle loop dominates the test time
     g = torch.Generator().manual_seed(13)
     m = Model(A)
     with torch.no_grad():
-        m.embeddings.embeds.data = points(model, 131, dims, 0.4 if dims <= 6 else 0.2, g)
+        m.embeddings.embeds.data = points(model, n_nodes, dims, 0.4 if dims <= 6 else 0.2, g)
     m = m.to(dev)
     with torch.no_grad():
         full = m.distance_matrix()
         block = m.distance_matrix(row_begin=17, row_count=40)
     ops.check_status(dev)
-    n_nodes = 131
     want = torch.zeros(n_nodes, n_nodes, dtype=torch.float64)
     all_nodes = torch.arange(n_nodes).unsqueeze(1)
     for node in range(n_nodes):            # the reference loop, with the oracle as forward
@@ -237,7 +237,7 @@ def test_dims_9_to_16_cooperative_kernel(dev, model, n):
     from sympa_amd import ops
     g = torch.Generator().manual_seed(1300 + n)
     w = torch.linspace(-0.4, 1.3, n, dtype=torch.float64)
-    for b, s in ((1, 0.2), (65, 1e-3), (300, 0.2)):
+    for b, s in ((1, 0.2), (65, 1e-3), (150, 0.2)):
         z1, z2 = points(model, b, n, s, g), points(model, b, n, s, g)
         for metric in METRICS:
             coop, vv = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), model, metric, w.to(dev), return_vvd=True)
