@@ -27,21 +27,31 @@ class SiegelManifold(Manifold, ABC):
         self.dims = dims
         self.ndim = ndim
         self._projected_points = 0
-        self._pending_projected = []      # device counters written by the fused optimiser step
+        self._device_projected = {}       # device -> persistent int32 counter the fused optimiser step adds to
         self.metric = Metric.get(metric, self.dims)
 
     @property
     def projected_points(self):
         """Number of points projx had to move (runner.py:47-48 logs it).  Counters produced by the fused
         optimiser kernel are folded in here, so the training loop itself never synchronises."""
-        if self._pending_projected:
-            self._projected_points += int(torch.stack(self._pending_projected).sum().item())
-            self._pending_projected = []
+        for counter in self._device_projected.values():
+            self._projected_points += int(counter.item())
+            counter.zero_()
         return self._projected_points
 
     @projected_points.setter
     def projected_points(self, value):
+        for counter in self._device_projected.values():
+            counter.zero_()
         self._projected_points = value
+
+    def projected_counter(self, device):
+        """The device counter sympa_rsgd_step accumulates into.  It persists across steps (nothing is allocated or
+        zeroed per step), so the optimiser step can be captured in a hipGraph and replayed."""
+        key = str(device)
+        if key not in self._device_projected:
+            self._device_projected[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._device_projected[key]
 
     # ------------------------------------------------------------------ the hot path
     def _metric_weights(self):

@@ -33,10 +33,9 @@ class RiemannianSGD(torch.optim.Optimizer):
                     continue
                 manifold = getattr(p, "manifold", None)
                 if isinstance(manifold, SiegelManifold) and p.is_cuda:
-                    counter = torch.zeros(1, dtype=torch.int32, device=p.device)
-                    ops.rsgd_step_(p.data, p.grad, manifold.model_name, lr, wd, counter=counter)
-                    manifold._pending_projected = getattr(manifold, "_pending_projected", [])
-                    manifold._pending_projected.append(counter)   # folded into projected_points lazily
+                    # the kernel adds the number of projected rows to a persistent device counter (read lazily by
+                    # manifold.projected_points): no allocation, no synchronisation, graph-capturable
+                    ops.rsgd_step_(p.data, p.grad, manifold.model_name, lr, wd, counter=manifold.projected_counter(p.device))
                 else:
                     g = p.grad
                     if wd != 0:

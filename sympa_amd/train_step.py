@@ -1,0 +1,73 @@
+"""The body of the reference's training loop (sympa/runner.py:98-118: zero_grad, forward, AverageDistortionLoss,
+backward, gradient clip, optimiser step) as ONE hipGraph replay per batch.
+
+Eagerly the step is a handful of launches (memset, the fused loss+backward kernel, the norm / clip kernels of
+torch.nn.utils.clip_grad_norm_, the fused RSGD kernel) issued from Python; at the reference's batch sizes (512 .. 8192
+triplets) the Python and launch overhead (~0.3 ms) is several times the GPU time.  Everything in the step is
+stream-ordered and allocation-free after the first call, so it is captured once per (batch size, learning rate) and
+replayed: the batch is copied into static buffers, the graph runs, the loss stays on the device."""
+import torch
+
+from sympa_amd import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, batch_size, max_grad_norm, device):
+        self.model, self.opt = model, optimizer
+        self.batch_size, self.max_grad_norm = int(batch_size), float(max_grad_norm)
+        self.ids = torch.zeros(self.batch_size, 2, dtype=torch.int64, device=device)
+        self.gd = torch.ones(self.batch_size, dtype=torch.float64, device=device)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=device)
+        self.graph = None
+        self.lr = None
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+    def _body(self):
+        self.opt.zero_grad(set_to_none=False)
+        loss = self.model.fused_loss_backward(self.ids, self.gd)
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+        self.opt.step()
+        self.loss.copy_(loss)
+
+    def eager(self, ids, gd):
+        """The same step without a graph (ragged last batch of an epoch, multi-GPU steps with an all-reduce inside)."""
+        self.opt.zero_grad(set_to_none=False)
+        loss = self.model.fused_loss_backward(ids, gd)
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+        self.opt.step()
+        return loss
+
+    def _capture(self, lr):
+        # warm-up outside the capture with lr = 0: allocates the gradients / status words / foreach workspaces and
+        # leaves the parameters where they are (retr(x, 0) = projx(x), the identity for points on the manifold)
+        for g in self.opt.param_groups:
+            g["lr"] = 0.0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self._body()
+        self.lr = lr
+
+    def __call__(self, ids, gd):
+        """ids [b, 2] int64, gd [b] fp64 on the device.  Returns the batch loss as a 1-element device tensor that is
+        overwritten by the next call (add it to an accumulator, do not keep it)."""
+        lr = self.opt.param_groups[0]["lr"]
+        if ids.shape[0] != self.batch_size:
+            return self.eager(ids, gd)
+        self.ids.copy_(ids)
+        self.gd.copy_(gd)
+        if self.graph is None or lr != self.lr:
+            self._capture(lr)
+        self.graph.replay()
+        return self.loss
+
+
+def check(device):
+    ops.check_status(device)

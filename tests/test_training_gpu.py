@@ -34,3 +34,18 @@ def test_embedding_at_dims_8_trains(tmp_path):
     assert last < 0.8 * first, hist
     ok, point, reason = model.check_all_points()
     assert ok, reason
+
+
+def test_graphed_step_equals_eager_step():
+    """One hipGraph replay per batch (sympa_amd/train_step.py) trains exactly like the kernel-by-kernel step: same
+    distortion history (fp64 atomics make the last bits of a gradient order-dependent, hence a tolerance)."""
+    import train_siegel
+    common = ["--graph", "grid3d-125", "--manifold", "upper", "--metric", "riem", "--dims", "3", "--epochs", "12",
+              "--batch_size", "512", "--val_every", "3", "--learning_rate", "0.02", "--burnin", "4"]
+    _, h_graph = train_siegel.train(train_siegel.parser().parse_args(common), log=lambda *_: None)
+    _, h_eager = train_siegel.train(train_siegel.parser().parse_args(common + ["--no_graph_step"]), log=lambda *_: None)
+    assert len(h_graph) == len(h_eager) == 4
+    for a, b in zip(h_graph, h_eager):
+        assert a[0] == b[0]
+        assert abs(a[1] - b[1]) < 1e-8 * abs(b[1]) and abs(a[2] - b[2]) < 1e-8 * abs(b[2]), (a, b)
+    assert h_graph[-1][2] < 0.9 * h_graph[0][2]

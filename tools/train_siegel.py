@@ -21,6 +21,7 @@ from sympa_amd import data, ops  # noqa: E402
 from sympa_amd.distributed import allreduce_gradients, shard_triplets  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
 from sympa_amd.optim import RiemannianSGD  # noqa: E402
+from sympa_amd.train_step import GraphedTrainStep  # noqa: E402
 
 
 def evaluate(model, ids, gd, batch):
@@ -49,6 +50,8 @@ def train(args, log=print):
     gd_all = trip[:, 2].to(torch.float64).to(dev)
     batch = max(1, args.batch_size // world)
     history = []
+    # single GPU: the whole step is one hipGraph replay; multi-GPU steps have an all-reduce in the middle and run eagerly
+    graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev) if (world == 1 and args.graph_step) else None
     for epoch in range(1, args.epochs + 1):
         mine = shard_triplets(trip, rank, world, epoch=epoch, seed=0).to(dev)
         t0 = time.perf_counter()
@@ -58,6 +61,9 @@ def train(args, log=print):
         loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
         for s in range(0, mine.shape[0], batch):
             b = mine[s:s + batch]
+            if graphed is not None:
+                loss_sum += graphed(b[:, :2], b[:, 2].to(torch.float64))
+                continue
             opt.zero_grad(set_to_none=False)
             loss_sum += model.fused_loss_backward(b[:, :2].contiguous(), b[:, 2].to(torch.float64))
             if world > 1:
@@ -65,12 +71,15 @@ def train(args, log=print):
             torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)      # runner.py:115
             opt.step()
         if epoch % args.val_every == 0 or epoch == args.epochs:
+            torch.cuda.synchronize(dev)
+            t_train = time.perf_counter() - t0
             distortion = evaluate(model, ids_all, gd_all, args.batch_size)
             ops.check_status(dev)
             history.append((epoch, float(loss_sum) / max(1, mine.shape[0]), distortion))
             if rank == 0:
                 log(f"epoch {epoch:4d}  loss/triplet {history[-1][1]:.4f}  avg distortion {distortion:.4f}  "
-                    f"{time.perf_counter() - t0:.2f} s/epoch  projected {model.manifold.projected_points}")
+                    f"{t_train * 1e3:.1f} ms/epoch ({mine.shape[0] / t_train / 1e6:.2f} M triplets/s)  "
+                    f"projected {model.manifold.projected_points}")
     return model, history
 
 
@@ -90,6 +99,8 @@ def parser():
     ap.add_argument("--burnin", type=int, default=10)
     ap.add_argument("--val_every", type=int, default=5)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no_graph_step", dest="graph_step", action="store_false", default=True,
+                    help="launch the kernels of a step one by one instead of replaying one hipGraph per batch")
     return ap
 
 
