@@ -155,6 +155,16 @@ int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double
 int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
                     double weight_decay, double eps, int32_t* projected_count, int32_t* status, void* stream);
 
+/* The gradient clip of the reference's loop (torch.nn.utils.clip_grad_norm_, sympa/runner.py:115) folded into the step:
+ * sympa_sqnorm_accum adds sum(x^2) to acc[0] (device; call it once per gradient tensor after zeroing acc), and
+ * sympa_rsgd_step_clipped is sympa_rsgd_step with every gradient row scaled by
+ *     min(1, max_norm / (sqrt(total_sqnorm[0]) + 1e-6))
+ * as it is loaded (the gradient buffer itself is left unscaled). */
+int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream);
+int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
+                            double weight_decay, double eps, const double* total_sqnorm, double max_norm,
+                            int32_t* projected_count, int32_t* status, void* stream);
+
 /* ---- SPD model (manifold "spd": geoopt.manifolds.SymmetricPositiveDefinite, sympa/embeddings.py:6,70-72,142) ----
  * Points are [n, n] fp64 symmetric positive definite matrices (upper triangle read), n <= 16.
  * dist = || log(x^-1/2 y x^-1/2) ||_F  (geoopt's default affine-invariant metric; geoopt is absent from the

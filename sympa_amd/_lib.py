@@ -23,6 +23,8 @@ SYMBOLS = (
     "sympa_egrad2rgrad",
     "sympa_projx",
     "sympa_rsgd_step",
+    "sympa_sqnorm_accum",
+    "sympa_rsgd_step_clipped",
     "sympa_spd_dist_fwd",
     "sympa_spd_model_forward",
 )
@@ -98,6 +100,12 @@ def load():
     lib.sympa_rsgd_step.restype = ctypes.c_int
     lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
+    lib.sympa_sqnorm_accum.restype = ctypes.c_int
+    lib.sympa_sqnorm_accum.argtypes = [_c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_void_p]
+    lib.sympa_rsgd_step_clipped.restype = ctypes.c_int
+    lib.sympa_rsgd_step_clipped.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_double_p,
+                                            ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_spd_dist_fwd.restype = ctypes.c_int
     lib.sympa_spd_dist_fwd.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, _c_i32_p,
                                        ctypes.c_int, ctypes.c_void_p]

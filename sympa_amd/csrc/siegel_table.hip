@@ -21,10 +21,22 @@ __global__ __launch_bounds__(BLOCK) void egrad2rgrad_kernel(const double* z, con
 }
 
 // OP 0: out = projx(z).   OP 1: table <- retr(table, -lr * egrad2rgrad(table, grad + wd * table)) in place.
+// sum of squares of `count` doubles, accumulated into acc[0] (the total gradient norm of clip_grad_norm_)
+__global__ __launch_bounds__(BLOCK) void sqnorm_kernel(const double* __restrict__ x, int64_t count, double* acc) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * BLOCK) s = fma(x[i], x[i], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(acc, s);
+}
+
+// clip: device pointer to the squared total gradient norm, or null.  torch.nn.utils.clip_grad_norm_ (runner.py:115)
+// scales every gradient by min(1, max_norm / (total_norm + 1e-6)); here the factor is applied to the row's gradient
+// as it is loaded, so the clip costs no pass of its own.
 template <int N, int MODEL, int OP>
 __global__ __launch_bounds__(BLOCK) void table_update_kernel(double* z, const double* grad, double* out, int64_t b,
                                                              double lr, double wd, double eps, int32_t* projected,
-                                                             int32_t* status) {
+                                                             int32_t* status, const double* clip, double max_norm) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < b;
     const int64_t ii = live ? i : b - 1;      // tail lanes recompute the last row (the Jacobi loops ballot)
@@ -38,6 +50,13 @@ __global__ __launch_bounds__(BLOCK) void table_update_kernel(double* z, const do
     } else {
         sympa::CMat<N> g;
         sympa::load_full<N>(grad + ii * ROW, g);
+        if (clip != nullptr) {
+            const double coef = fmin(1.0, max_norm / (sqrt(clip[0]) + 1e-6));
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int c = 0; c < N; ++c) { g.re[r][c] *= coef; g.im[r][c] *= coef; }
+        }
         moved = sympa::rsgd_row<N, MODEL>(a, g, lr, wd, eps, st);
     }
     if (live) sympa::store_full<N>((OP == 0 ? out : z) + i * ROW, a);
@@ -54,18 +73,18 @@ __global__ __launch_bounds__(BLOCK) void table_update_kernel(double* z, const do
 
 template <int N>
 int launch_table(int op, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
-                 double eps, int32_t* projected, int32_t* status, hipStream_t s) {
+                 double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm) {
     const unsigned grid = (unsigned)((b + BLOCK - 1) / BLOCK);
     const bool up = model == SYMPA_MODEL_UPPER;
     if (op == 2) {
         if (up) hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
         else hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
     } else if (op == 0) {
-        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
-        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
+        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
+        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
     } else {
-        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
-        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status);
+        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
+        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -73,7 +92,8 @@ int launch_table(int op, int model, double* z, const double* g, double* out, int
 }
 
 int dispatch_table(int op, int n, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
-                   double eps, int32_t* projected, int32_t* status, void* stream) {
+                   double eps, int32_t* projected, int32_t* status, void* stream, const double* clip = nullptr,
+                   double max_norm = 0.0) {
     if (b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative row count");
     if (b == 0) return 0;
     if (z == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
@@ -81,14 +101,14 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
     if (b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "too many rows for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
-        case 1: return launch_table<1>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 2: return launch_table<2>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 3: return launch_table<3>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 4: return launch_table<4>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 5: return launch_table<5>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 6: return launch_table<6>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 7: return launch_table<7>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
-        case 8: return launch_table<8>(op, model, z, g, out, b, lr, wd, eps, projected, status, s);
+        case 1: return launch_table<1>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 2: return launch_table<2>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 3: return launch_table<3>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 4: return launch_table<4>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 5: return launch_table<5>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 6: return launch_table<6>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 7: return launch_table<7>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+        case 8: return launch_table<8>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
         default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS]");
     }
 }
@@ -116,6 +136,27 @@ int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, 
     if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     return dispatch_table(1, n, model, table, grad, nullptr, num_rows, lr, weight_decay, eps, projected_count, status,
                           stream);
+}
+
+int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream) {
+    if (count < 0) return fail(SYMPA_ERR_BAD_ARG, "negative count");
+    if (count == 0) return 0;
+    if (x == nullptr || acc == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    const int64_t want = (count + BLOCK - 1) / BLOCK;
+    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x, count, acc);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
+                            double weight_decay, double eps, const double* total_sqnorm, double max_norm,
+                            int32_t* projected_count, int32_t* status, void* stream) {
+    if (num_rows > 0 && (grad == nullptr || total_sqnorm == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (!(eps > 0.0) || !(max_norm > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps and max_norm must be > 0");
+    return dispatch_table(1, n, model, table, grad, nullptr, num_rows, lr, weight_decay, eps, projected_count, status,
+                          stream, total_sqnorm, max_norm);
 }
 
 }  // extern "C"

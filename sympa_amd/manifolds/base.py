@@ -56,5 +56,16 @@ except Exception:  # noqa: BLE001
         def __repr__(self):
             return f"Parameter on {self.manifold} containing:\n" + torch.Tensor.__repr__(self)
 
+        def __deepcopy__(self, memo):
+            # nn.Parameter.__deepcopy__ rebuilds with type(self)(data, requires_grad): the manifold would be lost (and
+            # the optimiser would silently take the Euclidean branch for the copy)
+            if id(self) in memo:
+                return memo[id(self)]
+            import copy
+            result = type(self)(self.data.clone(memory_format=torch.preserve_format), copy.deepcopy(self.manifold, memo),
+                                self.requires_grad)
+            memo[id(self)] = result
+            return result
+
         def __reduce_ex__(self, proto):
             return ManifoldParameter, (self.data, self.manifold, self.requires_grad)

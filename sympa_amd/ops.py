@@ -306,8 +306,21 @@ def projx(z, model, eps=None, counter=None):
     return out
 
 
-def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None):
-    """In-place RiemannianSGD step over the whole table (one kernel)."""
+def sqnorm_accum_(x, acc):
+    """acc[0] += sum(x^2)  (C-ABI sympa_sqnorm_accum): the squared total norm of clip_grad_norm_, on the device."""
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    if x.dtype != torch.float64 or acc.dtype != torch.float64 or not x.is_contiguous():
+        raise TypeError("sqnorm_accum_ needs contiguous float64 tensors")
+    with torch.cuda.device(x.device):
+        rc = lib.sympa_sqnorm_accum(x.data_ptr(), x.numel(), acc.data_ptr(), _stream())
+    _lib.check(rc)
+    return acc
+
+
+def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None, clip_sqnorm=None, max_norm=None):
+    """In-place RiemannianSGD step over the whole table (one kernel).  With clip_sqnorm (1-element device tensor
+    holding the squared total gradient norm) and max_norm, the gradient rows are scaled like clip_grad_norm_ does."""
     lib = _lib.load()
     _need_gpu(table, "table")
     if not table.is_contiguous():
@@ -316,9 +329,15 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None)
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(table.device)
     with torch.cuda.device(table.device):
-        rc = lib.sympa_rsgd_step(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], MODEL_IDS[model],
-                                 float(lr), float(weight_decay), eps, None if counter is None else counter.data_ptr(),
-                                 st.data_ptr(), _stream())
+        if clip_sqnorm is not None:
+            rc = lib.sympa_rsgd_step_clipped(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2],
+                                             MODEL_IDS[model], float(lr), float(weight_decay), eps,
+                                             clip_sqnorm.data_ptr(), float(max_norm),
+                                             None if counter is None else counter.data_ptr(), st.data_ptr(), _stream())
+        else:
+            rc = lib.sympa_rsgd_step(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], MODEL_IDS[model],
+                                     float(lr), float(weight_decay), eps, None if counter is None else counter.data_ptr(),
+                                     st.data_ptr(), _stream())
     _lib.check(rc)
     return table
 

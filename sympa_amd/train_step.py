@@ -25,16 +25,23 @@ class GraphedTrainStep:
     def _body(self):
         self.opt.zero_grad(set_to_none=False)
         loss = self.model.fused_loss_backward(self.ids, self.gd)
-        torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
-        self.opt.step()
+        self._clip_and_step()
         self.loss.copy_(loss)
+
+    def _clip_and_step(self):
+        if hasattr(self.opt, "clip_max_norm"):       # sympa_amd.optim.RiemannianSGD: the clip rides inside the step
+            self.opt.clip_max_norm = self.max_grad_norm
+            self.opt.step()
+            self.opt.clip_max_norm = None
+        else:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+            self.opt.step()
 
     def eager(self, ids, gd):
         """The same step without a graph (ragged last batch of an epoch, multi-GPU steps with an all-reduce inside)."""
         self.opt.zero_grad(set_to_none=False)
         loss = self.model.fused_loss_backward(ids, gd)
-        torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
-        self.opt.step()
+        self._clip_and_step()
         return loss
 
     def _capture(self, lr):

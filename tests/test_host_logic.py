@@ -125,3 +125,19 @@ def test_check_all_points_batched_matches_per_point_loop():
     m.embeddings.embeds.data[3, 0, 0, 1] += 1.0                                # asymmetric row comes first
     ok, point, reason = m.check_all_points()
     assert not ok and torch.equal(point, m.embeddings.embeds.data[3]) and "symmetric" in reason
+
+
+def test_manifold_parameter_survives_deepcopy_and_pickle():
+    """copy.deepcopy(model) must keep the parameter on its manifold (nn.Parameter.__deepcopy__ would drop it and the
+    optimiser would then update the copy with the Euclidean rule)."""
+    import copy
+    import pickle
+    from sympa_amd.manifolds import UpperHalfManifold
+    from sympa_amd.manifolds.base import ManifoldParameter
+    man = UpperHalfManifold(dims=2)
+    p = ManifoldParameter(torch.zeros(3, 2, 2, 2, dtype=torch.float64), manifold=man)
+    q = copy.deepcopy(p)
+    assert isinstance(q, ManifoldParameter) and isinstance(q.manifold, UpperHalfManifold) and q.requires_grad
+    assert q.data_ptr() != p.data_ptr()
+    r = pickle.loads(pickle.dumps(p))
+    assert isinstance(r.manifold, UpperHalfManifold)

@@ -113,3 +113,42 @@ def test_gpu_rsgd_optimizer_on_model(dev, model):
         assert relmax(m.scale.detach().cpu(), scale) < 1e-8
     ops.check_status(dev)
     assert isinstance(m.manifold.projected_points, int)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("max_norm", [0.05, 1e6])
+def test_gpu_clip_folded_into_the_step_equals_torch_clip(dev, model, max_norm):
+    """RiemannianSGD.clip_max_norm (the total norm accumulated on the device, the factor applied inside the update
+    kernels) == torch.nn.utils.clip_grad_norm_ followed by the plain step (runner.py:115-116), with the clip active
+    (max_norm = 0.05) and inactive (1e6); table, scale and wsum weights are all trained."""
+    import copy
+    from sympa_amd.model import Model
+    from sympa_amd.optim import RiemannianSGD
+
+    class A:
+        manifold, metric, dims, num_points = model, "wsum", 3, 50
+        scale_coef, scale_init, train_scale = 1.0, 1.3, True
+
+    g = torch.Generator().manual_seed(33)
+    m1 = Model(A)
+    with torch.no_grad():
+        m1.embeddings.embeds.data = points(model, 50, 3, 0.3, g)
+    m1 = m1.to(dev)
+    m2 = copy.deepcopy(m1)
+    trip = torch.stack((torch.randint(0, 50, (300,), generator=g), torch.randint(0, 50, (300,), generator=g)), 1)
+    trip = trip[trip[:, 0] != trip[:, 1]].to(dev)
+    gd = torch.randint(1, 7, (trip.shape[0],), generator=g).to(torch.float64).to(dev)
+    o1 = RiemannianSGD(m1.parameters(), lr=0.05)
+    o2 = RiemannianSGD(m2.parameters(), lr=0.05)
+    for _ in range(2):
+        o1.zero_grad(); o2.zero_grad()
+        m1.fused_loss_backward(trip, gd)
+        m2.fused_loss_backward(trip, gd)
+        total = torch.nn.utils.clip_grad_norm_(m1.parameters(), max_norm)
+        o1.step()
+        o2.clip_max_norm = max_norm
+        o2.step()
+        assert (float(total) > max_norm) == (max_norm < 1.0)
+        for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+            assert relmax(b.cpu(), a.cpu()) < 1e-10, k
