@@ -218,15 +218,19 @@ __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArg
     }
 }
 
-template <int N, int MODEL>
-int launch_bwd_nm(const BwdArgs& a, bool scatter, hipStream_t s) {
+template <int N, int MODEL, bool SCATTER>
+int launch_bwd_nms(const BwdArgs& a, hipStream_t s) {
     constexpr int BLOCK = bwd_block<N>();
     const unsigned grid = (unsigned)((a.f.b + BLOCK - 1) / BLOCK);
-    if (scatter) hipLaunchKernelGGL((siegel_bwd_kernel<N, MODEL, true>), dim3(grid), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL((siegel_bwd_kernel<N, MODEL, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL((siegel_bwd_kernel<N, MODEL, SCATTER>), dim3(grid), dim3(BLOCK), 0, s, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
+}
+
+template <int N, int MODEL>
+int launch_bwd_nm(const BwdArgs& a, bool scatter, hipStream_t s) {
+    return scatter ? launch_bwd_nms<N, MODEL, true>(a, s) : launch_bwd_nms<N, MODEL, false>(a, s);
 }
 
 template <int N>
@@ -235,11 +239,18 @@ int launch_bwd_n(const BwdArgs& a, int model, bool scatter, hipStream_t s) {
                                       : launch_bwd_nm<N, sympa::MODEL_BOUNDED>(a, scatter, s);
 }
 
-// n = 7, 8: one translation unit per (n, model) -- siegel_bwd_n{7,8}_{upper,bounded}.hip -- because the fully
-// unrolled adjoint of an 8 x 8 pair takes minutes to compile; the build compiles the units in parallel.
-int launch_bwd_n7_upper(const BwdArgs& a, bool scatter, hipStream_t s);
-int launch_bwd_n7_bounded(const BwdArgs& a, bool scatter, hipStream_t s);
-int launch_bwd_n8_upper(const BwdArgs& a, bool scatter, hipStream_t s);
-int launch_bwd_n8_bounded(const BwdArgs& a, bool scatter, hipStream_t s);
+// n = 7, 8: one translation unit per kernel -- siegel_bwd_n{7,8}_{upper,bounded}_{scatter,dense}.hip -- because the
+// fully unrolled adjoint of an 8 x 8 pair takes a minute or two to compile; the build compiles the units in parallel.
+#define SYMPA_BWD_LARGE(N, M) \
+    int launch_bwd_n##N##_##M##_scatter(const BwdArgs& a, hipStream_t s); \
+    int launch_bwd_n##N##_##M##_dense(const BwdArgs& a, hipStream_t s); \
+    inline int launch_bwd_n##N##_##M(const BwdArgs& a, bool scatter, hipStream_t s) { \
+        return scatter ? launch_bwd_n##N##_##M##_scatter(a, s) : launch_bwd_n##N##_##M##_dense(a, s); \
+    }
+SYMPA_BWD_LARGE(7, upper)
+SYMPA_BWD_LARGE(7, bounded)
+SYMPA_BWD_LARGE(8, upper)
+SYMPA_BWD_LARGE(8, bounded)
+#undef SYMPA_BWD_LARGE
 
 }  // namespace sympa_hip

@@ -1,0 +1,6 @@
+// Backward kernel for n = 8, upper model, dense per-pair gradients (see siegel_bwd_kernel.hpp).
+#include "siegel_bwd_kernel.hpp"
+
+namespace sympa_hip {
+int launch_bwd_n8_upper_dense(const BwdArgs& a, hipStream_t s) { return launch_bwd_nms<8, sympa::MODEL_UPPER, false>(a, s); }
+}  // namespace sympa_hip
