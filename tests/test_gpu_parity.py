@@ -266,3 +266,20 @@ def test_dims_9_to_16_cooperative_kernel(dev, model, n):
     ops.siegel_dist_forward(bad.to(dev), z2.to(dev), model, "riem")
     with pytest.raises(AssertionError):
         ops.check_status(dev)
+
+
+@pytest.mark.parametrize("model,n", [("upper", 4), ("bounded", 4), ("upper", 8), ("bounded", 6), ("upper", 12)])
+def test_triangle_inequality_of_the_true_metrics(dev, model, n):
+    """riem (Riemannian), fone and finf (Finsler) are distances: d(x, z) <= d(x, y) + d(y, z) on random triples, over
+    every kernel family (register n <= 4, QL n <= 8, sixteen lanes n >= 9)."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(4000 + n)
+    b = 4096
+    x, y, z = (points(model, b, n, 0.4 if n <= 8 else 0.2, g).to(dev) for _ in range(3))
+    for metric in ("riem", "fone", "finf"):
+        dxz = ops.siegel_dist_forward(x, z, model, metric)
+        dxy = ops.siegel_dist_forward(x, y, model, metric)
+        dyz = ops.siegel_dist_forward(y, z, model, metric)
+        ops.check_status(dev)
+        assert torch.all(dxz <= (dxy + dyz) * (1 + 1e-12)), (model, n, metric)
+        assert torch.all(dxz > 0)
