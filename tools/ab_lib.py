@@ -9,6 +9,8 @@ import torch
 from sympa_amd import data
 
 paths = [a for a in sys.argv[1:] if not a.startswith("--")]
+streams = 4 if "--overlap" in sys.argv else 1       # --overlap: launches alternate over 4 streams, minimum-LDS kernel form
+flags = 1 if streams > 1 else 0
 rounds = 200
 dev = torch.device("cuda:0")
 nodes, n, batch, nb, gn = 5041, 4, 65536, 16, 128
@@ -28,16 +30,26 @@ for p in paths:
     def launch(i, fn=fn, outs=outs):
         t = batches[i % nb]
         rc = fn(table.data_ptr(), nodes, n, t.data_ptr(), 2, t.data_ptr() + 8, 2, batch, 0, 0, None, 1e-5,
-                scale.data_ptr(), 1.0, outs[i % nb].data_ptr(), status.data_ptr(), 0,
+                scale.data_ptr(), 1.0, outs[i % nb].data_ptr(), status.data_ptr(), flags,
                 torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     for i in range(nb):
         launch(i)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
+    side = [torch.cuda.Stream(device=dev) for _ in range(streams - 1)]
     with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        for st_ in side:
+            st_.wait_stream(main)
         for i in range(gn):
-            launch(i)
+            if i % streams == 0:
+                launch(i)
+            else:
+                with torch.cuda.stream(side[i % streams - 1]):
+                    launch(i)
+        for st_ in side:
+            main.wait_stream(st_)
     variants.append((p, g, outs))
 times = [[] for _ in variants]
 for r in range(rounds + 20):
