@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- pairwise Siegel distances/sec on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A *step* is one pass of the hot path (fused Model.forward: gather + distance + metric + scale,
-C-ABI `sympa_model_forward`) over one batch of synthetic pairs, inputs already resident in HBM.
-Default workload: upper / riem / n=4, batch 65 536 pairs per GPU, table of 5 041 nodes
-(the configuration the headline target is quoted on).  Weak scaling: every rank
-processes its own 65 536-pair shard of a (65 536 x N)-pair global batch (DistributedSampler-style
-interleave rank::N), table replicated, NO data-path collective.
+C-ABI `sympa_model_forward`, ONE kernel launch) over one batch of synthetic pairs, inputs already
+resident in HBM.  Default workload: upper / riem / n=4, batch 65 536 pairs per GPU, table of 5 041
+nodes (the configuration the headline target is quoted on).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md section 7 for every field).
+Scaling modes (the pair list shards by triplet, the table is replicated, NO data-path collective):
+  weak   (default)  every rank processes its own B-pair shard of a (B x N)-pair global batch
+                    (DistributedSampler-style interleave rank::N);
+  strong            the global batch is fixed at the workload's B and rank r takes pairs r::N of it
+                    (B / N pairs per GPU per step: the reference's semantics, train.py:105-110).
+
+Prints ONE JSON line on rank 0 (DESIGN.md section 7 explains every field).
 """
 import argparse
 import json
@@ -24,24 +28,44 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (model, metric, dims, nodes, batch per GPU)  -- BASELINE.json configs
+    # name: (model, metric, dims, nodes, batch)  -- BASELINE.json configs
     "upper-riem-n4-b65536": ("upper", "riem", 4, 5041, 65536),     # headline
     "tree-upper-riem-n4-b8192": ("upper", "riem", 4, 1093, 8192),  # configs[1]
     "grid-upper-riem-n2-b512": ("upper", "riem", 2, 125, 512),     # configs[0]
     "margulis-bounded-finf-n4-b65536": ("bounded", "finf", 4, 5041, 65536),  # configs[2]
-    "cartesian-upper-riem-n8-b262144": ("upper", "riem", 8, 45500, 262144),  # configs[3], per-GPU shard 32768 at 8 GPUs
+    "cartesian-upper-riem-n8-b262144": ("upper", "riem", 8, 45500, 262144),  # configs[3]
     "custom-spd-n16-b1048576": ("spd", "riem", 16, 100000, 1048576),         # configs[4] (parity unpinned: geoopt absent)
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MEASURED_COPY_GBS = 6290.0   # same guide, chip table: measured copy bandwidth
-FP64_VALU_PEAK_TFLOPS = 78.6   # AMD datasheet (vector fp64); reported as the honest second roof
+MODEL_ID = {"upper": 0, "bounded": 1}
 
 
 def algorithmic_bytes_per_pair(n, model="upper"):
     """2 int64 indices + two fp64 points ([2,n,n] Siegel, [n,n] spd) + one fp64 output, no reuse credit."""
     planes = 1 if model == "spd" else 2
     return 2 * 8 + 2 * (planes * n * n * 8) + 8
+
+
+def kernel_name(model, n, low_lds):
+    """Name of the kernel instantiation a forward launch runs (as `rocprofv3 --kernel-trace` prints it)."""
+    if model == "spd":
+        return "spd16_coop_kernel" if n >= 6 else "spd_dist_kernel"
+    if n > 8:
+        return f"siegel_coop_kernel (n={n})"
+    low = bool(low_lds) and n in (2, 4)          # DmaTile<N>::ENABLED (csrc/siegel_gather.hpp)
+    return f"siegel_dist_kernel<{n}, {MODEL_ID[model]}, {'true' if low else 'false'}, false>"
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
@@ -86,6 +110,7 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
             if el > budget_s or iters >= 50:
                 break
     return {"value": done / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model_name(), "host_logical_cpus": ncpu,
             "sample": f"{iters} x batch {batch} of the same workload, oracle/siegel_oracle.py "
                       f"{'spd_model_forward' if model == 'spd' else 'model_forward'}, "
                       f"{el:.1f} s"}
@@ -97,22 +122,24 @@ def main():
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--workload", default="upper-riem-n4-b65536", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch pairs per GPU per step; strong: --batch pairs per step in total, "
+                         "rank r takes pairs r::N (train.py:105-110)")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's pairs per step")
     ap.add_argument("--table", default="trained", choices=["trained", "init"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=16)
     ap.add_argument("--graph-nodes", type=int, default=128,
-                    help="kernel launches (= steps) captured per hipGraph; one replay costs ~10 us of host/launch "
-                         "overhead whatever its length")
-    ap.add_argument("--streams", type=int, default=4,
+                    help="kernel launches (= steps) captured per hipGraph")
+    ap.add_argument("--streams", type=int, default=0,
                     help="graph launch only: the steps of the timed region are captured on this many parallel HIP "
                          "streams, so that independent steps (different batches, different outputs) overlap on the "
                          "GPU: the next steps gather while the previous ones compute (minimum-LDS kernel form, three "
-                         "blocks per CU); 1 = strictly sequential launches")
+                         "blocks per CU); 1 = strictly sequential launches; 0 = 4 (8 when a step is < 1 wave per SIMD)")
     ap.add_argument("--launch", default="graph", choices=["graph", "direct"],
-                    help="graph: the steps are replayed from a captured hipGraph of --distinct-batches kernel "
-                         "nodes (one node = one step); direct: one Python->C-ABI call per step")
+                    help="graph: the steps are replayed from captured hipGraphs whose nodes are the launches "
+                         "(one node = one step); direct: one Python->C-ABI call per step")
     args = ap.parse_args()
 
     import torch
@@ -144,6 +171,8 @@ def main():
     model, metric, n, nodes, batch = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
+    # pairs of one GLOBAL step and of this rank's shard of it
+    global_pairs = batch * world if args.scaling == "weak" else batch
     if model == "spd":
         table_cpu = data.spd_table(nodes, n, seed=args.seed)
     else:
@@ -153,55 +182,58 @@ def main():
         raise SystemExit("init table is defined for the upper model")
     table = table_cpu.to(dev)
     scale = torch.ones(1, dtype=torch.float64, device=dev)
-    # global batch j has batch*world pairs; this rank takes the interleave rank::world (weak scaling)
+    # global batch j has `global_pairs` pairs; this rank takes the interleave rank::world of it
     nb = max(1, min(args.distinct_batches, args.steps))
     batches = []
     for j in range(nb):
-        glob = data.sample_pairs(nodes, batch * world, j, args.seed)
+        glob = data.sample_pairs(nodes, global_pairs, j, args.seed)
         batches.append(glob[rank::world].contiguous().to(dev))
-    outs = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(nb)]
-    out = outs[0]
+    my_pairs = batches[0].shape[0]
+    outs = [torch.empty(my_pairs, dtype=torch.float64, device=dev) for _ in range(nb)]
     if args.launch == "direct":
         args.streams = 1
+    if args.streams <= 0:
+        # a launch of < 1 wave per SIMD (65 536 pairs) leaves SIMDs idle: more launches in flight
+        args.streams = 4 if my_pairs >= 65536 else 8
     flags = ops.FLAG_LOW_LDS if (args.streams > 1 and not os.environ.get('SYMPA_BENCH_FULL_LDS')) else 0
     flags |= int(os.environ.get('SYMPA_BENCH_FLAGS', '0'), 0)
 
-    def step(i, fl=None):
+    def step(i, fl=None, dst=None):
+        o = (outs if dst is None else dst)[i % nb]
         if model == "spd":
-            ops.spd_model_forward(table, batches[i % nb], scale, 1.0, out=outs[i % nb])
+            ops.spd_model_forward(table, batches[i % nb], scale, 1.0, out=o)
             return
-        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=outs[i % nb],
+        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=o,
                           flags=flags if fl is None else fl)
 
     def sync_all():
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
 
     # ---- launch plan: K steps = K kernel launches, either direct or replayed from hipGraphs whose nodes are
-    # the launches themselves (a step is still exactly one kernel over one batch).  Two graphs are captured:
-    # a long one (--graph-nodes launches) and a short one (one cycle of the nb distinct batches); K steps =
-    # as many long replays as fit, then short ones, then direct launches for the last < nb steps.
-    def capture(nodes, streams=None, fl=None):
+    # the launches themselves (a step is still exactly one kernel over one batch): a long graph (--graph-nodes
+    # launches) plus exact-size graphs for what is left of K and of W, so no step is launched from Python.
+    def capture(nodes_, streams=None, fl=None, dst=None):
         streams = args.streams if streams is None else streams
         g_ = torch.cuda.CUDAGraph()
         side = [torch.cuda.Stream(device=dev) for _ in range(max(0, streams - 1))]
         # thread_local: with N > 1 the RCCL watchdog thread polls events while we capture; only THIS thread's calls
         # belong to the capture
         with torch.cuda.graph(g_, capture_error_mode="thread_local"):
-            main = torch.cuda.current_stream()
+            main_s = torch.cuda.current_stream()
             for st in side:
-                st.wait_stream(main)                     # fork
-            for i in range(nodes):
+                st.wait_stream(main_s)                     # fork
+            for i in range(nodes_):
                 k = i % streams
                 if k == 0:
-                    step(i, fl)
+                    step(i, fl, dst)
                 else:
                     with torch.cuda.stream(side[k - 1]):
-                        step(i, fl)
+                        step(i, fl, dst)
             for st in side:
-                main.wait_stream(st)                     # join
+                main_s.wait_stream(st)                     # join
         return g_
 
     graphs = []          # [(nodes, graph)], longest first
@@ -212,121 +244,169 @@ def main():
         torch.cuda.synchronize(dev)
         gn = max(1, min(args.graph_nodes, args.steps))
         graphs.append((gn, capture(gn)))
-        # exact-size graphs for what is left of K and of W after the long replays: no step of the timed region is
-        # launched from Python (a direct call is host-bound at ~15 us), whatever K the caller asks for
         for rem in sorted({args.steps % gn, args.warmup % gn} - {0, gn}, reverse=True):
             graphs.append((rem, capture(rem)))
 
     def run_steps(k):
         done = 0
-        for nodes, g_ in graphs:
-            while k - done >= nodes and (nodes == gn or k - done == nodes):
+        for nodes_, g_ in graphs:
+            while k - done >= nodes_ and (nodes_ == gn or k - done == nodes_):
                 g_.replay()
-                done += nodes
+                done += nodes_
         while done < k:
             step(done)
             done += 1
 
     # clock / cache pre-warm (not part of the W warmup steps or the K timed steps): ~0.2 s of the same launches,
     # so that a GPU coming out of idle has reached its sustained clock before the contractually timed region
+    prewarm_s = float(os.environ.get("SYMPA_BENCH_PREWARM_S", "0.2"))
+    pre_graph = None
+    if args.launch == "graph" and gn < args.graph_nodes and os.environ.get("SYMPA_BENCH_PREWARM_LONG"):
+        pre_graph = capture(args.graph_nodes)
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.2:
-        run_steps(max(gn, nb))
+    while time.perf_counter() - t_pre < prewarm_s:
+        if pre_graph is not None:
+            pre_graph.replay()
+        else:
+            run_steps(max(gn, nb))
         torch.cuda.synchronize(dev)
-    run_steps(args.warmup)
+    run_steps(args.warmup)          # the W contractual warmup steps
+    if not os.environ.get("SYMPA_BENCH_NO_HOT_REPLAY"):
+        run_steps(args.steps)       # one more untimed pass of the exact launch plan of the timed region (hot graphs)
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    # the same K steps once more, untimed by the wall clock, bracketed by HIP events on the launch stream: what the GPU
+    # side of such a region takes (recording events INSIDE the wall-timed region costs it ~70 us of host time)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    run_steps(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    device_ms = ev0.elapsed_time(ev1)
     ops.check_status(dev)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, device_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, device_ms = float(t[0].item()), float(t[1].item())
 
-    # Dominant-kernel duration for the roofline object: the SAME launches, strictly sequential on the launch
-    # stream (torch's current stream), bracketed by HIP events per group of back-to-back launches (one graph
-    # replay or nb direct launches).  The quotient includes the inter-kernel gaps, so it is an upper bound of
-    # the kernel's own duration; it is what `rocprofv3 --kernel-trace --stats` reports for the sequential
-    # kernel (`siegel_dist_kernel<..., false, false>`).  When the timed region overlaps steps on several
-    # streams its kernels live longer individually; that is why the roofline is taken on the sequential pass.
-    per_group = gn if graphs else nb
-    seq_graph = None
-    if graphs and args.streams > 1:
-        seq_graph = capture(per_group, streams=1, fl=0)
-
-    def run_group():
-        if seq_graph is not None:
-            seq_graph.replay()
-        else:
-            run_steps(per_group)
-
-    for _ in range(2):
-        run_group()
+    # ---- every output of the timed variant against a strictly sequential pass of the default kernel form
+    # (different instantiation when the timed region ran the minimum-LDS form): same arithmetic => bit-identical
+    # up to the wave-dependent number of extra (harmless) QL sweeps for n >= 5
+    ref_outs = [torch.empty_like(o) for o in outs]
+    for i in range(nb):
+        step(i, 0, ref_outs)
     torch.cuda.synchronize(dev)
-    groups = max(2, min(16, args.steps // per_group))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
-    for gidx in range(groups):
-        ev[gidx][0].record()
-        run_group()
-        ev[gidx][1].record()
-    torch.cuda.synchronize(dev)
-    kernel_ms = sorted(a.elapsed_time(b) / per_group for a, b in ev)
-    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
-    kernel_med_ms = kernel_ms[len(kernel_ms) // 2]
-
-    checksum = float(out.sum().item())
+    for i in range(min(nb, args.steps)):
+        same = torch.equal(outs[i], ref_outs[i]) if (model != "spd" and n <= 4) else \
+            torch.allclose(outs[i], ref_outs[i], rtol=1e-11, atol=1e-13)
+        assert same, f"timed-region output {i} differs from the sequential default-kernel pass"
+    checksum = float(outs[0].sum().item())
     assert checksum == checksum and checksum > 0, "bench produced non-finite distances"
 
+    # ---- per-kernel duration for the roofline objects: the SAME launches, strictly sequential on the launch
+    # stream (torch's current stream), bracketed by HIP events per group of back-to-back launches.  The quotient
+    # includes the inter-kernel gaps (upper bound of the kernel's own duration); it is what
+    # `rocprofv3 --kernel-trace --stats` reports per kernel (the profiler serialises a queue's dispatches).
+    per_group = max(1, min(args.graph_nodes, max(args.steps, 64)))
+
+    def kernel_time(fl):
+        if args.launch == "graph":
+            g_ = capture(per_group, streams=1, fl=fl)
+            run_group = g_.replay
+        else:
+            def run_group():
+                for i in range(per_group):
+                    step(i, fl)
+        for _ in range(2):
+            run_group()
+        torch.cuda.synchronize(dev)
+        groups = 8
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
+        for a, b in ev:
+            a.record()
+            run_group()
+            b.record()
+        torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(b) / per_group for a, b in ev)
+        return sum(ms) / len(ms), ms[len(ms) // 2]
+
+    timed_kernel = kernel_name(model, n, flags & ops.FLAG_LOW_LDS)
+    default_kernel = kernel_name(model, n, 0)
+    k_timed = kernel_time(flags)
+    k_default = k_timed if default_kernel == timed_kernel else kernel_time(0)
+
     if rank == 0:
-        pairs_total = batch * world * args.steps
+        pairs_total = global_pairs * args.steps
         value = pairs_total / elapsed
         bpp = algorithmic_bytes_per_pair(n, model)
-        achieved = bpp * batch / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = None
-        valu_per_wave = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
             try:
-                rec_pmc = json.load(open(pmc)).get(args.workload, {})
-                traffic = rec_pmc.get("hbm_bytes_per_launch")
-                c = rec_pmc.get("counters_avg_per_launch", {})
-                if c.get("SQ_WAVES"):
-                    valu_per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+                pmc = json.load(open(pmc_path)).get(args.workload, {})
             except Exception:  # noqa: BLE001
-                traffic = None
+                pmc = {}
+        c = pmc.get("counters_avg_per_launch", {})
+        valu_per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] if c.get("SQ_WAVES") else None
+        # PMC counters cannot be read from inside the run (rocprofv3 wraps the process): `traffic` is the figure of the
+        # committed counter pass of THIS command line (tools/pmc_collect.sh, one counter group per run) and says so
+        traffic = pmc.get("hbm_bytes_per_launch") if my_pairs == WORKLOADS[args.workload][4] else None
+
+        def roof(kname, kt, note):
+            avg_ms, med_ms = kt
+            ach = bpp * my_pairs / (avg_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic,
+                    "traffic_source": (f"profiles/pmc_latest.json [{pmc.get('round', '?')}]: {pmc.get('source', '')}; "
+                                       "2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of 16 B/lane reads, "
+                                       "MI355X_MICROARCH.md HBM section); not measured in this run") if traffic else None,
+                    "kernel": kname, "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
+                    "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": my_pairs,
+                    "pairs_per_s_kernel_only": my_pairs / (avg_ms * 1e-3),
+                    "frac_of_measured_copy_bw": ach / MEASURED_COPY_GBS,
+                    "mode": note}
+
         rec = {
             "metric": "pairwise Siegel distances/sec (upper, riem, n=4)" if args.workload == "upper-riem-n4-b65536"
                       else (f"pairwise SPD affine-invariant distances/sec (n={n})" if model == "spd"
                             else f"pairwise Siegel distances/sec ({model}, {metric}, n={n})"),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3,
+            # HIP events on the launch stream around an identical repetition of the K steps (max over ranks): what the GPU
+            # side of the timed region takes, launch latency of the first graph included
+            "ms_per_step_device": device_ms / args.steps,
+            "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "model": None, "manifold": model, "dist_metric": metric,
-                       "dims": n, "nodes": nodes, "pairs_per_gpu_per_step": batch,
-                       "global_pairs_per_step": batch * world, "table": args.table, "launch": args.launch, "streams": args.streams,
+            "config": {"workload": args.workload, "manifold": model, "dist_metric": metric,
+                       "dims": n, "nodes": nodes, "pairs_per_gpu_per_step": my_pairs,
+                       "global_pairs_per_step": global_pairs, "table": args.table, "launch": args.launch,
+                       "streams": args.streams,
                        "parallelism": f"pairs sharded rank::{world}, table replicated, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "spd16_coop_kernel" if model == "spd" else "siegel_dist_kernel", "kernel_avg_us": kernel_avg_ms * 1e3,
-                         "kernel_median_us": kernel_med_ms * 1e3,
-                         "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": batch,
-                         "pairs_per_s_kernel_only": batch / (kernel_avg_ms * 1e-3),
-                         "mode": "sequential launches of the same steps on one stream (rocprof-comparable)"},
+            # the kernel instantiation the timed region ran, timed alone (sequential launches: what rocprofv3 reports)
+            "roofline": roof(timed_kernel, k_timed,
+                             "the timed region's kernel instantiation, launched strictly sequentially on one stream "
+                             "(HIP events; rocprof-comparable). The contract roof is HBM (SURVEY 8d: algorithmic "
+                             "bytes, no reuse credit); the table is cache-resident and the kernel is bound by fp64 "
+                             "VALU issue and L2->LDS gather latency (valu_issue_fraction, DESIGN.md section 5)"),
             # whole-job throughput of the timed region expressed against the same roof (steps overlap on
             # --streams streams, so this exceeds roofline.frac, which is a per-kernel figure)
-            "throughput_frac_of_hbm_roof": value * bpp / (HBM_PEAK_GBS * 1e9),
+            "throughput_frac_of_hbm_roof": (value / world) * bpp / (HBM_PEAK_GBS * 1e9),
         }
-        # SURVEY 8d's "honest second roofs": the measured copy bandwidth of the chip table, and the fp64 VALU issue
-        # slots the whole job occupies (VALU instructions per wave from the committed PMC pass; one wave = 64 pairs;
-        # a wave instruction occupies its SIMD for 4 cycles; 1024 SIMDs at the 2.4 GHz peak clock)
-        rec["roofline"]["frac_of_measured_copy_bw"] = achieved / MEASURED_COPY_GBS
+        if default_kernel != timed_kernel:
+            rec["roofline_default_kernel"] = roof(
+                default_kernel, k_default,
+                "the kernel a single Model.forward call runs (both endpoints staged at once, one block per CU), "
+                "launched strictly sequentially on one stream")
+        # SURVEY 8d's "honest second roof": the fp64 VALU issue slots the whole job occupies (VALU instructions per
+        # wave from the committed PMC pass; one wave = 64 pairs; a wave instruction occupies its SIMD for 4 cycles;
+        # 1024 SIMDs at the 2.4 GHz peak clock)
         if valu_per_wave:
             rec["valu_issue_fraction"] = (value / world) / 64.0 * valu_per_wave * 4.0 / (1024 * 2.4e9)
-        del rec["config"]["model"]
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, batch, args.seed)
+            rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, my_pairs, args.seed)
         else:
             rec["cpu_baseline"] = None
     if use_dist:

@@ -54,6 +54,11 @@ extern "C" {
 #define SYMPA_FLAG_GENERIC 2 /* run the runtime-n one-lane-per-pair kernel even where a sixteen-lanes-per-pair one applies
                                 (spd n >= 6, upper / bounded n >= 9); the tests cross-check the two */
 
+#define SYMPA_FLAG_ANY_ORDER 4 /* forward launches only: dispatch without the in-order barrier bit (hipExtAnyOrderLaunch), so
+                                  the launch may start while earlier launches of the same stream still run.  Only for
+                                  launches that do not depend on earlier work of that stream (independent batches);
+                                  a later ordinary launch or synchronisation still waits for all of them */
+
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] run sixteen lanes per pair
@@ -92,6 +97,18 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
                         const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                         const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
                         int32_t* status, int flags, void* stream);
+
+/* Model.forward over a LIST of batches: what Runner.evaluate's loop (sympa/runner.py:126-137) and the batch loop of
+ * Runner.train_epoch's forward (runner.py:98-103) issue one call at a time.  Batch i reads the int64 triplets
+ * triplets[i] ([b[i], stride], src = column 0, dst = column 1) and writes out[i] ([b[i]] fp64); `triplets`, `b`,
+ * `out` and `streams` are HOST arrays (of device pointers / sizes / hipStream_t).  Launch i goes to
+ * streams[i % num_streams]: the batches are independent, so consecutive launches overlap on the GPU (the next batch
+ * gathers its rows while the previous one computes) -- with SYMPA_FLAG_LOW_LDS three blocks of different launches share
+ * a CU.  One kernel launch per batch, exactly as num_batches calls of sympa_model_forward; nothing is synchronised. */
+int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, const int64_t* const* triplets,
+                                int64_t stride, const int64_t* b, int num_batches, int model, int metric,
+                                const double* metric_w, double eps, const double* scale, double scale_coef,
+                                double* const* out, int32_t* status, int flags, void* const* streams, int num_streams);
 
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
  * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):

@@ -16,6 +16,7 @@ SYMBOLS = (
     "sympa_max_dims",
     "sympa_siegel_dist_fwd",
     "sympa_model_forward",
+    "sympa_model_forward_batches",
     "sympa_all_pairs_dist",
     "sympa_siegel_dist_bwd",
     "sympa_model_backward",
@@ -67,6 +68,12 @@ def load():
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p,
         ctypes.c_double, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+    ]
+    lib.sympa_model_forward_batches.restype = ctypes.c_int
+    lib.sympa_model_forward_batches.argtypes = [
+        _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, ctypes.c_void_p,
+        _c_i32_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
     ]
     lib.sympa_all_pairs_dist.restype = ctypes.c_int
     lib.sympa_all_pairs_dist.argtypes = [

@@ -113,9 +113,17 @@ __global__ __launch_bounds__(64) void siegel_coop_kernel(const DistArgs a, const
     const bool conv = sympa::tridiag_ql_lockstep<N>(d, e2);
     double v[N];
     constexpr double quarter = (MODEL == sympa::MODEL_UPPER) ? 0.25 : 1.0;      // sinh(v/2) = sigma / 2 (upper), sigma (bounded)
+    bool finite = true;          // tested before the clamp: fmax would turn a NaN eigenvalue into distance 0
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = sympa::vvd_from_sinh2(fmax(d[k], 0.0) * quarter, a.inv_eps);
+    for (int k = 0; k < N; ++k) {
+        finite = finite && sympa::d_finite(d[k]);
+        v[k] = sympa::vvd_from_sinh2(fmax(d[k], 0.0) * quarter, a.inv_eps);
+    }
     sympa::sort_ascending<N>(v);
+    if (!finite) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = __builtin_nan("");
+    }
     const int pad = N - n;
     if (a.vvd != nullptr && live) {
 #pragma unroll
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(64) void siegel_coop_kernel(const DistArgs a, const
             if (k >= pad) a.vvd[i * n + (k - pad)] = v[k];
     }
     double out = reduce_metric_padded(v, n, a.metric, a.metric_w);
+    if (!finite) out = __builtin_nan("");
     if (!ok) st |= sympa::ST_NOT_PD;
     if (!conv) st |= sympa::ST_NO_CONVERGENCE;
     if (!(out == out) || !(fabs(out) <= 1.79e308)) st |= sympa::ST_NONFINITE;

@@ -8,6 +8,7 @@
 // The workload is VALU-fp64 bound: the table rows come out of L2 / Infinity Cache.
 #include "siegel_common.hpp"
 #include "siegel_math_generic.hpp"
+#include <hip/hip_ext.h>
 
 namespace sympa_hip {
 
@@ -144,21 +145,35 @@ __global__ __launch_bounds__(64) void siegel_dist_generic_kernel(const DistArgs 
     }
 }
 
+// One launch.  SYMPA_FLAG_ANY_ORDER: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch), so the command
+// processor may start it while earlier launches of the SAME stream are still running -- independent steps overlap
+// without any cross-stream dependency.
+template <typename K>
+hipError_t launch_kernel(K kern, unsigned grid, const DistArgs& a, hipStream_t s) {
+    if (a.flags & SYMPA_FLAG_ANY_ORDER) {
+        void* args[] = {const_cast<DistArgs*>(&a)};
+        return hipExtLaunchKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(BLOCK), args, 0, s, nullptr,
+                                  nullptr, hipExtAnyOrderLaunch);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int N>
 int launch_n(const DistArgs& a, int model, hipStream_t s) {
     const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
     // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
     const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256);
+    hipError_t e;
     if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
-        hipLaunchKernelGGL((siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, a, s);
     } else if (model == SYMPA_MODEL_UPPER) {
-        if (low) hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER, true>), dim3(grid), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_UPPER, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, a, s);
+        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, a, s);
     } else {
-        if (low) hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>), dim3(grid), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>, grid, a, s);
+        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>, grid, a, s);
     }
-    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
 }
@@ -253,6 +268,23 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
     a.metric = metric;
     a.flags = flags;
     return launch(a, n, model, stream);
+}
+
+int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, const int64_t* const* triplets,
+                                int64_t stride, const int64_t* b, int num_batches, int model, int metric,
+                                const double* metric_w, double eps, const double* scale, double scale_coef,
+                                double* const* out, int32_t* status, int flags, void* const* streams, int num_streams) {
+    if (num_batches < 0 || num_streams < 1 || streams == nullptr) return fail(SYMPA_ERR_BAD_ARG, "bad batch / stream list");
+    if (num_batches > 0 && (triplets == nullptr || b == nullptr || out == nullptr))
+        return fail(SYMPA_ERR_BAD_ARG, "null batch list");
+    if (stride < 2) return fail(SYMPA_ERR_BAD_ARG, "triplet stride must be >= 2");
+    for (int i = 0; i < num_batches; ++i) {
+        const int rc = sympa_model_forward(table, num_rows, n, triplets[i], stride, triplets[i] + 1, stride, b[i], model,
+                                           metric, metric_w, eps, scale, scale_coef, out[i], status, flags,
+                                           streams[i % num_streams]);
+        if (rc != 0) return rc;
+    }
+    return 0;
 }
 
 int sympa_all_pairs_dist(const double* table, int64_t num_rows, int n, int64_t row_begin, int64_t row_count, int model,

@@ -71,6 +71,8 @@ SYMPA_HD double d_frexp_mant(double x) { int e; return std::frexp(x, &e); }
 SYMPA_HD int d_frexp_exp(double x) { int e; (void)std::frexp(x, &e); return e; }
 #endif
 SYMPA_HD double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// neither NaN nor +-Inf (every comparison with a NaN is false)
+SYMPA_HD bool d_finite(double x) { return fabs(x) <= 1.79e308; }
 
 // 1/sqrt(x): seed + one Halley step  y <- y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2.      (6 ops)
 SYMPA_HD double d_rsqrt(double x) {
@@ -444,7 +446,9 @@ SYMPA_HD bool jacobi_can_finish(const Herm<N>& h) {
             const double a2 = d_fma(h.re[p][q], h.re[p][q], h.im[p][q] * h.im[p][q]);
             const double delta = h.d[q] - h.d[p];
             off2 += a2;
-            ok = ok && (a2 <= fmax(finish_t2<N>() * delta * delta, floor2));
+            // written so that a NaN (non-finite input) counts as "finished": no extra sweeps are spent on it, the
+            // eigenvalues are tested for finiteness afterwards (pair_distance_mats)
+            ok = ok && !(a2 > fmax(finish_t2<N>() * delta * delta, floor2));
         }
     }
     return ok && !(off2 > finish_off2<N>() * diag2);
@@ -626,7 +630,9 @@ SYMPA_HD bool tridiag_ql(double (&d)[N], double (&e2)[N]) {
 // Lanes that are through with position L do not idle until the slowest one is: they take their shift from the
 // first position in {L+1, L+2} that still has a non-negligible off-diagonal (a deflated e^2 = 0 makes the
 // sweep pass through that position with c = 1, s = 0: an identity), so they arrive at the next stages converged.
-SYMPA_HD bool ql_negligible(double e2, double da, double db) { return e2 <= 1.3e-32 * fabs(da * db) + 1e-290; }
+// (a NaN off-diagonal counts as negligible: the iteration does not spin on non-finite input, which is caught by the
+// finiteness test of the eigenvalues afterwards)
+SYMPA_HD bool ql_negligible(double e2, double da, double db) { return !(e2 > 1.3e-32 * fabs(da * db) + 1e-290); }
 
 template <int N, int L>
 SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
@@ -822,18 +828,30 @@ SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int met
 
     const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
     double v[N];
+    // A NaN / Inf anywhere in the two points reaches H through E = L1^-1 (Z2 - Z1) L2^-T and from there the
+    // eigenvalues; fmax(lambda, 0) below would turn a NaN into distance 0, so finiteness is tested BEFORE the clamp
+    // (the reference yields NaN and fails its assert, siegel_manifold.py:64-66).
+    bool finite = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = vvd_from_sinh2(fmax(h.d[i], 0.0) * scale, inv_eps);
+    for (int i = 0; i < N; ++i) {
+        finite = finite && d_finite(h.d[i]);
+        v[i] = vvd_from_sinh2(fmax(h.d[i], 0.0) * scale, inv_eps);
+    }
+    if (!finite) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = __builtin_nan("");
+    }
 
     if (vvd != nullptr) {
         sort_ascending<N>(v);
 #pragma unroll
         for (int i = 0; i < N; ++i) vvd[i] = v[i];
     }
-    const double out = reduce_metric<N>(v, metric, w);
+    double out = reduce_metric<N>(v, metric, w);
+    if (!finite) out = __builtin_nan("");       // (the max / min based metrics drop a NaN operand)
     if (!ok) status |= ST_NOT_PD;
     if (!conv) status |= ST_NO_CONVERGENCE;
-    if (!(out == out) || !(fabs(out) <= 1.79e308)) status |= ST_NONFINITE;
+    if (!d_finite(out)) status |= ST_NONFINITE;
     return out;
 }
 

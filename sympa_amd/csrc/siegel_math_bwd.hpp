@@ -298,8 +298,10 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
     const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
     double vv[N], dv[N], lam[N];
     int rank[N];
+    bool finite = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
+        finite = finite && d_finite(h.d[i]);     // before the clamp: fmax drops a NaN
         lam[i] = fmax(h.d[i], 0.0);
         const double lp = lam[i] * scale;
         const double root = d_sqrt(d_fma(lp, lp, lp));       // sqrt(lp (1 + lp))
@@ -407,9 +409,10 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
                 g2.im[i][j] = 0.5 * (t2.im[i][j] + t2.im[j][i]);
             }
     }
+    if (!finite) out = __builtin_nan("");     // non-finite input: the forward value is NaN like the gradients
     if (!ok) status |= ST_NOT_PD;
     if (!conv) status |= ST_NO_CONVERGENCE;
-    if (!(out == out) || !(fabs(out) <= 1.79e308)) status |= ST_NONFINITE;
+    if (!d_finite(out)) status |= ST_NONFINITE;
     return out;
 }
 

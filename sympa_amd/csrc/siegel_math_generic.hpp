@@ -158,7 +158,11 @@ SYMPA_HD double pair_distance_generic(GenericWork& w, const double* __restrict__
             }
     }
     const double scale = (model == MODEL_UPPER) ? 0.25 : 1.0;
-    for (int i = 0; i < n; ++i) w.v[i] = vvd_from_sinh2(fmax(w.hr[gix(n, i, i)], 0.0) * scale, inv_eps);
+    bool finite = true;          // tested before the clamp: fmax would turn a NaN eigenvalue into distance 0
+    for (int i = 0; i < n; ++i) {
+        finite = finite && d_finite(w.hr[gix(n, i, i)]);
+        w.v[i] = vvd_from_sinh2(fmax(w.hr[gix(n, i, i)], 0.0) * scale, inv_eps);
+    }
     for (int i = 1; i < n; ++i) {            // insertion sort, ascending
         const double x = w.v[i];
         int j = i - 1;
@@ -171,6 +175,10 @@ SYMPA_HD double pair_distance_generic(GenericWork& w, const double* __restrict__
     else if (metric == METRIC_FINF) { out = w.v[n - 1]; }
     else if (metric == METRIC_FMIN) { for (int i = 0; i < n; ++i) out += 2.0 * i * w.v[i]; }
     else { for (int i = 0; i < n; ++i) out += fmax(mw[i], 0.0) * w.v[i]; }
+    if (!finite) {
+        out = __builtin_nan("");
+        for (int i = 0; i < n; ++i) w.v[i] = out;
+    }
     if (vvd != nullptr) for (int i = 0; i < n; ++i) vvd[i] = w.v[i];
     if (!ok) status |= ST_NOT_PD;
     if (!conv) status |= ST_NO_CONVERGENCE;

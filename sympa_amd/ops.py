@@ -84,6 +84,7 @@ def _weights(metric, weights, n, device):
 
 FLAG_LOW_LDS = 1
 FLAG_GENERIC = 2      # spd: force the runtime-n one-lane-per-pair kernel
+FLAG_ANY_ORDER = 4    # forward: dispatch without the in-order barrier bit (independent batches of one stream overlap)
 
 
 def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=None, return_vvd=False, flags=0):
@@ -163,6 +164,81 @@ def model_forward(table, triplets, model="upper", metric="riem", weights=None, s
     if _debug:
         check_status(dev)
     return out
+
+
+class BatchedForward:
+    """Model.forward over a list of batches in ONE C call (C-ABI sympa_model_forward_batches; the loop of
+    Runner.evaluate, runner.py:126-137): launch i reads `batches[i]` ([b_i, 2|3] int64) and writes `outs[i]`, on
+    streams[i % len(streams)].  The host-side pointer arrays are built once here; `run()` is a single ctypes call
+    that enqueues every launch and returns without synchronising.  The caller orders the streams against the
+    producers of the inputs / consumers of the outputs (torch stream semantics)."""
+
+    def __init__(self, table, batches, outs, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0,
+                 eps=None, flags=0, streams=None):
+        self.lib = _lib.load()
+        _need_gpu(table, "table")
+        if table.dtype != torch.float64 or table.dim() != 4 or table.shape[1] != 2 or table.shape[2] != table.shape[3]:
+            raise ValueError(f"table must be float64 [N,2,n,n], got {tuple(table.shape)} {table.dtype}")
+        if not table.is_contiguous():
+            raise ValueError("table must be contiguous")
+        if len(batches) != len(outs):
+            raise ValueError("one output per batch")
+        k = len(batches)
+        stride = None
+        for t, o in zip(batches, outs):
+            _need_gpu(t, "triplets"); _need_gpu(o, "out")
+            if t.dtype != torch.int64 or t.dim() != 2 or t.shape[1] < 2 or not t.is_contiguous():
+                raise TypeError("every batch must be a contiguous int64 [b, >=2] tensor")
+            if stride is not None and t.shape[1] != stride:
+                raise ValueError("all batches must have the same number of columns")
+            stride = t.shape[1]
+            if o.dtype != torch.float64 or not o.is_contiguous() or o.numel() < t.shape[0]:
+                raise TypeError("every output must be a contiguous float64 tensor of at least b elements")
+        self.keep = (table, list(batches), list(outs), weights, scale)
+        self.dev = table.device
+        self.n = table.shape[2]
+        self.num_rows = table.shape[0]
+        self.stride = stride or 2
+        self.k = k
+        self.trip = (ctypes.c_void_p * max(k, 1))(*[t.data_ptr() for t in batches])
+        self.b = (ctypes.c_int64 * max(k, 1))(*[t.shape[0] for t in batches])
+        self.out = (ctypes.c_void_p * max(k, 1))(*[o.data_ptr() for o in outs])
+        self.w = _weights(metric, weights, self.n, self.dev) if metric == "wsum" else None
+        self.sc = None
+        if scale is not None:
+            self.sc = scale if (scale.device == self.dev and scale.dtype == torch.float64) \
+                else scale.detach().to(self.dev, torch.float64)
+        self.args = (MODEL_IDS[model], METRIC_IDS[metric], None if self.w is None else self.w.data_ptr(),
+                     1e-5 if eps is None else float(eps), None if self.sc is None else self.sc.data_ptr(),
+                     float(scale_coef))
+        self.flags = int(flags)
+        self.status = _status_buf(self.dev)
+        self.set_streams(streams)
+
+    def set_streams(self, streams):
+        if not streams:
+            streams = [torch.cuda.current_stream(self.dev)]
+        self.streams = list(streams)
+        self.stream_arr = (ctypes.c_void_p * len(self.streams))(*[s.cuda_stream for s in self.streams])
+
+    def run(self, first=0, count=None):
+        """Enqueues launches first .. first+count-1 (default: all)."""
+        count = self.k - first if count is None else count
+        if count <= 0:
+            return
+        if first < 0 or first + count > self.k:
+            raise IndexError("batch range outside the prepared list")
+        off = first * ctypes.sizeof(ctypes.c_void_p)
+        rc = self.lib.sympa_model_forward_batches(
+            self.keep[0].data_ptr(), self.num_rows, self.n, ctypes.addressof(self.trip) + off, self.stride,
+            ctypes.addressof(self.b) + off, count, self.args[0], self.args[1], self.args[2], self.args[3],
+            self.args[4], self.args[5], ctypes.addressof(self.out) + off, self.status.data_ptr(), self.flags,
+            self.stream_arr, len(self.streams))
+        if rc != 0:
+            _lib.check(rc)
+        if _debug:
+            check_status(self.dev)
+
 
 def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None):
     """Backward of manifold.dist for pre-gathered points (C-ABI sympa_siegel_dist_bwd).

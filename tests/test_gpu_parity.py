@@ -283,3 +283,101 @@ def test_triangle_inequality_of_the_true_metrics(dev, model, n):
         ops.check_status(dev)
         assert torch.all(dxz <= (dxy + dyz) * (1 + 1e-12)), (model, n, metric)
         assert torch.all(dxz > 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 10, 16])
+@pytest.mark.parametrize("model", MODELS)
+def test_nonfinite_input_gives_nan_and_status(dev, model, n):
+    """NaN / Inf in a point: NaN out + ST_NONFINITE (reference: NaN eigenvalues fail the assert,
+    siegel_manifold.py:64-66) -- not a distance of 0 through the eigenvalue clamp or a max / min metric."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(2000 + n)
+    b = 130
+    for bad in (float("nan"), float("inf")):
+        for plane in (0, 1):
+            z1, z2 = points(model, b, n, 0.3, g), points(model, b, n, 0.3, g)
+            rows = [3, 64, 129]
+            for k, r in enumerate(rows):
+                tgt = z1 if k % 2 == 0 else z2
+                i, j = (0, n - 1) if k < 2 else (n - 1, n - 1)
+                tgt[r, plane, i, j] = bad
+                tgt[r, plane, j, i] = bad
+            for metric in METRICS:
+                w = torch.linspace(0.2, 1.2, n).to(dev)
+                out = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), model, metric, w).cpu()
+                good = torch.ones(b, dtype=torch.bool)
+                good[rows] = False
+                assert torch.isnan(out[rows]).all(), (model, n, bad, plane, metric, out[rows])
+                assert torch.isfinite(out[good]).all()
+                with pytest.raises(AssertionError):
+                    ops.check_status(dev)
+    # through the fused gather too: a table row with a NaN real part (what rsgd leaves behind a NaN gradient)
+    table = points(model, 50, n, 0.3, g)
+    table[7, 0] = float("nan")
+    trip = torch.tensor([[7, 1], [2, 7], [3, 4]])
+    out = ops.model_forward(table.to(dev), trip.to(dev), model, "riem").cpu()
+    assert torch.isnan(out[0]) and torch.isnan(out[1]) and torch.isfinite(out[2])
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("model", MODELS)
+def test_low_lds_gather_variants_bit_identical(dev, model, n):
+    """The minimum-LDS gather forms (SYMPA_FLAG_LOW_LDS: PASS4 at n = 4, one endpoint at a time at n = 2; chosen
+    automatically for grids deeper than two blocks per CU, and by bench.py's overlapped launches) run the same
+    arithmetic on the same rows: outputs must be bit-identical to the default form."""
+    from sympa_amd import data, ops
+    N = 777
+    table = data.trained_like_table(N, n, model=model, seed=11).to(dev)
+    for b in (1, 63, 1000, 65536 + 37, 131072 + 4097):          # ragged; > 131 072 selects the low form by itself
+        trip = data.sample_pairs(N, b, 3, 5).to(dev)
+        base = ops.model_forward(table, trip, model, "riem", flags=0)
+        low = ops.model_forward(table, trip, model, "riem", flags=ops.FLAG_LOW_LDS)
+        ops.check_status(dev)
+        assert torch.equal(low, base), (model, n, b)
+        if b <= 1000:
+            want = so.model_forward(table.cpu(), trip.cpu(), model, "riem")
+            assert rel_err(low.cpu(), want) < TOL
+        else:
+            # explicit gather + pre-gathered entry (no index path at all) on a slice
+            sl = slice(b - 5000, b)
+            two = ops.siegel_dist_forward(table[trip[sl, 0]], table[trip[sl, 1]], model, "riem", flags=0)
+            assert torch.equal(low[sl], two)
+    # all-pairs matrix with N >= 363 rows (deep grid -> low form) against the pairwise kernel in its default form
+    N2 = 400
+    t2 = table[:N2].contiguous()
+    mat = ops.all_pairs_dist(t2, model, "riem")
+    ii, jj = torch.meshgrid(torch.arange(N2, device=dev), torch.arange(N2, device=dev), indexing="ij")
+    trip = torch.stack((ii.reshape(-1), jj.reshape(-1)), 1)
+    chunks = [ops.model_forward(t2, trip[k:k + 60000].contiguous(), model, "riem", flags=0)
+              for k in range(0, N2 * N2, 60000)]
+    assert torch.equal(mat.reshape(-1), torch.cat(chunks))
+
+
+def test_batched_forward_equals_single_calls(dev):
+    """C-ABI sympa_model_forward_batches (the loop of Runner.evaluate, runner.py:126-137, in one call, launches
+    alternating over streams) == one sympa_model_forward per batch, bit for bit; ragged batch sizes."""
+    from sympa_amd import data, ops
+    N, n = 500, 4
+    table = data.trained_like_table(N, n, seed=3).to(dev)
+    scale = torch.tensor([0.7], device=dev)
+    sizes = [1, 300, 65536, 4099, 256, 70000]
+    batches = [data.sample_pairs(N, b, k, 9).to(dev) for k, b in enumerate(sizes)]
+    outs = [torch.zeros(b, dtype=torch.float64, device=dev) for b in sizes]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    for fl in (0, ops.FLAG_LOW_LDS, ops.FLAG_LOW_LDS | ops.FLAG_ANY_ORDER):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        bf = ops.BatchedForward(table, batches, outs, "upper", "fone", None, scale, 2.0, flags=fl, streams=streams)
+        bf.run()
+        torch.cuda.synchronize()
+        ops.check_status(dev)
+        for t, o in zip(batches, outs):
+            assert torch.equal(o, ops.model_forward(table, t, "upper", "fone", None, scale, 2.0))
+    bf.run(2, 2)          # a sub-range
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        bf.run(5, 2)

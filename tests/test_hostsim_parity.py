@@ -79,3 +79,36 @@ def test_generic_runtime_n_fallback(model, n):
         if n <= 8:
             out2, _, _ = hostsim_dist(z1.numpy(), z2.numpy(), model, metric, w.numpy())
             assert rel_err(out, out2) < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_nonfinite_input_gives_nan_and_status(model, n):
+    """A NaN / Inf anywhere in a point must come out as NaN with ST_NONFINITE, for every metric (the reference
+    produces NaN and fails `assert torch.all(eigvalues >= 0 - eps)`, siegel_manifold.py:64-66) -- never as a
+    distance of 0 through the clamp of the eigenvalues at 0 or through a max / min reduction."""
+    g = torch.Generator().manual_seed(300 + n)
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        for plane in (0, 1):
+            for which in (0, 1):
+                for (i, j) in {(0, 0), (0, n - 1), (n - 1, n - 1)}:
+                    z = [points(model, 1, n, 0.3, g), points(model, 1, n, 0.3, g)]
+                    z[which][0, plane, i, j] = bad
+                    z[which][0, plane, j, i] = bad
+                    for metric in METRICS:
+                        for generic in (False, True):
+                            out, vvd, st = hostsim_dist(z[0].numpy(), z[1].numpy(), model, metric, generic=generic)
+                            assert np.isnan(out[0]), (model, n, bad, plane, which, (i, j), metric, generic, out)
+                            assert st & 2, (model, n, bad, plane, which, (i, j), metric, generic, st)
+                            assert np.all(np.isnan(vvd))
+
+
+@pytest.mark.parametrize("n", [11, 16])
+def test_nonfinite_input_generic_large_n(n):
+    g = torch.Generator().manual_seed(400 + n)
+    for model in MODELS:
+        z1, z2 = points(model, 1, n, 0.2, g), points(model, 1, n, 0.2, g)
+        z2[0, 0, 2, 5] = float("nan")
+        for metric in ("riem", "finf", "fmin"):
+            out, _, st = hostsim_dist(z1.numpy(), z2.numpy(), model, metric, generic=True)
+            assert np.isnan(out[0]) and (st & 2)
