@@ -137,9 +137,14 @@ def main():
                          "streams, so that independent steps (different batches, different outputs) overlap on the "
                          "GPU: the next steps gather while the previous ones compute (minimum-LDS kernel form, three "
                          "blocks per CU); 1 = strictly sequential launches; 0 = 4 (8 when a step is < 1 wave per SIMD)")
-    ap.add_argument("--launch", default="graph", choices=["graph", "direct"],
-                    help="graph: the steps are replayed from captured hipGraphs whose nodes are the launches "
-                         "(one node = one step); direct: one Python->C-ABI call per step")
+    ap.add_argument("--launch", default="fused", choices=["fused", "graph", "direct"],
+                    help="fused (default; Siegel models with dims <= 8): the K steps go through ONE C call "
+                         "(sympa_model_forward_batches, SYMPA_FLAG_FUSE) that evaluates up to --steps-per-launch "
+                         "consecutive steps per kernel launch -- a 65 536-pair batch is exactly one wave per SIMD, so the "
+                         "steps only fill the machine when several are in flight; graph: one kernel launch per step, "
+                         "replayed from captured hipGraphs over --streams parallel streams; direct: one "
+                         "Python->C-ABI call and one launch per step")
+    ap.add_argument("--steps-per-launch", type=int, default=32, help="fused launch only (<= 32)")
     args = ap.parse_args()
 
     import torch
@@ -190,8 +195,11 @@ def main():
         batches.append(glob[rank::world].contiguous().to(dev))
     my_pairs = batches[0].shape[0]
     outs = [torch.empty(my_pairs, dtype=torch.float64, device=dev) for _ in range(nb)]
-    if args.launch == "direct":
+    if args.launch == "fused" and (model == "spd" or n > 8):
+        args.launch = "graph"          # no fused kernel for the sixteen-lanes-per-pair models
+    if args.launch in ("direct", "fused"):
         args.streams = 1
+    spl = max(1, min(args.steps_per_launch, ops.MAX_FUSED_BATCHES))
     if args.streams <= 0:
         # a launch of < 1 wave per SIMD (65 536 pairs) leaves SIMDs idle: more launches in flight
         args.streams = 4 if my_pairs >= 65536 else 8
@@ -247,7 +255,44 @@ def main():
         for rem in sorted({args.steps % gn, args.warmup % gn} - {0, gn}, reverse=True):
             graphs.append((rem, capture(rem)))
 
+    fused = None
+    if args.launch == "fused":
+        for i in range(nb):
+            step(i)            # warm (allocates the status word)
+        torch.cuda.synchronize(dev)
+
+        class Fused:
+            """K steps = ceil(K / spl) launches of up to spl consecutive steps each, enqueued by one C call per
+            group of launches (step i reads batches[i % nb], writes outs[i % nb])."""
+            def __init__(self, dst):
+                self.plans = {}
+                self.dst = dst
+
+            def plan(self, k):
+                if k not in self.plans:
+                    self.plans[k] = ops.BatchedForward(table, [batches[i % nb] for i in range(k)],
+                                                       [self.dst[i % nb] for i in range(k)], model, metric, None,
+                                                       scale, 1.0, flags=ops.FLAG_FUSE,
+                                                       streams=[torch.cuda.current_stream(dev)])
+                return self.plans[k]
+
+            def run(self, k):
+                p = self.plan(k)
+                if spl == ops.MAX_FUSED_BATCHES:
+                    p.run()                       # the C entry cuts the list into launches of 32 steps itself
+                else:
+                    for i0 in range(0, k, spl):
+                        p.run(i0, min(spl, k - i0))
+
+        fused = Fused(outs)
+        for k_ in {args.steps, args.warmup, args.steps if args.steps <= 4 * spl else 4 * spl} - {0}:
+            fused.plan(k_)
+
     def run_steps(k):
+        if fused is not None:
+            if k > 0:
+                fused.run(k)
+            return
         done = 0
         for nodes_, g_ in graphs:
             while k - done >= nodes_ and (nodes_ == gn or k - done == nodes_):
@@ -267,6 +312,8 @@ def main():
     while time.perf_counter() - t_pre < prewarm_s:
         if pre_graph is not None:
             pre_graph.replay()
+        elif fused is not None:
+            run_steps(args.steps if args.steps <= 4 * spl else 4 * spl)     # launches of the timed region's shape
         else:
             run_steps(max(gn, nb))
         torch.cuda.synchronize(dev)
@@ -276,8 +323,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0      # this rank's K steps; the MAX over ranks is taken below
+    sync_all()                              # closing barrier + synchronize (N > 1: an RCCL all-reduce of ~30 us -- the
+    #                                         clock is read before it, the slowest rank still sets the reported time)
     # the same K steps once more, untimed by the wall clock, bracketed by HIP events on the launch stream: what the GPU
     # side of such a region takes (recording events INSIDE the wall-timed region costs it ~70 us of host time)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -312,14 +361,7 @@ def main():
     # `rocprofv3 --kernel-trace --stats` reports per kernel (the profiler serialises a queue's dispatches).
     per_group = max(1, min(args.graph_nodes, max(args.steps, 64)))
 
-    def kernel_time(fl):
-        if args.launch == "graph":
-            g_ = capture(per_group, streams=1, fl=fl)
-            run_group = g_.replay
-        else:
-            def run_group():
-                for i in range(per_group):
-                    step(i, fl)
+    def timed_groups(run_group, launches_per_group):
         for _ in range(2):
             run_group()
         torch.cuda.synchronize(dev)
@@ -330,13 +372,33 @@ def main():
             run_group()
             b.record()
         torch.cuda.synchronize(dev)
-        ms = sorted(a.elapsed_time(b) / per_group for a, b in ev)
+        ms = sorted(a.elapsed_time(b) / launches_per_group for a, b in ev)
         return sum(ms) / len(ms), ms[len(ms) // 2]
 
-    timed_kernel = kernel_name(model, n, flags & ops.FLAG_LOW_LDS)
+    def kernel_time(fl):
+        """Average duration of ONE single-step launch with gather flags `fl`, launches strictly sequential."""
+        if args.launch == "direct":
+            def run_group():
+                for i in range(per_group):
+                    step(i, fl)
+        else:
+            run_group = capture(per_group, streams=1, fl=fl).replay
+        return timed_groups(run_group, per_group)
+
     default_kernel = kernel_name(model, n, 0)
-    k_timed = kernel_time(flags)
-    k_default = k_timed if default_kernel == timed_kernel else kernel_time(0)
+    if fused is not None:
+        # the timed region's kernel: launches of spl steps (the last one of what is left), strictly sequential on the
+        # launch stream -- its average duration IS the event-bracketed repetition of the timed region over its launches
+        n_launches = (args.steps + spl - 1) // spl
+        timed_kernel = f"siegel_dist_multi_kernel<{n}, {MODEL_ID[model]}>"
+        k_timed = (device_ms / n_launches, device_ms / n_launches)
+        timed_pairs_per_launch = my_pairs * args.steps / n_launches
+        k_default = kernel_time(0)
+    else:
+        timed_kernel = kernel_name(model, n, flags & ops.FLAG_LOW_LDS)
+        k_timed = kernel_time(flags)
+        timed_pairs_per_launch = my_pairs
+        k_default = k_timed if default_kernel == timed_kernel else kernel_time(0)
 
     if rank == 0:
         pairs_total = global_pairs * args.steps
@@ -353,19 +415,23 @@ def main():
         valu_per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] if c.get("SQ_WAVES") else None
         # PMC counters cannot be read from inside the run (rocprofv3 wraps the process): `traffic` is the figure of the
         # committed counter pass of THIS command line (tools/pmc_collect.sh, one counter group per run) and says so
-        traffic = pmc.get("hbm_bytes_per_launch") if my_pairs == WORKLOADS[args.workload][4] else None
+        # (stored per step = per 65 536-pair batch; a fused launch moves that times its steps)
+        traffic = pmc.get("hbm_bytes_per_step", pmc.get("hbm_bytes_per_launch")) \
+            if my_pairs == WORKLOADS[args.workload][4] else None
 
-        def roof(kname, kt, note):
+        def roof(kname, kt, pairs_per_launch, note):
             avg_ms, med_ms = kt
-            ach = bpp * my_pairs / (avg_ms * 1e-3) / 1e9
+            ach = bpp * pairs_per_launch / (avg_ms * 1e-3) / 1e9
+            tr = traffic * (pairs_per_launch / my_pairs) if traffic else None
             return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic,
+                    "traffic": tr,
                     "traffic_source": (f"profiles/pmc_latest.json [{pmc.get('round', '?')}]: {pmc.get('source', '')}; "
                                        "2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of 16 B/lane reads, "
-                                       "MI355X_MICROARCH.md HBM section); not measured in this run") if traffic else None,
+                                       "MI355X_MICROARCH.md HBM section), per single-step launch x steps per launch; "
+                                       "a committed counter pass, not measured in this run") if tr else None,
                     "kernel": kname, "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
-                    "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": my_pairs,
-                    "pairs_per_s_kernel_only": my_pairs / (avg_ms * 1e-3),
+                    "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": pairs_per_launch,
+                    "pairs_per_s_kernel_only": pairs_per_launch / (avg_ms * 1e-3),
                     "frac_of_measured_copy_bw": ach / MEASURED_COPY_GBS,
                     "mode": note}
 
@@ -385,21 +451,26 @@ def main():
                        "global_pairs_per_step": global_pairs, "table": args.table, "launch": args.launch,
                        "streams": args.streams,
                        "parallelism": f"pairs sharded rank::{world}, table replicated, no collective"},
-            # the kernel instantiation the timed region ran, timed alone (sequential launches: what rocprofv3 reports)
-            "roofline": roof(timed_kernel, k_timed,
-                             "the timed region's kernel instantiation, launched strictly sequentially on one stream "
-                             "(HIP events; rocprof-comparable). The contract roof is HBM (SURVEY 8d: algorithmic "
-                             "bytes, no reuse credit); the table is cache-resident and the kernel is bound by fp64 "
-                             "VALU issue and L2->LDS gather latency (valu_issue_fraction, DESIGN.md section 5)"),
-            # whole-job throughput of the timed region expressed against the same roof (steps overlap on
-            # --streams streams, so this exceeds roofline.frac, which is a per-kernel figure)
+            # the kernel the timed region ran, its launches strictly sequential (what rocprofv3 --kernel-trace reports)
+            "roofline": roof(timed_kernel, k_timed, timed_pairs_per_launch,
+                             ("the timed region's kernel: one launch evaluates up to %d consecutive steps (batches); duration = "
+                              "HIP-event time of an identical repetition of the timed region / its %d launch(es), launch "
+                              "latency included; " % (spl, (args.steps + spl - 1) // spl)
+                              if fused is not None else "the timed region's kernel instantiation, one step per launch, "
+                              "launches strictly sequential on one stream, HIP events per group; ")
+                             + "rocprof-comparable. CONTRACT roof (SURVEY 8d): algorithmic bytes (536 B/pair at n = 4, no "
+                             "reuse credit) against the 8 TB/s HBM peak -- the table is cache-resident (`traffic` is what "
+                             "actually reaches the fabric), so this fraction can approach or exceed 1; the physical "
+                             "limiter is fp64 VALU issue: see valu_issue_fraction and DESIGN.md section 5"),
+            # whole-job throughput of the timed region expressed against the same roof
             "throughput_frac_of_hbm_roof": (value / world) * bpp / (HBM_PEAK_GBS * 1e9),
         }
+        rec["config"]["steps_per_launch"] = min(spl, args.steps) if fused is not None else 1
         if default_kernel != timed_kernel:
             rec["roofline_default_kernel"] = roof(
-                default_kernel, k_default,
-                "the kernel a single Model.forward call runs (both endpoints staged at once, one block per CU), "
-                "launched strictly sequentially on one stream")
+                default_kernel, k_default, my_pairs,
+                "the kernel ONE Model.forward call runs (one step per launch, both endpoints staged at once, one block "
+                "per CU: a 65 536-pair batch is one wave per SIMD), launches strictly sequential on one stream")
         # SURVEY 8d's "honest second roof": the fp64 VALU issue slots the whole job occupies (VALU instructions per
         # wave from the committed PMC pass; one wave = 64 pairs; a wave instruction occupies its SIMD for 4 cycles;
         # 1024 SIMDs at the 2.4 GHz peak clock)

@@ -59,6 +59,10 @@ extern "C" {
                                   launches that do not depend on earlier work of that stream (independent batches);
                                   a later ordinary launch or synchronisation still waits for all of them */
 
+#define SYMPA_FLAG_FUSE 8 /* sympa_model_forward_batches only (dims <= SYMPA_MAX_DIMS): up to SYMPA_MAX_FUSED_BATCHES
+                             consecutive batches per kernel launch instead of one launch per batch */
+#define SYMPA_MAX_FUSED_BATCHES 32
+
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] run sixteen lanes per pair
@@ -104,7 +108,12 @@ int sympa_model_forward(const double* table, int64_t num_rows, int n, const int6
  * `out` and `streams` are HOST arrays (of device pointers / sizes / hipStream_t).  Launch i goes to
  * streams[i % num_streams]: the batches are independent, so consecutive launches overlap on the GPU (the next batch
  * gathers its rows while the previous one computes) -- with SYMPA_FLAG_LOW_LDS three blocks of different launches share
- * a CU.  One kernel launch per batch, exactly as num_batches calls of sympa_model_forward; nothing is synchronised. */
+ * a CU.  One kernel launch per batch, exactly as num_batches calls of sympa_model_forward; nothing is synchronised.
+ * With SYMPA_FLAG_FUSE (dims <= SYMPA_MAX_DIMS) groups of up to SYMPA_MAX_FUSED_BATCHES consecutive batches are
+ * evaluated by ONE launch each (group g on streams[g % num_streams]): the grid is several blocks per CU deep, so
+ * the batches overlap inside the launch with no kernel boundary between them -- the form to use when a batch is
+ * about one wave per SIMD or less (65 536 pairs fill the 1 024 SIMDs of an MI355X exactly once).  Same results,
+ * bit for bit. */
 int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, const int64_t* const* triplets,
                                 int64_t stride, const int64_t* b, int num_batches, int model, int metric,
                                 const double* metric_w, double eps, const double* scale, double scale_coef,

@@ -39,16 +39,22 @@ int validate(const DistArgs& a, int model) {
 namespace {
 using namespace sympa_hip;
 
+// Body of one 256-thread block: pairs [first, first + 256) of the batch described by `a`.
 // EXPERIMENT: a spare instantiation selected by flags bit 0x100 for in-process A/B timing (tools/ab_bench.py);
 // identical to the product kernel unless a variant is being measured.
-template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
-__global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
-    constexpr bool PASS4 = (N == 4) && LOWLDS;   // minimum-LDS gather: three blocks of different launches per CU
-    constexpr int WAVE_SLOTS = PASS4 ? PASS4_WAVE_SLOTS
-                               : DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
-                               : (PassTile<N>::ENABLED ? PassTile<N>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
-    __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+template <int N, int MODEL, bool LOWLDS>
+struct BlockLds {
+    static constexpr bool PASS4 = (N == 4) && LOWLDS;   // minimum-LDS gather: three blocks of different launches per CU
+    static constexpr int WAVE_SLOTS = PASS4 ? PASS4_WAVE_SLOTS
+                                      : DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
+                                      : (PassTile<N>::ENABLED ? PassTile<N>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
+};
+
+template <int N, int MODEL, bool LOWLDS>
+__device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t first, v2d* __restrict__ lds) {
+    constexpr bool PASS4 = BlockLds<N, MODEL, LOWLDS>::PASS4;
+    constexpr int WAVE_SLOTS = BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS;
+    const int64_t i = first + threadIdx.x;
     const bool live = i < a.b;
     const int64_t ii = live ? i : a.b - 1;   // idle tail lanes recompute the last pair (wave ballots need them)
 
@@ -103,6 +109,50 @@ __global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
             if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
         }
     }
+}
+
+template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
+__global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
+    __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
+    dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * BLOCK, lds);
+}
+
+// Several batches in ONE launch (C-ABI sympa_model_forward_batches with SYMPA_FLAG_FUSE): block x belongs to the
+// batch k with blk_end[k-1] <= x < blk_end[k]; the batches share table, metric and scale and differ in their index
+// list, size and output.  The grid is several blocks per CU deep, so the minimum-LDS gather form is used: three
+// blocks of different batches share a CU and one batch's gather hides behind another's arithmetic -- what
+// overlapping the launches on streams achieves, without kernel boundaries, fork/join dependencies or idle SIMDs
+// when a batch is smaller than one wave per SIMD.
+struct MultiArgs {
+    DistArgs c;                                    // idx1/idx2/out/b are taken from the lists below
+    const int64_t* trip[SYMPA_MAX_FUSED_BATCHES];
+    double* out[SYMPA_MAX_FUSED_BATCHES];
+    int64_t b[SYMPA_MAX_FUSED_BATCHES];
+    unsigned blk_end[SYMPA_MAX_FUSED_BATCHES];     // exclusive prefix end, in blocks
+    int num_batches;
+};
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void siegel_dist_multi_kernel(const MultiArgs m) {
+    constexpr bool LOW = DmaTile<N>::ENABLED;
+    __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOW>::WAVE_SLOTS];
+    // batch of this block: binary search over <= 32 prefix ends (block-uniform, scalar)
+    int lo = 0, hi = m.num_batches - 1;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int mid = (lo + hi) >> 1;
+        const bool right = blockIdx.x >= m.blk_end[mid];
+        lo = right ? mid + 1 : lo;
+        hi = right ? hi : mid;
+    }
+    const int k = lo;
+    const unsigned blk0 = (k == 0) ? 0u : m.blk_end[k - 1];
+    DistArgs a = m.c;
+    a.idx1 = m.trip[k];
+    a.idx2 = m.trip[k] + 1;
+    a.out = m.out[k];
+    a.b = m.b[k];
+    dist_block<N, MODEL, LOW>(a, (int64_t)(blockIdx.x - blk0) * BLOCK, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -213,6 +263,76 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS_GENERIC]");
 }
 
+template <int N>
+int launch_multi_n(const MultiArgs& m, unsigned grid, int model, hipStream_t s) {
+    if (model == SYMPA_MODEL_UPPER)
+        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, m);
+    else
+        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, m);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int launch_multi(const double* table, int64_t num_rows, int n, const int64_t* const* triplets, int64_t stride,
+                 const int64_t* b, int cnt, int model, int metric, const double* metric_w, double eps,
+                 const double* scale, double scale_coef, double* const* out, int32_t* status, int flags, void* stream) {
+    if (table == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
+    if (metric < SYMPA_METRIC_RIEM || metric > SYMPA_METRIC_WSUM) return fail(SYMPA_ERR_BAD_ARG, "unknown metric");
+    if (metric == SYMPA_METRIC_WSUM && metric_w == nullptr) return fail(SYMPA_ERR_BAD_ARG, "metric wsum needs metric_w");
+    if (!(eps > 0.0) || !(1.0 / eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    if (num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
+    if (n <= 4 && num_rows * 16 * n * n >= ((int64_t)1 << 32))
+        return fail(SYMPA_ERR_BAD_ARG, "tables of dims <= 4 are limited to 4 GiB (32-bit row offsets in the gather)");
+    MultiArgs m;
+    std::memset(&m, 0, sizeof(m));
+    m.c.base1 = table;
+    m.c.base2 = table;
+    m.c.idx1_stride = stride;
+    m.c.idx2_stride = stride;
+    m.c.num_rows = num_rows;
+    m.c.metric_w = metric_w;
+    m.c.scale = scale;
+    m.c.inv_scale_coef = 1.0 / scale_coef;
+    m.c.inv_eps = 1.0 / eps;
+    m.c.status = status;
+    m.c.metric = metric;
+    m.c.flags = flags;
+    uint64_t blocks = 0;
+    int k = 0;
+    for (int i = 0; i < cnt; ++i) {
+        if (b[i] < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
+        if (b[i] == 0) continue;
+        if (triplets[i] == nullptr || out[i] == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+        blocks += (uint64_t)((b[i] + BLOCK - 1) / BLOCK);
+        if (blocks > 0x7fffffffull) return fail(SYMPA_ERR_BAD_ARG, "batches too large for one launch");
+        m.trip[k] = triplets[i];
+        m.out[k] = out[i];
+        m.b[k] = b[i];
+        m.blk_end[k] = (unsigned)blocks;
+        ++k;
+    }
+    if (k == 0) return 0;
+    for (int i = k; i < SYMPA_MAX_FUSED_BATCHES; ++i) m.blk_end[i] = (unsigned)blocks;   // the search never lands there
+    m.num_batches = k;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (n) {
+        case 1: return launch_multi_n<1>(m, (unsigned)blocks, model, s);
+        case 2: return launch_multi_n<2>(m, (unsigned)blocks, model, s);
+        case 3: return launch_multi_n<3>(m, (unsigned)blocks, model, s);
+        case 4: return launch_multi_n<4>(m, (unsigned)blocks, model, s);
+        case 5: return launch_multi_n<5>(m, (unsigned)blocks, model, s);
+        case 6: return launch_multi_n<6>(m, (unsigned)blocks, model, s);
+        case 7: return launch_multi_n<7>(m, (unsigned)blocks, model, s);
+        case 8: return launch_multi_n<8>(m, (unsigned)blocks, model, s);
+        default: break;
+    }
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "fused batches need dims <= SYMPA_MAX_DIMS");
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +398,17 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
     if (num_batches > 0 && (triplets == nullptr || b == nullptr || out == nullptr))
         return fail(SYMPA_ERR_BAD_ARG, "null batch list");
     if (stride < 2) return fail(SYMPA_ERR_BAD_ARG, "triplet stride must be >= 2");
+    if ((flags & SYMPA_FLAG_FUSE) && n >= 1 && n <= SYMPA_MAX_DIMS) {
+        // groups of up to SYMPA_MAX_FUSED_BATCHES batches per launch; group g goes to streams[g % num_streams]
+        int group = 0;
+        for (int i0 = 0; i0 < num_batches; i0 += SYMPA_MAX_FUSED_BATCHES, ++group) {
+            const int cnt = num_batches - i0 < SYMPA_MAX_FUSED_BATCHES ? num_batches - i0 : SYMPA_MAX_FUSED_BATCHES;
+            const int rc = launch_multi(table, num_rows, n, triplets + i0, stride, b + i0, cnt, model, metric, metric_w,
+                                        eps, scale, scale_coef, out + i0, status, flags, streams[group % num_streams]);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
     for (int i = 0; i < num_batches; ++i) {
         const int rc = sympa_model_forward(table, num_rows, n, triplets[i], stride, triplets[i] + 1, stride, b[i], model,
                                            metric, metric_w, eps, scale, scale_coef, out[i], status, flags,

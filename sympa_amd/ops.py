@@ -85,6 +85,8 @@ def _weights(metric, weights, n, device):
 FLAG_LOW_LDS = 1
 FLAG_GENERIC = 2      # spd: force the runtime-n one-lane-per-pair kernel
 FLAG_ANY_ORDER = 4    # forward: dispatch without the in-order barrier bit (independent batches of one stream overlap)
+FLAG_FUSE = 8         # BatchedForward: up to MAX_FUSED_BATCHES consecutive batches per kernel launch
+MAX_FUSED_BATCHES = 32
 
 
 def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=None, return_vvd=False, flags=0):

@@ -381,3 +381,34 @@ def test_batched_forward_equals_single_calls(dev):
     torch.cuda.synchronize()
     with pytest.raises(IndexError):
         bf.run(5, 2)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_fused_batches_bit_identical(dev, model, n):
+    """SYMPA_FLAG_FUSE: up to 32 batches per kernel launch (block -> batch by a prefix-sum search) == one launch per
+    batch, bit for bit; ragged and empty batches, more than one group, bad index flagged in the right batch."""
+    from sympa_amd import data, ops
+    N = 300
+    table = data.trained_like_table(N, n, model=model, seed=5).to(dev)
+    scale = torch.tensor([1.3], device=dev)
+    sizes = [257, 1, 0, 4096, 255, 256, 70001 if n <= 4 else 9001] + [100 + 37 * k for k in range(30)]
+    batches = [data.sample_pairs(N, max(b, 1), k, 21)[:b].contiguous().to(dev) for k, b in enumerate(sizes)]
+    outs = [torch.full((b,), -1.0, dtype=torch.float64, device=dev) for b in sizes]
+    w = torch.linspace(0.1, 1.0, n).to(dev)
+    bf = ops.BatchedForward(table, batches, outs, model, "wsum", w, scale, 1.5, flags=ops.FLAG_FUSE)
+    assert len(sizes) > ops.MAX_FUSED_BATCHES
+    bf.run()
+    torch.cuda.synchronize()
+    ops.check_status(dev)
+    for t, o in zip(batches, outs):
+        if t.shape[0]:
+            assert torch.equal(o, ops.model_forward(table, t, model, "wsum", w, scale, 1.5))
+    # an out-of-range index in batch 4 only
+    batches[4][7, 1] = N
+    bf2 = ops.BatchedForward(table, batches[:8], outs[:8], model, "riem", None, scale, 1.5, flags=ops.FLAG_FUSE)
+    bf2.run()
+    torch.cuda.synchronize()
+    assert torch.isnan(outs[4][7]) and torch.isfinite(outs[4][:7]).all() and torch.isfinite(outs[3]).all()
+    with pytest.raises(IndexError):
+        ops.check_status(dev)

@@ -36,6 +36,13 @@ def _worker(rank, world, port, results):
         dist.all_gather(idxs, mine)
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # bench.py's max-over-ranks
+        # strong scaling (bench.py --scaling strong; the reference's semantics, train.py:105-110): the global batch
+        # keeps the single-rank size, rank r takes pairs r::world of it
+        glob_s = data.sample_pairs(nodes, batch, 5, seed=42)
+        mine_s = glob_s[rank::world].contiguous()
+        d_s = so.model_forward(table, mine_s, "upper", "riem")
+        outs_s = [torch.zeros_like(d_s) for _ in range(world)]
+        dist.all_gather(outs_s, d_s)
         # DistributedSampler semantics for a triplet list (train.py:105-110)
         shard = data.distributed_sampler_indices(1001, world, rank, epoch=3, seed=0)
         all_shards = [None] * world
@@ -50,6 +57,11 @@ def _worker(rank, world, port, results):
             results["union_equal"] = bool(torch.equal(merged_idx, glob))
             results["dist_equal"] = bool(torch.equal(merged, full))
             results["max"] = float(t.item())
+            full_s = so.model_forward(table, glob_s, "upper", "riem")
+            merged_s = torch.empty_like(full_s)
+            for r in range(world):
+                merged_s[r::world] = outs_s[r]
+            results["strong_equal"] = bool(torch.equal(merged_s, full_s)) and mine_s.shape[0] * world == batch
             flat = sorted(i for s in all_shards for i in s)
             results["sampler_cover"] = sorted(set(flat)) == list(range(1001)) and len(flat) == 1002
             results["sampler_sizes"] = [len(s) for s in all_shards]
@@ -62,7 +74,7 @@ def test_two_rank_sharding_over_gloo():
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
-    assert results["union_equal"] and results["dist_equal"]
+    assert results["union_equal"] and results["dist_equal"] and results["strong_equal"]
     assert results["max"] == 2.0
     assert results["sampler_cover"] and results["sampler_sizes"] == [501, 501]
 

@@ -1,23 +1,31 @@
 #!/bin/bash
-# One gpurun call: GPU tests, smoke, bench, rocprofv3 kernel trace + PMC passes.   usage: tools/gpu_check.sh <tag>
-TAG=${1:-r01}
+# One gpurun call: GPU tests, smoke, bench at the driver's K and at the default K, rocprofv3 kernel trace + PMC passes.
+# usage: tools/gpu_check.sh <tag> [notests]
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "$2" != "notests" ]; then
 echo "== pytest -m gpu" | tee $OUT/pytest.log
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee -a $OUT/pytest.log
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee -a $OUT/pytest.log
 echo "== smoke" | tee $OUT/smoke.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $OUT/smoke.log
-echo "== bench" | tee $OUT/bench.log
-timeout 600 python bench.py 2>&1 | tail -1 | tee $OUT/bench.json
-echo "== rocprof kernel trace (same command)"
+fi
+echo "== bench (driver's command line, then defaults)"
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_k20.err | tail -1 | tee $OUT/bench_k20.json | cut -c1-300
+timeout 600 python bench.py 2>$OUT/bench.err | tail -1 | tee $OUT/bench.json | cut -c1-300
+echo "== rocprof kernel trace (same commands)"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k20 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_k20.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline > $OUT/prof_bench.log 2>&1
-find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -3 | tee $OUT/kernel_stats_head.txt
+for d in prof_k20 prof; do find $OUT/$d -name "*kernel_stats.csv" | head -1 | xargs -r head -4; done | tee $OUT/kernel_stats_head.txt
 bash tools/pmc_collect.sh $TAG > $OUT/pmc.log 2>&1
-tail -25 $OUT/pmc.log
-echo "== secondary workloads (rocprof kernel trace of each)"
-for W in margulis-bounded-finf-n4-b65536 cartesian-upper-riem-n8-b262144 custom-spd-n16-b1048576; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --steps 64 --warmup 8 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
-  tail -1 $OUT/bench_$W.json | cut -c1-400
+tail -30 $OUT/pmc.log
+bash tools/pmc_collect.sh ${TAG}_single upper-riem-n4-b65536 "siegel_dist_kernel<4, 0, false" 65536 "--launch graph --streams 1" > $OUT/pmc_single.log 2>&1
+tail -30 $OUT/pmc_single.log
+echo "== secondary workloads (bench line, then rocprof kernel trace of each, one launch per step and sequential: clean per-kernel figures)"
+for W in margulis-bounded-finf-n4-b65536 cartesian-upper-riem-n8-b262144 custom-spd-n16-b1048576 tree-upper-riem-n4-b8192 grid-upper-riem-n2-b512; do
+  timeout 600 python bench.py --workload $W --steps 64 --warmup 8 2>$OUT/bench_$W.err | tail -1 > $OUT/bench_$W.json
+  cut -c1-300 $OUT/bench_$W.json
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --steps 64 --warmup 8 --launch graph --streams 1 > $OUT/prof_$W.log 2>&1
   find $OUT/prof_$W -name "*kernel_stats.csv" | head -1 | xargs -r head -2
 done
