@@ -161,6 +161,22 @@ int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, cons
                               double loss_scale, double* loss, double* grad_table, double* grad_w, double* grad_scale,
                               double* out, int32_t* status, int flags, void* stream);
 
+/* The same fused step with the table gradient left in per-pair form (no scatter): grad_src_rows[i] / grad_dst_rows[i]
+ * ([b, 2, n, n] each, written) are the gradient rows of table[src[i]] / table[dst[i]] contributed by pair i.  This is
+ * the message of the touched-row gradient exchange of data-parallel training (sympa_amd/distributed.py): 2 b rows per
+ * rank instead of the dense [num_rows, 2, n, n] tensor the reference's DDP all-reduces (train.py:59) -- smaller
+ * whenever 2 x global batch < num_rows.  sympa_scatter_add_rows then accumulates any list of such rows,
+ *     grad_table[idx[r * idx_stride]] += alpha * rows[r],   r in [0, count)      (alpha = 1 / world for DDP's mean),
+ * into the dense gradient the optimiser step reads (fp64 atomics; rows of 2 n^2 doubles). */
+int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n, const int64_t* src,
+                                   int64_t src_stride, const int64_t* dst, int64_t dst_stride, const double* graph_dist,
+                                   int64_t b, int model, int metric, const double* metric_w, double eps,
+                                   const double* scale, double scale_coef, double loss_scale, double* loss,
+                                   double* grad_src_rows, double* grad_dst_rows, double* grad_w, double* grad_scale,
+                                   double* out, int32_t* status, int flags, void* stream);
+int sympa_scatter_add_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int n,
+                           int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream);
+
 /* ---- optimiser-side manifold operations over table rows (one [2,n,n] point per row) --------------------
  * egrad2rgrad: UpperHalfManifold.egrad2rgrad (sympa/manifolds/upper_half.py:25-40, Y G Y on both planes) /
  *              BoundedDomainManifold.egrad2rgrad (sympa/manifolds/bounded_domain.py:41-53, A G A, A = I - conj(Z) Z).

@@ -21,6 +21,8 @@ SYMBOLS = (
     "sympa_siegel_dist_bwd",
     "sympa_model_backward",
     "sympa_model_loss_backward",
+    "sympa_model_loss_backward_rows",
+    "sympa_scatter_add_rows",
     "sympa_egrad2rgrad",
     "sympa_projx",
     "sympa_rsgd_step",
@@ -98,6 +100,16 @@ def load():
         ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int,
         ctypes.c_void_p,
     ]
+    lib.sympa_model_loss_backward_rows.restype = ctypes.c_int
+    lib.sympa_model_loss_backward_rows.argtypes = [
+        _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
+        ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p,
+        ctypes.c_int, ctypes.c_void_p,
+    ]
+    lib.sympa_scatter_add_rows.restype = ctypes.c_int
+    lib.sympa_scatter_add_rows.argtypes = [_c_double_p, _c_i64_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                           ctypes.c_int64, ctypes.c_double, _c_double_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_egrad2rgrad.restype = ctypes.c_int
     lib.sympa_egrad2rgrad.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
                                       ctypes.c_void_p]

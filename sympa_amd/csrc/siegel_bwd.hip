@@ -5,7 +5,7 @@ namespace {
 using namespace sympa_hip;
 
 int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
-    const int rc = validate(a.f, model);
+    const int rc = validate(a.f, model, n);
     if (rc != 0) return rc;
     if (a.f.b == 0) return 0;
     if ((a.go == nullptr && a.graph_dist == nullptr) || a.g1 == nullptr || a.g2 == nullptr)
@@ -119,6 +119,44 @@ int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, cons
     a.loss = loss;
     a.loss_scale = loss_scale;
     return launch_bwd(a, n, model, true, stream);
+}
+
+int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n, const int64_t* src,
+                                   int64_t src_stride, const int64_t* dst, int64_t dst_stride, const double* graph_dist,
+                                   int64_t b, int model, int metric, const double* metric_w, double eps,
+                                   const double* scale, double scale_coef, double loss_scale, double* loss,
+                                   double* grad_src_rows, double* grad_dst_rows, double* grad_w, double* grad_scale,
+                                   double* out, int32_t* status, int flags, void* stream) {
+    if (b > 0 && (src == nullptr || dst == nullptr || graph_dist == nullptr))
+        return fail(SYMPA_ERR_BAD_ARG, "null index / graph-distance buffer");
+    if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    BwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.f.base1 = table;
+    a.f.base2 = table;
+    a.f.idx1 = src;
+    a.f.idx2 = dst;
+    a.f.idx1_stride = src_stride;
+    a.f.idx2_stride = dst_stride;
+    a.f.num_rows = num_rows;
+    a.f.b = b;
+    a.f.metric_w = metric_w;
+    a.f.scale = scale;
+    a.f.inv_scale_coef = 1.0 / scale_coef;
+    a.f.inv_eps = 1.0 / eps;
+    a.f.out = out;
+    a.f.status = status;
+    a.f.metric = metric;
+    a.f.flags = flags;
+    a.g1 = grad_src_rows;
+    a.g2 = grad_dst_rows;
+    a.gw = grad_w;
+    a.gscale = grad_scale;
+    a.graph_dist = graph_dist;
+    a.loss = loss;
+    a.loss_scale = loss_scale;
+    return launch_bwd(a, n, model, false, stream);
 }
 
 }  // extern "C"

@@ -176,14 +176,15 @@ __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArg
             scatter_add_rows<N>(g2, (int)r2, a.g2, dtile, live && !bad);
         }
     } else if (live) {
+        // per-pair rows (a pair with an out-of-range index contributes zeros, like the scatter form skips it)
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
             for (int c = 0; c < N; ++c) {
-                a.g1[i * ROW + r * N + c] = g1.re[r][c];
-                a.g1[i * ROW + N * N + r * N + c] = g1.im[r][c];
-                a.g2[i * ROW + r * N + c] = g2.re[r][c];
-                a.g2[i * ROW + N * N + r * N + c] = g2.im[r][c];
+                a.g1[i * ROW + r * N + c] = bad ? 0.0 : g1.re[r][c];
+                a.g1[i * ROW + N * N + r * N + c] = bad ? 0.0 : g1.im[r][c];
+                a.g2[i * ROW + r * N + c] = bad ? 0.0 : g2.re[r][c];
+                a.g2[i * ROW + N * N + r * N + c] = bad ? 0.0 : g2.im[r][c];
             }
     }
     // reductions over the wave, one atomic per wave

@@ -39,7 +39,7 @@ struct DistArgs {
 // thread-local message behind sympa_last_error()
 char* last_error_buffer();
 int fail(int code, const char* msg);
-int validate(const DistArgs& a, int model);
+int validate(const DistArgs& a, int model, int n);
 
 // siegel_coop.hip: 9 <= n <= 16, sixteen lanes per pair
 int launch_siegel_coop(const DistArgs& a, int n, int model, hipStream_t s);

@@ -19,7 +19,7 @@ int fail(int code, const char* msg) {
     return code;
 }
 
-int validate(const DistArgs& a, int model) {
+int validate(const DistArgs& a, int model, int n) {
     if (a.b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (a.base1 == nullptr || a.base2 == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
     if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
@@ -29,8 +29,10 @@ int validate(const DistArgs& a, int model) {
     if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
-    if (a.num_rows * 256 >= ((int64_t)1 << 32))   // conservative for every dims <= 4
-        return fail(SYMPA_ERR_BAD_ARG, "tables are limited to 2^24 rows (32-bit row offsets in the gather)");
+    // only the LDS-DMA / staged gathers of dims <= 4 address rows with 32-bit byte offsets
+    if (n <= 4 && a.num_rows * 16 * n * n >= ((int64_t)1 << 32))
+        return fail(SYMPA_ERR_BAD_ARG, "dims <= 4: the table (or the batch of pre-gathered points) is limited to 4 GiB "
+                                       "per launch (32-bit row offsets in the gather); split the call");
     return 0;
 }
 

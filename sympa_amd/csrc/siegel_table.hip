@@ -71,6 +71,26 @@ __global__ __launch_bounds__(BLOCK) void table_update_kernel(double* z, const do
     }
 }
 
+// grad[idx[r]] += alpha * rows[r] for `count` rows of `rowd` doubles: consecutive lanes take consecutive doubles of a
+// row, so one atomic wave-instruction covers 512 contiguous bytes of ONE gradient row (the shape the fp64 atomics run
+// at rate with, profiles/r01_atomic_scope.txt); rows with an index outside [0, num_rows) are skipped and flagged.
+__global__ __launch_bounds__(BLOCK) void scatter_add_rows_kernel(const double* __restrict__ rows, const int64_t* __restrict__ idx,
+                                                                 int64_t idx_stride, int64_t count, int rowd, int64_t num_rows,
+                                                                 double alpha, double* __restrict__ grad, int32_t* status) {
+    const int64_t total = count * rowd;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = t / rowd;
+        const int e = (int)(t - r * rowd);
+        const int64_t row = idx[r * idx_stride];
+        if (row < 0 || row >= num_rows) {
+            if (e == 0 && status != nullptr) { atomicOr(&status[0], sympa::ST_BAD_INDEX); atomicAdd(&status[1], 1); }
+            continue;
+        }
+        const double v = rows[t] * alpha;
+        if (v != 0.0) atomicAdd(grad + row * rowd + e, v);
+    }
+}
+
 template <int N>
 int launch_table(int op, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
                  double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm) {
@@ -145,6 +165,22 @@ int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream
     const int64_t want = (count + BLOCK - 1) / BLOCK;
     const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
     hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x, count, acc);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int sympa_scatter_add_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int n,
+                           int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream) {
+    if (count < 0 || n < 1 || n > SYMPA_MAX_DIMS_GENERIC) return fail(SYMPA_ERR_BAD_ARG, "bad row count / dims");
+    if (count == 0) return 0;
+    if (rows == nullptr || idx == nullptr || grad_table == nullptr || num_rows <= 0)
+        return fail(SYMPA_ERR_BAD_ARG, "null buffer / empty table");
+    const int rowd = 2 * n * n;
+    const int64_t want = (count * rowd + BLOCK - 1) / BLOCK;
+    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows, idx,
+                       idx_stride, count, rowd, num_rows, alpha, grad_table, status);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

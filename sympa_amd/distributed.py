@@ -9,7 +9,11 @@ with this package (the autograd Functions return ordinary dense gradients).  The
 the equivalent exchange explicitly: all gradients are packed into ONE flat fp64 buffer and reduced with a
 single RCCL all-reduce over xGMI (backend "nccl" on ROCm; "gloo" on CPU for the tests) -- one large
 message instead of DDP's 25 MB buckets, which is what the point-to-point xGMI links prefer -- then
-averaged like DDP does (the reference pre-multiplies lr by n_procs, train.py:136)."""
+averaged like DDP does (the reference pre-multiplies lr by n_procs, train.py:136).
+
+`GradientExchange` is the persistent-buffer form used by the training harness: gradients are views of one flat
+buffer (no per-step `torch.cat`), and for graphs with more nodes than 2 x the global batch the table gradient
+travels as touched rows instead of the dense tensor.  `allreduce_gradients` is kept as the one-shot helper."""
 import torch
 import torch.distributed as dist
 
@@ -35,6 +39,125 @@ def allreduce_gradients(params, average=True, group=None):
         n = p.grad.numel()
         p.grad.copy_(flat[off:off + n].reshape(p.grad.shape).to(p.grad.dtype))
         off += n
+
+
+class GradientExchange:
+    """Gradient exchange of data-parallel training with persistent buffers (nothing is allocated or concatenated per
+    step, so the step stays stream-ordered and capturable).
+
+    * every gradient lives in ONE flat fp64 buffer allocated here, `p.grad` of each parameter is a view into it;
+      `allreduce()` is a single in-place collective on that buffer followed by the 1 / world of DDP's mean;
+    * mode "rows" (touched-row exchange): the table gradient does not travel as the dense
+      [N, 2, n, n] tensor the reference's DDP all-reduces (train.py:59) but as the 2 b per-pair gradient rows of each
+      rank (C-ABI sympa_model_loss_backward_rows) plus their row indices: one all-gather of [2b, 2n^2] rows and one of
+      [2b] int64 indices, then every rank scatter-adds all world x 2b rows into its (zeroed) dense gradient
+      (sympa_scatter_add_rows, alpha = 1 / world).  Message per step: 2 B 16 n^2 bytes over all ranks (B = global
+      batch) instead of N 16 n^2 per rank -- "auto" picks it when that is smaller, i.e. 2 B < N (large graphs with the
+      reference's default batch sizes); for BASELINE's configs 2 B > N and the dense all-reduce is the smaller message.
+    The small parameters (model scale, wsum weights) always go through the flat all-reduce."""
+
+    def __init__(self, params, table=None, local_batch=0, mode="auto", group=None, scatter_fn=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.table = table
+        if table is not None and not any(p is table for p in self.params):
+            raise ValueError("`table` must be one of the parameters")
+        n_rows = table.shape[0] if table is not None else 0
+        if mode == "auto":
+            mode = "rows" if (table is not None and local_batch > 0 and 2 * local_batch * self.world < n_rows) else "dense"
+        if mode not in ("dense", "rows"):
+            raise ValueError(mode)
+        if mode == "rows" and (table is None or local_batch <= 0):
+            raise ValueError("mode 'rows' needs the table parameter and the per-rank batch size")
+        self.mode = mode
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float64, device=dev)
+        off = 0
+        self._views = []
+        self._small = []           # (offset, numel) of everything but the table, for the "rows" mode
+        for p in self.params:
+            if p.dtype != torch.float64:
+                raise TypeError("parameters are float64 (reference default dtype, config.py:17-18)")
+            v = self.flat[off:off + p.numel()].view(p.shape)
+            p.grad = v
+            self._views.append(v)
+            if p is table:
+                self._table_span = (off, p.numel())
+            else:
+                self._small.append((off, p.numel()))
+            off += p.numel()
+        self.local_batch = int(local_batch)
+        if mode == "rows":
+            rowd = table[0].numel()
+            b2 = 2 * self.local_batch
+            self.rows = torch.zeros(b2, rowd, dtype=torch.float64, device=dev)
+            self.idx = torch.zeros(b2, dtype=torch.int64, device=dev)
+            self.rows_all = torch.zeros(self.world * b2, rowd, dtype=torch.float64, device=dev)
+            self.idx_all = torch.zeros(self.world * b2, dtype=torch.int64, device=dev)
+            # the small parameters share one contiguous tail/head buffer for their all-reduce
+            n_small = sum(k for _, k in self._small)
+            self.small = torch.zeros(n_small, dtype=torch.float64, device=dev) if n_small else None
+        if scatter_fn is None:
+            from sympa_amd import ops
+            scatter_fn = ops.scatter_add_rows_          # HIP kernel; raises on CPU tensors (no CPU path in the product)
+        self.scatter_fn = scatter_fn
+
+    # bytes this rank SENDS per step (ring all-reduce: 2 (G-1)/G of the buffer; all-gather: its own block to G-1 peers)
+    @property
+    def message_bytes(self):
+        g = self.world
+        if self.mode == "dense":
+            return int(2 * (g - 1) / g * self.flat.numel() * 8)
+        small = 0 if self.small is None else int(2 * (g - 1) / g * self.small.numel() * 8)
+        return (self.rows.numel() * 8 + self.idx.numel() * 8) * (g - 1) + small
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def check_views(self):
+        """The parameters' .grad must still be the views created here (zero_grad(set_to_none=True) breaks that)."""
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("a parameter's .grad no longer aliases the exchange buffer; use zero_() / "
+                                   "zero_grad(set_to_none=False)")
+
+    def allreduce(self):
+        """Dense mode: one in-place all-reduce of the flat buffer, then DDP's mean."""
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.mul_(1.0 / self.world)
+
+    def exchange_rows(self, idx_src, idx_dst):
+        """Rows mode, after the local backward has written this rank's per-pair rows into `self.rows`
+        ([0, b): rows of idx_src, [b, 2b): rows of idx_dst) and accumulated the small gradients into the flat buffer:
+        all-gather rows + indices, scatter-add everything into the dense table gradient (mean), all-reduce the rest."""
+        b = self.local_batch
+        if idx_src.shape[0] != b or idx_dst.shape[0] != b:
+            raise ValueError("rows mode exchanges full batches of the size given at construction")
+        self.idx[:b].copy_(idx_src)
+        self.idx[b:].copy_(idx_dst)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.rows_all, self.rows, group=self.group)
+            dist.all_gather_into_tensor(self.idx_all, self.idx, group=self.group)
+            rows_all, idx_all = self.rows_all, self.idx_all
+        else:
+            rows_all, idx_all = self.rows, self.idx
+        off, k = self._table_span
+        tgrad = self.flat[off:off + k].view(self.table.shape)
+        tgrad.zero_()
+        self.scatter_fn(tgrad, rows_all, idx_all, 1.0 / self.world)
+        if self.small is not None and self.world > 1:
+            o = 0
+            for so_, k_ in self._small:
+                self.small[o:o + k_].copy_(self.flat[so_:so_ + k_])
+                o += k_
+            dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
+            o = 0
+            for so_, k_ in self._small:
+                self.flat[so_:so_ + k_].copy_(self.small[o:o + k_]).mul_(1.0 / self.world)
+                o += k_
 
 
 def allreduce_scalar(t, group=None, op="sum"):

@@ -64,6 +64,31 @@ class Model(nn.Module):
                                 gs, self.scale_coef, loss_scale)
         return loss
 
+    def fused_loss_backward_rows(self, input_triplet, graph_distances, grad_rows, loss_scale=1.0):
+        """fused_loss_backward with the table gradient left as per-pair rows in `grad_rows` [2b, 2, n, n] (written;
+        rows [0, b) belong to the src ids, [b, 2b) to the dst ids) for the touched-row gradient exchange of
+        sympa_amd.distributed.GradientExchange; the scale / wsum-weight gradients accumulate into .grad as usual."""
+        from sympa_amd import ops
+        man = self.manifold
+        table = self.embeddings.embeds
+        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
+        weights = gw = None
+        if wsum:
+            weights = man.metric.weights
+            if weights.grad is None:
+                weights.grad = torch.zeros_like(weights.data)
+            gw = weights.grad
+        gs = None
+        if self.scale.requires_grad:
+            if self.scale.grad is None:
+                self.scale.grad = torch.zeros_like(self.scale.data)
+            gs = self.scale.grad
+        loss = torch.zeros(1, dtype=torch.float64, device=table.device)
+        ops.model_loss_backward_rows(table.data, input_triplet, graph_distances, grad_rows, loss, man.model_name,
+                                     man.metric.kind.value, None if weights is None else weights.data, gw,
+                                     self.scale.data, gs, self.scale_coef, loss_scale)
+        return loss
+
     def distance_matrix(self, row_begin=0, row_count=None):
         """Extension: the N x N matrix Runner.build_distance_matrix (runner.py:142-154) assembles with N
         forward calls, as one launch (or one launch per row block).  Diagonal exactly 0."""

@@ -349,6 +349,70 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
     return loss
 
 
+def model_loss_backward_rows(table, triplets, graph_dist, grad_rows, loss, model="upper", metric="riem", weights=None,
+                             grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None):
+    """The fused training step with the table gradient left per pair (C-ABI sympa_model_loss_backward_rows):
+    `grad_rows` [2b, 2, n, n] is WRITTEN -- rows [0, b) belong to triplets[:, 0], rows [b, 2b) to triplets[:, 1];
+    loss / grad_weights / grad_scale are accumulated as in model_loss_backward."""
+    lib = _lib.load()
+    tab = table if table.is_contiguous() else table.contiguous()
+    num_rows, n = tab.shape[0], tab.shape[2]
+    b = triplets.shape[0]
+    if b == 0:
+        return loss
+    _need_gpu(tab, "table"); _need_gpu(triplets, "triplets"); _need_gpu(graph_dist, "graph_dist"); _need_gpu(grad_rows, "grad_rows")
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    if grad_rows.dtype != torch.float64 or not grad_rows.is_contiguous() or grad_rows.numel() < 2 * b * 2 * n * n:
+        raise ValueError("grad_rows must be a contiguous float64 tensor of at least [2b, 2, n, n]")
+    dev = tab.device
+    gd = graph_dist if (graph_dist.dtype == torch.float64 and graph_dist.is_contiguous()) \
+        else graph_dist.to(torch.float64).contiguous()
+    w = _weights(metric, weights, n, dev) if metric == "wsum" else None
+    sc_ptr = None
+    if scale is not None:
+        sc = scale if (scale.device == dev and scale.dtype == torch.float64) else scale.detach().to(dev, torch.float64)
+        sc_ptr = sc.data_ptr()
+    eps = 1e-5 if eps is None else float(eps)
+    st = _status_buf(dev)
+    tp = triplets.data_ptr()
+    rowbytes = 2 * n * n * 8
+    with torch.cuda.device(dev):
+        rc = lib.sympa_model_loss_backward_rows(
+            tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, gd.data_ptr(), b, MODEL_IDS[model],
+            METRIC_IDS[metric], None if w is None else w.data_ptr(), eps, sc_ptr, float(scale_coef), float(loss_scale),
+            loss.data_ptr(), grad_rows.data_ptr(), grad_rows.data_ptr() + b * rowbytes,
+            None if grad_weights is None else grad_weights.data_ptr(),
+            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), 0,
+            torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _lib.check(rc)
+    if _debug:
+        check_status(dev)
+    return loss
+
+
+def scatter_add_rows_(grad_table, rows, idx, alpha=1.0):
+    """grad_table[idx[r]] += alpha * rows[r]  (C-ABI sympa_scatter_add_rows; fp64 atomics, whole contiguous rows)."""
+    lib = _lib.load()
+    _need_gpu(grad_table, "grad_table"); _need_gpu(rows, "rows"); _need_gpu(idx, "idx")
+    if grad_table.dtype != torch.float64 or rows.dtype != torch.float64 or idx.dtype != torch.int64:
+        raise TypeError("scatter_add_rows_ needs float64 rows / table and int64 indices")
+    if not (grad_table.is_contiguous() and rows.is_contiguous() and idx.dim() == 1):
+        raise ValueError("contiguous tensors and a 1-d index list expected")
+    n = grad_table.shape[-1]
+    count = idx.shape[0]
+    if rows.numel() != count * 2 * n * n:
+        raise ValueError("rows must hold one [2, n, n] gradient row per index")
+    st = _status_buf(grad_table.device)
+    with torch.cuda.device(grad_table.device):
+        rc = lib.sympa_scatter_add_rows(rows.data_ptr(), idx.data_ptr(), idx.stride(0), count, n, grad_table.shape[0],
+                                        float(alpha), grad_table.data_ptr(), st.data_ptr(), _stream())
+    _lib.check(rc)
+    return grad_table
+
+
 # ---------------------------------------------------------------------------------------------------
 # optimiser-side manifold operations over table rows (C-ABI sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step)
 # ---------------------------------------------------------------------------------------------------

@@ -225,3 +225,51 @@ def test_gpu_fused_training_step_equals_autograd_step(dev, model, metric):
     assert relmax(m2.scale.grad.cpu(), m1.scale.grad.cpu()) < 1e-10
     if metric == "wsum":
         assert relmax(m2.manifold.metric.weights.grad.cpu(), m1.manifold.metric.weights.grad.cpu()) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 6, 8])
+@pytest.mark.parametrize("model,metric", [("upper", "riem"), ("bounded", "wsum")])
+def test_gpu_rows_backward_plus_scatter_equals_dense_backward(dev, model, metric, n):
+    """sympa_model_loss_backward_rows (per-pair gradient rows, the message of the touched-row exchange) followed by
+    sympa_scatter_add_rows == sympa_model_loss_backward (in-kernel scatter), through GradientExchange at world 1."""
+    from sympa_amd import ops
+    from sympa_amd.distributed import GradientExchange
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, dims, num_points = model, n, 60
+        scale_coef, scale_init, train_scale = 1.0, 1.3, True
+    A.metric = metric
+    g = torch.Generator().manual_seed(31 + n)
+    torch.manual_seed(2)
+    m1, m2 = Model(A), Model(A)
+    pts = points(model, 60, n, 0.3, g)
+    for m in (m1, m2):
+        with torch.no_grad():
+            m.embeddings.embeds.data = pts.clone()
+            if metric == "wsum":
+                m.manifold.metric.weights.copy_(torch.linspace(-0.2, 1.1, n).reshape(m.manifold.metric.weights.shape))
+    m1, m2 = m1.to(dev), m2.to(dev)
+    b = 500
+    trip = torch.stack((torch.randint(0, 60, (b,), generator=g), torch.randint(0, 60, (b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    loss1 = m1.fused_loss_backward(trip, gd, loss_scale=0.5)
+    ex = GradientExchange(list(m2.parameters()), table=m2.embeddings.embeds, local_batch=b, mode="rows")
+    assert m2.embeddings.embeds.grad.data_ptr() >= ex.flat.data_ptr()
+    ex.zero_()
+    loss2 = m2.fused_loss_backward_rows(trip, gd, ex.rows, loss_scale=0.5)
+    ex.check_views()
+    ex.exchange_rows(trip[:, 0], trip[:, 1])
+    ops.check_status(dev)
+    assert abs(float(loss1) - float(loss2)) <= 1e-12 * abs(float(loss1))
+    assert relmax(m2.embeddings.embeds.grad.cpu(), m1.embeddings.embeds.grad.cpu()) < 1e-11
+    assert relmax(m2.scale.grad.cpu(), m1.scale.grad.cpu()) < 1e-11
+    if metric == "wsum":
+        assert relmax(m2.manifold.metric.weights.grad.cpu(), m1.manifold.metric.weights.grad.cpu()) < 1e-11
+    # a bad index in the row list is skipped and flagged
+    idx = trip[:, 0].clone()
+    idx[3] = 60
+    ops.scatter_add_rows_(torch.zeros_like(m2.embeddings.embeds.data), ex.rows[:b].contiguous(), idx)
+    with pytest.raises(IndexError):
+        ops.check_status(dev)

@@ -121,3 +121,78 @@ def test_two_rank_gradient_allreduce_equals_ddp_mean():
     results = mgr.dict()
     mp.spawn(_grad_worker, args=(world, _free_port(), results), nprocs=world, join=True)
     assert results["grad_equal"] and results["scale_zero"]
+
+
+def _exchange_worker(rank, world, port, results):
+    """GradientExchange over gloo: the dense mode (flat persistent buffer, in-place all-reduce) and the touched-row
+    mode (all-gather of per-pair rows + indices, scatter-add) both give DDP's mean gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympa_amd.distributed import GradientExchange, shard_triplets
+        nodes, n, b_glob = 300, 2, 64                      # 2 B = 128 < N = 300: the rows message is the smaller one
+        table0 = data.trained_like_table(nodes, n, seed=9)
+        g = torch.Generator().manual_seed(1)
+        trip = torch.cat((data.sample_pairs(nodes, b_glob, 0, seed=9), torch.randint(1, 6, (b_glob, 1), generator=g)), 1)
+        trip[5, 0] = trip[6, 1]                            # a node touched twice inside one shard and across shards
+        trip[7, 0] = trip[6, 1]
+        mine = shard_triplets(trip, rank, world, epoch=2, seed=0)
+        b = mine.shape[0]
+
+        def reference_mean_grad():
+            ref = torch.nn.Parameter(table0.clone())
+            sc = torch.nn.Parameter(torch.full((1,), 1.7, dtype=torch.float64))
+            total = 0.0
+            for r in range(world):
+                t = shard_triplets(trip, r, world, epoch=2, seed=0)
+                d = so.model_forward(ref, t, "upper", "riem", None, sc, 1.0)
+                total = total + so.distortion_loss(t[:, 2].to(torch.float64), d)
+            (total / world).backward()
+            return ref.grad, sc.grad
+
+        for mode in ("dense", "rows", "auto"):
+            table = torch.nn.Parameter(table0.clone())
+            scale = torch.nn.Parameter(torch.full((1,), 1.7, dtype=torch.float64))
+            ex = GradientExchange([table, scale], table=table, local_batch=b, mode=mode,
+                                  scatter_fn=lambda gt, rows, idx, alpha: gt.index_add_(0, idx, rows.view(-1, *gt.shape[1:]), alpha=alpha))
+            assert table.grad.data_ptr() == ex.flat.data_ptr()
+            ex.zero_()
+            if ex.mode == "dense":
+                d = so.model_forward(table, mine, "upper", "riem", None, scale, 1.0)
+                so.distortion_loss(mine[:, 2].to(torch.float64), d).backward()      # accumulates into the views
+                ex.check_views()
+                ex.allreduce()
+            else:
+                sc = scale.detach().clone().requires_grad_(True)
+                z1 = table.detach()[mine[:, 0]].clone().requires_grad_(True)
+                z2 = table.detach()[mine[:, 1]].clone().requires_grad_(True)
+                dd = so.manifold_dist("upper", z1, z2, "riem") * (sc / 1.0).clamp_min(0.1)
+                so.distortion_loss(mine[:, 2].to(torch.float64), dd).backward()
+                ex.rows.copy_(torch.cat((z1.grad, z2.grad), 0).reshape(2 * b, -1))
+                scale.grad.add_(sc.grad)
+                ex.exchange_rows(mine[:, 0], mine[:, 1])
+            want_t, want_s = reference_mean_grad()
+            ok = torch.allclose(table.grad, want_t, rtol=1e-11, atol=1e-13) and \
+                torch.allclose(scale.grad, want_s, rtol=1e-11, atol=1e-13)
+            if rank == 0:
+                results[f"{mode}_ok"] = bool(ok)
+                results[f"{mode}_mode"] = ex.mode
+                results[f"{mode}_bytes"] = ex.message_bytes
+        if rank == 0:
+            results["dense_bound"] = nodes * 16 * n * n
+            results["rows_bound"] = 2 * b_glob * 16 * n * n
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_dense_and_touched_rows():
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    assert results["dense_ok"] and results["rows_ok"] and results["auto_ok"]
+    assert results["auto_mode"] == "rows"                       # 2 B < N
+    # per-step message: touched rows (+ their int64 indices + the scalar) stay below 2 B 16 n^2 (1 + 1/(2 n^2)) and
+    # below the dense table
+    assert results["rows_bytes"] <= results["rows_bound"] * 1.2 + 64
+    assert results["rows_bytes"] < results["dense_bytes"]

@@ -49,3 +49,17 @@ def test_graphed_step_equals_eager_step():
         assert a[0] == b[0]
         assert abs(a[1] - b[1]) < 1e-8 * abs(b[1]) and abs(a[2] - b[2]) < 1e-8 * abs(b[2]), (a, b)
     assert h_graph[-1][2] < 0.9 * h_graph[0][2]
+
+
+@pytest.mark.parametrize("mode", ["dense", "rows"])
+def test_gradient_exchange_step_equals_plain_step(mode):
+    """The data-parallel step (persistent flat gradient buffer; dense all-reduce or touched-row exchange with the rows
+    backward kernel + scatter kernel) at world size 1 trains exactly like the plain eager step."""
+    import train_siegel
+    common = ["--graph", "grid3d-125", "--manifold", "bounded", "--metric", "riem", "--dims", "3", "--epochs", "8",
+              "--batch_size", "512", "--val_every", "2", "--learning_rate", "0.02", "--burnin", "3"]
+    _, h_plain = train_siegel.train(train_siegel.parser().parse_args(common + ["--no_graph_step"]), log=lambda *_: None)
+    _, h_ex = train_siegel.train(train_siegel.parser().parse_args(common + ["--grad_exchange", mode]), log=lambda *_: None)
+    assert len(h_plain) == len(h_ex) == 4
+    for a, b in zip(h_ex, h_plain):
+        assert abs(a[1] - b[1]) < 1e-8 * abs(b[1]) and abs(a[2] - b[2]) < 1e-8 * abs(b[2]), (a, b)

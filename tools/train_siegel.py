@@ -18,7 +18,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from sympa_amd import data, ops  # noqa: E402
-from sympa_amd.distributed import allreduce_gradients, shard_triplets  # noqa: E402
+from sympa_amd.distributed import GradientExchange, shard_triplets  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
 from sympa_amd.optim import RiemannianSGD  # noqa: E402
 from sympa_amd.train_step import GraphedTrainStep  # noqa: E402
@@ -51,7 +51,16 @@ def train(args, log=print):
     batch = max(1, args.batch_size // world)
     history = []
     # single GPU: the whole step is one hipGraph replay; multi-GPU steps have an all-reduce in the middle and run eagerly
-    graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev) if (world == 1 and args.graph_step) else None
+    graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev) \
+        if (world == 1 and args.graph_step and args.grad_exchange == "none") else None
+    # N > 1 (or --grad_exchange given): gradients live in one persistent flat buffer; the table gradient travels dense
+    # (one in-place all-reduce) or as touched rows (all-gather of the 2 b per-pair rows), whichever message is smaller
+    ex = None
+    if world > 1 or args.grad_exchange != "none":
+        ex = GradientExchange(list(model.parameters()), table=model.embeddings.embeds, local_batch=batch,
+                              mode="auto" if args.grad_exchange == "none" else args.grad_exchange)
+        if rank == 0:
+            log(f"gradient exchange: {ex.mode}, {ex.message_bytes / 1e6:.3f} MB sent per rank per step")
     for epoch in range(1, args.epochs + 1):
         mine = shard_triplets(trip, rank, world, epoch=epoch, seed=0).to(dev)
         t0 = time.perf_counter()
@@ -64,12 +73,23 @@ def train(args, log=print):
             if graphed is not None:
                 loss_sum += graphed(b[:, :2], b[:, 2].to(torch.float64))
                 continue
-            opt.zero_grad(set_to_none=False)
-            loss_sum += model.fused_loss_backward(b[:, :2].contiguous(), b[:, 2].to(torch.float64))
-            if world > 1:
-                allreduce_gradients(model.parameters())
+            ids, gd = b[:, :2].contiguous(), b[:, 2].to(torch.float64)
+            if ex is None:
+                opt.zero_grad(set_to_none=False)
+                loss_sum += model.fused_loss_backward(ids, gd)
+            else:
+                ex.zero_()
+                if ex.mode == "rows" and ids.shape[0] == batch:
+                    loss_sum += model.fused_loss_backward_rows(ids, gd, ex.rows)
+                    ex.exchange_rows(ids[:, 0], ids[:, 1])
+                else:                                   # dense mode, or the ragged last batch of an epoch
+                    loss_sum += model.fused_loss_backward(ids, gd)
+                    ex.allreduce()
             torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)      # runner.py:115
             opt.step()
+        # the reference asserts inside every dist() call (siegel_manifold.py:64-66) and checks all points once per epoch
+        # (runner.py:180-184); here the status word of the kernels is read once per epoch (one host sync)
+        ops.check_status(dev)
         if epoch % args.val_every == 0 or epoch == args.epochs:
             torch.cuda.synchronize(dev)
             t_train = time.perf_counter() - t0
@@ -99,6 +119,9 @@ def parser():
     ap.add_argument("--burnin", type=int, default=10)
     ap.add_argument("--val_every", type=int, default=5)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--grad_exchange", default="none", choices=["none", "auto", "dense", "rows"],
+                    help="single GPU: run the step through sympa_amd.distributed.GradientExchange anyway (tests); with "
+                         "N > 1 GPUs the exchange is always on and this picks its mode (none = auto)")
     ap.add_argument("--no_graph_step", dest="graph_step", action="store_false", default=True,
                     help="launch the kernels of a step one by one instead of replaying one hipGraph per batch")
     return ap
