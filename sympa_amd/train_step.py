@@ -19,7 +19,8 @@ class GraphedTrainStep:
         self.gd = torch.ones(self.batch_size, dtype=torch.float64, device=device)
         self.loss = torch.zeros(1, dtype=torch.float64, device=device)
         self.graph = None
-        self.lr = None
+        self.key = None
+        self.grad_ptrs = []
         self.params = [p for p in model.parameters() if p.requires_grad]
 
     def _body(self):
@@ -44,9 +45,19 @@ class GraphedTrainStep:
         self._clip_and_step()
         return loss
 
-    def _capture(self, lr):
+    def _key(self):
+        """Everything the captured launches bake in as immediates: per-group lr and weight decay, the clip norm."""
+        return (tuple((float(g["lr"]), float(g.get("weight_decay", 0.0))) for g in self.opt.param_groups),
+                self.max_grad_norm)
+
+    def _capture(self):
+        if ops._debug:
+            raise RuntimeError("ops.set_debug(True) synchronises after every kernel and cannot run inside a hipGraph "
+                               "capture: switch it off for graphed training steps")
         # warm-up outside the capture with lr = 0: allocates the gradients / status words / foreach workspaces and
-        # leaves the parameters where they are (retr(x, 0) = projx(x), the identity for points on the manifold)
+        # leaves the parameters where they are (retr(x, 0) = projx(x), the identity for points on the manifold);
+        # every group gets its own lr back afterwards
+        saved = [g["lr"] for g in self.opt.param_groups]
         for g in self.opt.param_groups:
             g["lr"] = 0.0
         side = torch.cuda.Stream()
@@ -55,23 +66,29 @@ class GraphedTrainStep:
             for _ in range(2):
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
-        for g in self.opt.param_groups:
+        for g, lr in zip(self.opt.param_groups, saved):
             g["lr"] = lr
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._body()
-        self.lr = lr
+        self.key = self._key()
+        # the graph writes the gradients through these addresses
+        self.grad_ptrs = [None if p.grad is None else p.grad.data_ptr() for p in self.params]
 
     def __call__(self, ids, gd):
         """ids [b, 2] int64, gd [b] fp64 on the device.  Returns the batch loss as a 1-element device tensor that is
         overwritten by the next call (add it to an accumulator, do not keep it)."""
-        lr = self.opt.param_groups[0]["lr"]
         if ids.shape[0] != self.batch_size:
             return self.eager(ids, gd)
         self.ids.copy_(ids)
         self.gd.copy_(gd)
-        if self.graph is None or lr != self.lr:
-            self._capture(lr)
+        if self.graph is None or self._key() != self.key:
+            self._capture()          # learning rate / weight decay / clip norm of any group changed (end of burn-in)
+        for p, ptr in zip(self.params, self.grad_ptrs):
+            if (None if p.grad is None else p.grad.data_ptr()) != ptr:
+                # e.g. zero_grad(set_to_none=True) between replays: the graph would write freed memory
+                raise RuntimeError("a parameter's .grad was replaced since the step was captured; keep the gradient "
+                                   "tensors (zero_grad(set_to_none=False)) or build a new GraphedTrainStep")
         self.graph.replay()
         return self.loss
 

@@ -60,3 +60,36 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsympa_hip.so")
     with pytest.raises(_lib.SympaHipError):
         _lib.load()
+
+
+def test_integration_md_stub_compiles_and_matches_the_binding():
+    """INTEGRATION.md section 3 shows the ctypes stub a maintainer of the reference would paste into
+    sympa/manifolds/siegel_manifold.py.  Extract it, execute it (stand-ins for the two names the reference file
+    already has in scope) and check its prototypes against this package's own binding, and that it only uses
+    attributes the reference's class really has (self.dims, self.metric -- there is no metric_name)."""
+    import re
+    from abc import ABC
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3."):text.index("## 4.")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 1
+    src = blocks[0]
+    assert "metric_name" not in src and "self.metric" in src and "self.dims" in src
+    cwd = os.getcwd()
+    os.chdir(ROOT)                  # the stub loads the library by its in-tree relative path
+    try:
+        ns = {"Manifold": type("Manifold", (), {}), "ABC": ABC}   # geoopt's base class stands in
+        exec(compile(src, "INTEGRATION.md#3", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    lib = _lib.load()
+    for name in ("sympa_siegel_dist_fwd", "sympa_siegel_dist_bwd"):
+        assert list(getattr(ns["_lib"], name).argtypes) == list(getattr(lib, name).argtypes), name
+        assert getattr(ns["_lib"], name).restype is getattr(lib, name).restype
+    # the class-name -> id table covers exactly the mirror's metric classes, with the C-ABI's ids
+    from sympa_amd.manifolds import metrics as mm
+    from sympa_amd.ops import METRIC_IDS
+    for t in mm.MetricType:
+        cls = type(mm.Metric.get(t, 3)).__name__
+        assert ns["_METRIC_ID"][cls] == METRIC_IDS[t.value], cls
+    assert hasattr(ns["SiegelManifold"], "dist") and ns["SiegelManifold"].model_id == 0

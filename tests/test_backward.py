@@ -65,7 +65,11 @@ def test_hostsim_backward_matches_oracle_autograd(model, n):
         assert st == 0
         for got, ref in ((g1, want[1].numpy()), (g2, want[2].numpy())):
             err = per_pair_rel(got, ref)
-            assert np.quantile(err, 0.95) < 1e-8 and err.max() < 1e-2, (model, n, m, err.max())
+            # observed on these 333 pairs (tools: the same comparison with the g++ build): 95 % below 3e-11, at most
+            # 2 pairs above 1e-6 (near-degenerate eigenvalue pairs, where torch autograd through the reference's
+            # 2n x 2n eigh divides by the gap and the finite difference sides with the kernel), worst 1.7e-3
+            assert np.quantile(err, 0.95) < 1e-10 and int((err > 1e-6).sum()) <= 3 and err.max() < 5e-3, \
+                (model, n, m, err.max())
         if m == "wsum":
             assert relmax(gw, want[3].numpy().reshape(-1)) < 1e-5
     # finite-difference adjudication of the pair where analytic and autograd gradients differ most
@@ -120,7 +124,7 @@ def test_gpu_backward_golden(dev, model, n):
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_autograd_function_vs_cpu_build_and_oracle(dev, model, n):
     """manifold.dist under torch autograd on the GPU: (a) equals the g++ build of the same arithmetic to
-    rounding, (b) agrees with torch autograd through the oracle (95 % of pairs to 1e-8, all to 1e-3; see
+    rounding, (b) agrees with torch autograd through the oracle (95 % of pairs to 1e-10, all but <= 3 to 1e-6; see
     test_hostsim_backward_matches_oracle_autograd for why the autograd path is the looser side)."""
     from sympa_amd.manifolds import BoundedDomainManifold, MetricType, UpperHalfManifold
     g = torch.Generator().manual_seed(70 + n)
@@ -145,7 +149,11 @@ def test_gpu_autograd_function_vs_cpu_build_and_oracle(dev, model, n):
         assert relmax(out.detach().cpu(), want[0]) < 1e-9
         for got, ref in ((a.grad.cpu().numpy(), want[1].numpy()), (c.grad.cpu().numpy(), want[2].numpy())):
             err = per_pair_rel(got, ref)
-            assert np.quantile(err, 0.95) < 1e-8 and err.max() < 1e-2, (model, n, m, err.max())
+            # observed on these 333 pairs (tools: the same comparison with the g++ build): 95 % below 3e-11, at most
+            # 2 pairs above 1e-6 (near-degenerate eigenvalue pairs, where torch autograd through the reference's
+            # 2n x 2n eigh divides by the gap and the finite difference sides with the kernel), worst 1.7e-3
+            assert np.quantile(err, 0.95) < 1e-10 and int((err > 1e-6).sum()) <= 3 and err.max() < 5e-3, \
+                (model, n, m, err.max())
         if m == "wsum":
             assert relmax(man.metric.weights.grad.cpu().reshape(-1), hw) < 1e-9
 

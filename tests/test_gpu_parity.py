@@ -412,3 +412,43 @@ def test_fused_batches_bit_identical(dev, model, n):
     assert torch.isnan(outs[4][7]) and torch.isfinite(outs[4][:7]).all() and torch.isfinite(outs[3]).all()
     with pytest.raises(IndexError):
         ops.check_status(dev)
+
+
+def test_integration_md_stub_runs_on_the_gpu(dev):
+    """The ctypes stub of INTEGRATION.md section 3 (what a maintainer pastes into the reference's siegel_manifold.py),
+    executed as written: forward and backward through the C-ABI equal the package's own binding."""
+    import os
+    import re
+    from abc import ABC
+    from sympa_amd import autograd as sa
+    from sympa_amd.manifolds import metrics as mm
+    from tests.helpers import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = re.findall(r"```python\n(.*?)```", text[text.index("## 3."):text.index("## 4.")], flags=re.S)[0]
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        ns = {"Manifold": type("Manifold", (), {}), "ABC": ABC}   # geoopt's base class stands in
+        exec(compile(src, "INTEGRATION.md#3", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(77)
+    n = 3
+    for model_id, model in enumerate(MODELS):
+        for t in (mm.MetricType.RIEMANNIAN, mm.MetricType.WEIGHTED_SUM):
+            man = ns["SiegelManifold"]()
+            man.dims, man.model_id = n, model_id
+            man.metric = mm.Metric.get(t, n)
+            if t is mm.MetricType.WEIGHTED_SUM:
+                man.metric = man.metric.to(dev)
+            z1 = points(model, 50, n, 0.4, g).to(dev).requires_grad_(True)
+            z2 = points(model, 50, n, 0.4, g).to(dev).requires_grad_(True)
+            d = man.dist(z1, z2)
+            assert man.dist(z1, z2, keepdim=True).shape == (50, 1)
+            d.sum().backward()
+            w = getattr(man.metric, "weights", None)
+            y1, y2 = z1.detach().clone().requires_grad_(True), z2.detach().clone().requires_grad_(True)
+            ref = sa.siegel_dist(y1, y2, model, t.value, w)
+            ref.sum().backward()
+            assert torch.equal(d.detach(), ref.detach())
+            assert torch.equal(z1.grad, y1.grad) and torch.equal(z2.grad, y2.grad)

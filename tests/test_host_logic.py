@@ -54,6 +54,54 @@ def test_graph_triplets_match_networkx_bfs(name, nodes, triplets, diam):
     assert trip.tolist() == [list(t) for t in want]          # lexicographic, exact integers
 
 
+def test_graph_triplets_tree_b3_h6_match_networkx_bfs():
+    """configs[1]: balanced tree b = 3, h = 6 -- every one of the 596 778 triplets against a networkx BFS per source."""
+    import networkx as nx
+    g = data.named_graph("tree-b3-h6")
+    trip, id2node = data.graph_triplets(g)
+    assert len(id2node) == 1093 and trip.shape == (1093 * 1092 // 2, 3) and int(trip[:, 2].max()) == 12
+    relabelled = nx.convert_node_labels_to_integers(g, ordering="sorted")
+    want = []
+    for i in range(1093):
+        sp = nx.single_source_shortest_path_length(relabelled, i)
+        want.extend((i, j, sp[j]) for j in range(i + 1, 1093))
+    assert torch.equal(trip, torch.tensor(want, dtype=torch.int64))
+
+
+def test_graph_triplets_margulis_71_multigraph_with_self_loops():
+    """configs[2]: margulis_gabber_galil_graph(71) is a MultiGraph on 71^2 = 5 041 nodes with parallel edges and 284
+    self-loops (preprocess.py:60-61) -- the case where an adjacency-matrix BFS can go wrong (loops on the diagonal,
+    multiplicities as weights).  All 12.7 M triplets are generated; the rows of 150 source nodes (every 40th, plus
+    nodes that carry self-loops, plus the last ones) are compared with a networkx BFS, the rest through invariants."""
+    import networkx as nx
+    g = data.named_graph("margulis-71")
+    assert g.is_multigraph() and nx.number_of_selfloops(g) == 284
+    trip, id2node = data.graph_triplets(g)
+    n = 5041
+    assert len(id2node) == n and trip.shape == (n * (n - 1) // 2, 3)          # connected: every pair has a distance
+    assert id2node[0] == (0, 0) and id2node[n - 1] == (70, 70)                 # sorted() relabelling of (x, y) nodes
+    # lexicographic order of (i, j), i < j
+    iu, ju = torch.triu_indices(n, n, offset=1)
+    assert torch.equal(trip[:, 0], iu) and torch.equal(trip[:, 1], ju)
+    assert int(trip[:, 2].min()) == 1
+    relabelled = nx.convert_node_labels_to_integers(g, ordering="sorted")
+    loops = sorted({u for u, _ in nx.selfloop_edges(relabelled)})
+    sources = sorted(set(range(0, n, 40)) | set(loops[:12]) | {n - 3, n - 2})
+    starts = torch.cumsum(torch.tensor([0] + [n - 1 - i for i in range(n - 1)]), 0)     # first row of source i
+    diam = 0
+    for i in sources:
+        sp = nx.single_source_shortest_path_length(relabelled, i)
+        want = torch.tensor([sp[j] for j in range(i + 1, n)], dtype=torch.int64)
+        got = trip[int(starts[i]):int(starts[i]) + n - 1 - i, 2]
+        assert torch.equal(got, want), i
+        diam = max(diam, max(sp.values()))
+    assert int(trip[:, 2].max()) >= diam
+    # every edge of the simple graph is a triplet at distance 1, and nothing else is
+    simple = {(min(u, v), max(u, v)) for u, v in relabelled.edges() if u != v}
+    one = trip[trip[:, 2] == 1]
+    assert {(int(a), int(b)) for a, b in one[:, :2].tolist()} == simple
+
+
 @pytest.mark.parametrize("length,world", [(103, 4), (8, 3), (5, 8), (64, 2), (7750, 8)])
 @pytest.mark.parametrize("drop_last", [False, True])
 def test_distributed_sampler_semantics(length, world, drop_last):
