@@ -1,10 +1,10 @@
-// Upper-half model for 9 <= n <= 16: sixteen lanes per pair (the layout and the DPP machinery of spd_coop.hpp), complex.
+// Upper-half / bounded models for 9 <= n <= 16: sixteen lanes per pair (the layout and the DPP machinery of spd_coop.hpp),
+// complex, instantiated for every matrix size M = n (no padding: the routines are templates over M, see spd_coop.hpp).
 //
 // One lane per pair (siegel_math_generic.hpp) keeps E, H and the Cholesky factors of a 16 x 16 pair in scratch memory
 // (12 KB per lane) and runs at 3-15 M pairs/s.  Here lane r of a group of 16 owns row r of each REAL matrix of its pair
-// -- X1, Y1, X2, Y2, then Re/Im of D = Z2 - Z1, of E = L1^-1 D L2^-T and of H = E^H E -- and n < 16 is padded with the
-// point i I (X = 0, Y = I), which adds singular values sigma = 0, i.e. v = 0: nothing for riem / fone / finf, and the
-// index-weighted metrics (fmin, wsum) take the n largest of the sixteen sorted values.
+// -- X1, Y1, X2, Y2, then Re/Im of D = Z2 - Z1, of E = L1^-1 D L2^-T and of H = E^H E; lanes r >= n of a group are
+// phantoms (spd_coop.hpp).
 //
 //   Cholesky Y1 = L1 L1^T, Y2 = L2 L2^T                                  (cholesky_rows, twice)
 //   W = D L2^-T, transpose, E^T = W^T L1^-T            for Re and Im     (real factors: the two planes do not mix)
@@ -30,12 +30,13 @@ using spd_coop::sfor;
 constexpr int N = spd_coop::N;
 
 // H = E^H E.  er/ei: my column of E (element k = E[k][me]).  Row `me` of H comes out in hr/hi.
-__device__ __forceinline__ void gram_columns(double (&sr)[N], double (&si)[N], double (&hr)[N], double (&hi)[N]) {
-    sfor<0, N>([&](auto K) { sr[K] = settle(sr[K]); si[K] = settle(si[K]); });
-    sfor<0, N>([&](auto J) {
+template <int M>
+__device__ __forceinline__ void gram_columns(double (&sr)[M], double (&si)[M], double (&hr)[M], double (&hi)[M]) {
+    sfor<0, M>([&](auto K) { sr[K] = settle(sr[K]); si[K] = settle(si[K]); });
+    sfor<0, M>([&](auto J) {
         constexpr int j = J;
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        sfor<0, N>([&](auto K) {
+        sfor<0, M>([&](auto K) {
             constexpr int k = K;
             // conj(E[k][i]) E[k][j] = (er_i er_j + ei_i ei_j) + i (er_i ei_j - ei_i er_j)
             fmac_bc<j>(a0, sr[k], sr[k]);
@@ -50,13 +51,14 @@ __device__ __forceinline__ void gram_columns(double (&sr)[N], double (&si)[N], d
 
 // ---- bounded model: A = I - W W^H = C C^H with complex factors -------------------------------------------------
 // A = I - W W^H from the rows of the complex-symmetric W held one per lane:  A[i][j] = delta_ij - sum_l W[i][l] conj(W[j][l])
-__device__ __forceinline__ void id_minus_wwh_rows(double (&wr)[N], double (&wi)[N], double (&ar)[N], double (&ai)[N],
+template <int M>
+__device__ __forceinline__ void id_minus_wwh_rows(double (&wr)[M], double (&wi)[M], double (&ar)[M], double (&ai)[M],
                                                   const int r) {
-    sfor<0, N>([&](auto L) { wr[L] = settle(wr[L]); wi[L] = settle(wi[L]); });
-    sfor<0, N>([&](auto J) {
+    sfor<0, M>([&](auto L) { wr[L] = settle(wr[L]); wi[L] = settle(wi[L]); });
+    sfor<0, M>([&](auto J) {
         constexpr int j = J;
         double a0 = (r == j) ? 1.0 : 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        sfor<0, N>([&](auto L) {
+        sfor<0, M>([&](auto L) {
             constexpr int l = L;
             fnmac_bc<j>(a0, wr[l], wr[l]);      // - wr_i wr_j
             fnmac_bc<j>(a1, wi[l], wi[l]);      // - wi_i wi_j
@@ -70,9 +72,10 @@ __device__ __forceinline__ void id_minus_wwh_rows(double (&wr)[N], double (&wi)[
 
 // Cholesky A = C C^H of the Hermitian matrix held one row per lane (complex, right-looking, in place): after step j,
 // registers j of lane i >= j hold C[i][j]; the diagonal is real, rd[j] = 1 / C[j][j].
-__device__ __forceinline__ bool ccholesky_rows(double (&xr)[N], double (&xi)[N], double (&rd)[N]) {
+template <int M>
+__device__ __forceinline__ bool ccholesky_rows(double (&xr)[M], double (&xi)[M], double (&rd)[M]) {
     bool pd = true;
-    sfor<0, N>([&](auto J) {
+    sfor<0, M>([&](auto J) {
         constexpr int j = J;
         const double piv = bcast<j>(settle(xr[j]));
         pd = pd && (piv > 0.0);
@@ -80,7 +83,7 @@ __device__ __forceinline__ bool ccholesky_rows(double (&xr)[N], double (&xi)[N],
         rd[j] = rr;
         xr[j] = settle(xr[j] * rr);
         xi[j] = settle(xi[j] * rr);
-        sfor<j + 1, N>([&](auto K) {
+        sfor<j + 1, M>([&](auto K) {
             constexpr int k = K;
             // X[i][k] -= C[i][j] conj(C[k][j])
             fnmac_bc<k>(xr[k], xr[j], xr[j]);
@@ -93,9 +96,10 @@ __device__ __forceinline__ bool ccholesky_rows(double (&xr)[N], double (&xi)[N],
 }
 
 // a <- a C^-T (plain transpose) for complex rows held one per lane:  a[j] = (a[j] - sum_{k<j} a[k] C[j][k]) / C[j][j]
-__device__ __forceinline__ void csolve_right_lt(double (&ar)[N], double (&ai)[N], const double (&cr)[N], const double (&ci)[N],
-                                                const double (&rd)[N]) {
-    sfor<0, N>([&](auto J) {
+template <int M>
+__device__ __forceinline__ void csolve_right_lt(double (&ar)[M], double (&ai)[M], const double (&cr)[M], const double (&ci)[M],
+                                                const double (&rd)[M]) {
+    sfor<0, M>([&](auto J) {
         constexpr int j = J;
         sfor<0, j>([&](auto K) {
             constexpr int k = K;
@@ -111,15 +115,16 @@ __device__ __forceinline__ void csolve_right_lt(double (&ar)[N], double (&ai)[N]
 
 // Complex Householder tridiagonalisation of the Hermitian H held one row per lane (hr[j] + i hi[j] = H[me][j]).
 // d_k and |b_k|^2 are group-uniform; the lane with keep = true stores them.
-__device__ __forceinline__ void tridiagonalize_rows(double (&hr)[N], double (&hi)[N], const int r, const bool keep,
-                                                    double (&d)[N], double (&e2)[N]) {
-    sfor<0, N - 2>([&](auto K) {
+template <int M>
+__device__ __forceinline__ void tridiagonalize_rows(double (&hr)[M], double (&hi)[M], const int r, const bool keep,
+                                                    double (&d)[M], double (&e2)[M]) {
+    sfor<0, M - 2>([&](auto K) {
         constexpr int k = K;
         // my element of column k: H[me][k]; every use of the reflector broadcasts from these registers
         const double cr = settle(hr[k]), ci = settle(hi[k]);
         const double x0r = bcast<k + 1>(cr), x0i = bcast<k + 1>(ci);
         const double dk = bcast<k>(cr);
-        const double t2 = (r > k + 1) ? sympa::d_fma(cr, cr, ci * ci) : 0.0;
+        const double t2 = (r > k + 1 && r < M) ? sympa::d_fma(cr, cr, ci * ci) : 0.0;
         const double s2 = group_sum(t2);
         const double x02 = sympa::d_fma(x0r, x0r, x0i * x0i);
         const double n2 = x02 + s2;
@@ -132,24 +137,24 @@ __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[N], double (&hi
         const double pr = x0zero ? 1.0 : x0r * ix0, pi = x0zero ? 0.0 : x0i * ix0;      // phase of x0
         const double v0r = pr * (ax0 + nx), v0i = pi * (ax0 + nx);                      // v = x + phase ||x|| e1
         const double beta = (s2 > 0.0) ? sympa::d_rcp(nx * (nx + ax0)) : 0.0;           // 2 / ||v||^2
-        const double vr = settle((r <= k) ? 0.0 : ((r == k + 1) ? v0r : cr));
-        const double vi = settle((r <= k) ? 0.0 : ((r == k + 1) ? v0i : ci));
+        const double vr = settle((r <= k || r >= M) ? 0.0 : ((r == k + 1) ? v0r : cr));
+        const double vi = settle((r <= k || r >= M) ? 0.0 : ((r == k + 1) ? v0i : ci));
         // p = beta H v:  p_i = sum_j H[i][j] v_j
         double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
-        sfor<k + 1, N>([&](auto J) {
+        sfor<k + 1, M>([&](auto J) {
             constexpr int j = J;
             fmac_bc<j>(p0, vr, hr[j]);
             fnmac_bc<j>(p1, vi, hi[j]);
             fmac_bc<j>(q0, vi, hr[j]);
             fmac_bc<j>(q1, vr, hi[j]);
         });
-        double pr_ = (r <= k) ? 0.0 : beta * (p0 + p1);
-        double pi_ = (r <= k) ? 0.0 : beta * (q0 + q1);
+        double pr_ = (r <= k || r >= M) ? 0.0 : beta * (p0 + p1);
+        double pi_ = (r <= k || r >= M) ? 0.0 : beta * (q0 + q1);
         const double kk = 0.5 * beta * group_sum(sympa::d_fma(vr, pr_, vi * pi_));       // Re(v^H p) beta / 2
         const double qr = settle(sympa::d_fma(-kk, vr, pr_));
         const double qi = settle(sympa::d_fma(-kk, vi, pi_));
         // H <- H - v q^H - q v^H:   H[i][j] -= v_i conj(q_j) + q_i conj(v_j)
-        sfor<k + 1, N>([&](auto J) {
+        sfor<k + 1, M>([&](auto J) {
             constexpr int j = J;
             fnmac_bc<j>(hr[j], qr, vr);
             fnmac_bc<j>(hr[j], qi, vi);
@@ -161,33 +166,13 @@ __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[N], double (&hi
             fmac_bc<j>(hi[j], vi, qr);
         });
     });
-    const double lr = settle(hr[N - 1]), li = settle(hi[N - 1]);
-    const double dm = bcast<N - 2>(settle(hr[N - 2]));
-    const double dn = bcast<N - 1>(lr);
-    const double br = bcast<N - 2>(lr), bi = bcast<N - 2>(li);
-    d[N - 2] = keep ? dm : d[N - 2];
-    d[N - 1] = keep ? dn : d[N - 1];
-    e2[N - 2] = keep ? sympa::d_fma(br, br, bi * bi) : e2[N - 2];
-}
-
-// Metric over the n largest of the sixteen ASCENDING values v.  The 16 - n smallest belong to the padding: zero
-// eigenvalues that come out of the QL iteration as a few ulps of ||H||, which v ~ 2 sqrt(lambda) turns into 1e-8 --
-// they are dropped by position, not trusted to be zero.
-__device__ __forceinline__ double reduce_metric_padded(double (&v)[N], const int n, const int metric,
-                                                       const double* __restrict__ w) {
-    const int pad = N - n;
-    double acc = 0.0;
-    sfor<0, N>([&](auto I) {
-        constexpr int i = I;
-        const bool mine = i >= pad;
-        const double x = mine ? v[i] : 0.0;
-        if (metric == sympa::METRIC_RIEM) acc = sympa::d_fma(x, x, acc);
-        else if (metric == sympa::METRIC_FONE) acc += x;
-        else if (metric == sympa::METRIC_FINF) acc = fmax(acc, x);
-        else if (metric == sympa::METRIC_FMIN) acc = sympa::d_fma(mine ? 2.0 * (double)(i - pad) : 0.0, x, acc);
-        else acc = sympa::d_fma(mine ? fmax(w[(i - pad) > 0 ? (i - pad) : 0], 0.0) : 0.0, x, acc);
-    });
-    return metric == sympa::METRIC_RIEM ? sympa::d_sqrt(acc) : acc;
+    const double lr = settle(hr[M - 1]), li = settle(hi[M - 1]);
+    const double dm = bcast<M - 2>(settle(hr[M - 2]));
+    const double dn = bcast<M - 1>(lr);
+    const double br = bcast<M - 2>(lr), bi = bcast<M - 2>(li);
+    d[M - 2] = keep ? dm : d[M - 2];
+    d[M - 1] = keep ? dn : d[M - 1];
+    e2[M - 2] = keep ? sympa::d_fma(br, br, bi * bi) : e2[M - 2];
 }
 
 }  // namespace siegel_coop

@@ -28,8 +28,14 @@
 
 namespace spd_coop {
 
-constexpr int N = 16;
+constexpr int N = 16;                            // lanes per pair (a DPP row); matrices are M x M, M <= N
 constexpr int ROUNDS = 16;                       // 4 pairs per round, 64 pairs per wave
+// The row-per-lane routines below are templates over the matrix size M <= 16: lane r < M of a group of sixteen owns
+// row r, lanes r >= M are phantoms -- they execute the same instructions on values nobody reads (every DPP broadcast
+// takes its source from a lane j < M, the group sums mask them out, the LDS transposes give them columns nobody
+// wrote), and still take their turn as the lane that keeps a pair's tridiagonal form for the one-pair-per-lane
+// QL phase.  A wave instruction costs the same with 10 or 16 active rows, so the time goes with M^2, not M^3:
+// M = n exactly instead of padding every n to 16 is worth (16 / n)^2.
 constexpr int TILE_BYTES = 4 * 2 * N * N * 8;    // one round: 4 pairs x {X, Y} x 2 KB
 constexpr int LDS_BYTES = TILE_BYTES;            // the transpose of a round reuses the (consumed) tile
 
@@ -84,8 +90,9 @@ __device__ __forceinline__ int tile_slot(const int r, const int c) { return r * 
 
 // a <- a L^-T for the rows held one per lane:  a[j] = (a[j] - sum_{k<j} a[k] L[j][k]) / L[j][j];
 // L[j][k] is register k of lane j.
-__device__ __forceinline__ void solve_right_lt(double (&a)[N], const double (&l)[N], const double (&rd)[N]) {
-    sfor<0, N>([&](auto J) {
+template <int M>
+__device__ __forceinline__ void solve_right_lt(double (&a)[M], const double (&l)[M], const double (&rd)[M]) {
+    sfor<0, M>([&](auto J) {
         constexpr int j = J;
         sfor<0, j>([&](auto K) {
             constexpr int k = K;
@@ -97,16 +104,17 @@ __device__ __forceinline__ void solve_right_lt(double (&a)[N], const double (&l)
 
 // Cholesky X = L L^T of the matrix held one row per lane, right-looking, in place: after step j, register j of
 // lane i >= j holds L[i][j]; rd[j] = 1 / L[j][j] (group-uniform).  Returns "all pivots positive".
-__device__ __forceinline__ bool cholesky_rows(double (&x)[N], double (&rd)[N]) {
+template <int M>
+__device__ __forceinline__ bool cholesky_rows(double (&x)[M], double (&rd)[M]) {
     bool pd = true;
-    sfor<0, N>([&](auto J) {
+    sfor<0, M>([&](auto J) {
         constexpr int j = J;
         const double piv = bcast<j>(settle(x[j]));
         pd = pd && (piv > 0.0);
         const double rr = sympa::d_rsqrt(piv);
         rd[j] = rr;
         x[j] = settle(x[j] * rr);
-        sfor<j + 1, N>([&](auto K) {
+        sfor<j + 1, M>([&](auto K) {
             constexpr int k = K;
             fnmac_bc<k>(x[k], x[j], x[j]);      // X[i][k] -= L[k][j] L[i][j]
         });
@@ -115,18 +123,20 @@ __device__ __forceinline__ bool cholesky_rows(double (&x)[N], double (&rd)[N]) {
 }
 
 // m <- y^T for the rows held one per lane, through 2 KB of LDS private to my group
-__device__ __forceinline__ void transpose_rows(const double (&y)[N], double (&m)[N], double* __restrict__ tbuf, const int r) {
+template <int M>
+__device__ __forceinline__ void transpose_rows(const double (&y)[M], double (&m)[M], double* __restrict__ tbuf, const int r) {
     wave_lds_fence();
-    sfor<0, N>([&](auto J) { tbuf[r * N + J] = y[J]; });
+    sfor<0, M>([&](auto J) { tbuf[r * N + J] = y[J]; });
     wave_lds_fence();
-    sfor<0, N>([&](auto J) { m[J] = tbuf[J * N + r]; });
+    sfor<0, M>([&](auto J) { m[J] = tbuf[J * N + r]; });
 }
 
 // First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
 // W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
-__device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N], double (&rd)[N], double (&m)[N],
+template <int M>
+__device__ __forceinline__ bool reduce_pair_front(double (&x)[M], double (&y)[M], double (&rd)[M], double (&m)[M],
                                                   double* __restrict__ tbuf, const int r) {
-    sfor<0, N>([&](auto J) { y[J] -= x[J]; });      // D = Y - X
+    sfor<0, M>([&](auto J) { y[J] -= x[J]; });      // D = Y - X
     const bool pd = cholesky_rows(x, rd);
     solve_right_lt(y, x, rd);                        // W = D L^-T
     transpose_rows(y, m, tbuf, r);
@@ -134,20 +144,21 @@ __device__ __forceinline__ bool reduce_pair_front(double (&x)[N], double (&y)[N]
 }
 
 // Second half: M = W^T L^-T = L^-1 (Y - X) L^-T, then its tridiagonal form (d, e2), kept by the lane with keep = true.
-__device__ __forceinline__ void reduce_pair_back(double (&m)[N], const double (&x)[N], const double (&rd)[N],
-                                                 const int r, const bool keep, double (&d)[N], double (&e2)[N]) {
+template <int M>
+__device__ __forceinline__ void reduce_pair_back(double (&m)[M], const double (&x)[M], const double (&rd)[M],
+                                                 const int r, const bool keep, double (&d)[M], double (&e2)[M]) {
     solve_right_lt(m, x, rd);
 
     // Householder tridiagonalisation.  The reflector of step k is taken from COLUMN k, one element per lane (my
     // own register k), and broadcast from there for every use: with a single source for v the update is an exact
     // similarity whatever rounding-level asymmetry M carries.  (Mixing row k of lane k with my own column element
     // is inconsistent by that asymmetry RELATIVE TO |v|, which is large when the eliminated column is small.)
-    sfor<0, N - 2>([&](auto K) {
+    sfor<0, M - 2>([&](auto K) {
         constexpr int k = K;
         const double col = settle(m[k]);
         const double x0 = bcast<k + 1>(col);
         const double dk = bcast<k>(col);
-        const double tail = (r > k + 1) ? col : 0.0;
+        const double tail = (r > k + 1 && r < M) ? col : 0.0;
         const double s2 = group_sum(tail * tail);
         const double n2 = sympa::d_fma(x0, x0, s2);
         d[k] = keep ? dk : d[k];
@@ -156,28 +167,28 @@ __device__ __forceinline__ void reduce_pair_back(double (&m)[N], const double (&
         const double v0 = x0 + copysign(nx, x0);
         const double den = sympa::d_fma(v0, v0, s2);
         const double beta = (den > 0.0) ? 2.0 * sympa::d_rcp(den) : 0.0;
-        const double vi = settle((r <= k) ? 0.0 : ((r == k + 1) ? v0 : col));
+        const double vi = settle((r <= k || r >= M) ? 0.0 : ((r == k + 1) ? v0 : col));
         // p_i = sum_j M[i][j] v_j, four partial sums: the chain is the latency of the step
         double ps[4] = {0.0, 0.0, 0.0, 0.0};
-        sfor<k + 1, N>([&](auto J) { fmac_bc<J>(ps[J % 4], vi, m[J]); });
+        sfor<k + 1, M>([&](auto J) { fmac_bc<J>(ps[J % 4], vi, m[J]); });
         double p = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        p = (r <= k) ? 0.0 : beta * p;
+        p = (r <= k || r >= M) ? 0.0 : beta * p;
         const double kk = 0.5 * beta * group_sum(vi * p);
         const double q = settle(sympa::d_fma(-kk, vi, p));
         // M <- M - q v^T - v q^T on the trailing block (lanes <= k have v = q = 0 and keep their rows)
-        sfor<k + 1, N>([&](auto J) {
+        sfor<k + 1, M>([&](auto J) {
             constexpr int j = J;
             fnmac_bc<j>(m[j], vi, q);       // - v_j q_i
             fnmac_bc<j>(m[j], q, vi);       // - q_j v_i
         });
     });
-    const double last = settle(m[N - 1]);
-    const double dm = bcast<N - 2>(settle(m[N - 2]));
-    const double dn = bcast<N - 1>(last);
-    const double en = bcast<N - 2>(last);
-    d[N - 2] = keep ? dm : d[N - 2];
-    d[N - 1] = keep ? dn : d[N - 1];
-    e2[N - 2] = keep ? en * en : e2[N - 2];
+    const double last = settle(m[M - 1]);
+    const double dm = bcast<M - 2>(settle(m[M - 2]));
+    const double dn = bcast<M - 1>(last);
+    const double en = bcast<M - 2>(last);
+    d[M - 2] = keep ? dm : d[M - 2];
+    d[M - 1] = keep ? dn : d[M - 1];
+    e2[M - 2] = keep ? en * en : e2[M - 2];
 }
 
 }  // namespace spd_coop

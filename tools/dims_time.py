@@ -12,7 +12,7 @@ from sympa_amd import data, ops  # noqa: E402
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 model = sys.argv[2] if len(sys.argv) > 2 else "upper"
 dev = torch.device("cuda:0")
-for n in (2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
+for n in [int(x) for x in os.environ.get("DIMS", "2,3,4,5,6,7,8,9,10,11,12,13,14,15,16").split(",")]:
     nodes = 5000
     table = data.trained_like_table(nodes, n, seed=1, model=model).to(dev)
     pairs = data.sample_pairs(nodes, b, 0, 1).to(dev)
