@@ -62,9 +62,11 @@ extern "C" {
 #define SYMPA_FLAG_FUSE 8 /* sympa_model_forward_batches only (dims <= SYMPA_MAX_DIMS): up to SYMPA_MAX_FUSED_BATCHES
                              consecutive batches per kernel launch instead of one launch per batch */
 #define SYMPA_MAX_FUSED_BATCHES 32
+#define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
+#define SYMPA_MAX_DIMS_ALL_PAIRS_PACKED 4 /* sympa_all_pairs_dist_packed: per-point factor reuse, dims 1..4 */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] run sixteen lanes per pair
                                      (csrc/siegel_coop.hpp); SYMPA_FLAG_GENERIC selects the runtime-n fallback (scratch) */
 
@@ -126,6 +128,19 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
 int sympa_all_pairs_dist(const double* table, int64_t num_rows, int n, int64_t row_begin, int64_t row_count, int model,
                          int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
                          double* out, int32_t* status, int flags, void* stream);
+
+/* The same matrix with per-point factor reuse (dims <= SYMPA_MAX_DIMS_ALL_PAIRS_PACKED): every point is factored once
+ * into `workspace` (sympa_all_pairs_workspace_bytes(num_rows, n, model) bytes of device memory owned by the caller,
+ * overwritten; 0 = this build has no packed kernel for these dims), the pair kernel then needs neither a Cholesky nor
+ * a gather, and for the FULL matrix (row_begin = 0, row_count = num_rows) of dims >= 3 only the pairs i <= j are
+ * evaluated and each value is stored at (i, j) and (j, i) -- out is exactly symmetric -- unless SYMPA_FLAG_NO_SYMMETRY
+ * is given; the diagonal is exactly 0 in every mode.  Same distances as
+ * sympa_all_pairs_dist to rounding (1e-12 relative). */
+int64_t sympa_all_pairs_workspace_bytes(int64_t num_rows, int n, int model);
+int sympa_all_pairs_dist_packed(const double* table, int64_t num_rows, int n, int64_t row_begin, int64_t row_count,
+                                int model, int metric, const double* metric_w, double eps, const double* scale,
+                                double scale_coef, double* out, void* workspace, int64_t workspace_bytes,
+                                int32_t* status, int flags, void* stream);
 
 /* Backward of manifold.dist for pre-gathered points: what torch autograd computes through
  * siegel_manifold.py:41-72 / bounded_domain.py:27-39 when runner.py:105 calls loss.backward().

@@ -18,6 +18,8 @@ SYMBOLS = (
     "sympa_model_forward",
     "sympa_model_forward_batches",
     "sympa_all_pairs_dist",
+    "sympa_all_pairs_workspace_bytes",
+    "sympa_all_pairs_dist_packed",
     "sympa_siegel_dist_bwd",
     "sympa_model_backward",
     "sympa_model_loss_backward",
@@ -81,6 +83,14 @@ def load():
     lib.sympa_all_pairs_dist.argtypes = [
         _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
         _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+    ]
+    lib.sympa_all_pairs_workspace_bytes.restype = ctypes.c_int64
+    lib.sympa_all_pairs_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    lib.sympa_all_pairs_dist_packed.restype = ctypes.c_int
+    lib.sympa_all_pairs_dist_packed.argtypes = [
+        _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+        _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_void_p, ctypes.c_int64,
+        _c_i32_p, ctypes.c_int, ctypes.c_void_p,
     ]
     lib.sympa_siegel_dist_bwd.restype = ctypes.c_int
     lib.sympa_siegel_dist_bwd.argtypes = [

@@ -788,41 +788,11 @@ SYMPA_HD double reduce_metric(double (&v)[N], int metric, const double* __restri
 // One pair, start to finish.  p1/p2 point at [2,n,n] fp64 points.  Returns the metric value; the
 // ascending vector-valued distance is written to vvd (if non-null) and status bits are OR-ed.
 // ---------------------------------------------------------------------------------------------
+// Second half of a pair: from E (sinh(v_i / 2) = sigma_i(E) / 2 upper, sigma_i(E) bounded) to the metric value.
 template <int N, int MODEL>
-SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
-                                   double inv_eps, double* __restrict__ vvd, int& status) {
-    CMat<N> e;
+SYMPA_HD double distance_from_e(const CMat<N>& e, const bool ok, int metric, const double* __restrict__ w,
+                                double inv_eps, double* __restrict__ vvd, int& status) {
     Herm<N> h;
-    bool ok;
-    {
-        if (MODEL == MODEL_UPPER) {
-            Tri<N, false> l1, l2;
-            ok = chol_real<N>(z1.im, l1);
-            ok = chol_real<N>(z2.im, l2) && ok;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    e.re[i][j] = z2.re[i][j] - z1.re[i][j];
-                    e.im[i][j] = z2.im[i][j] - z1.im[i][j];
-                }
-            solve_left<N, false>(l1, e);
-            solve_right_t<N, false>(l2, e);
-        } else {
-            Tri<N, true> c1, c2;
-            ok = chol_id_minus_wwh<N>(z1, c1);
-            ok = chol_id_minus_wwh<N>(z2, c2) && ok;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    e.re[i][j] = z2.re[i][j] - z1.re[i][j];
-                    e.im[i][j] = z2.im[i][j] - z1.im[i][j];
-                }
-            solve_left<N, true>(c1, e);
-            solve_right_t<N, true>(c2, e);
-        }
-    }
     gram<N>(e, h);
     const bool conv = herm_eigenvalues<N>(h);
 
@@ -853,6 +823,173 @@ SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int met
     if (!conv) status |= ST_NO_CONVERGENCE;
     if (!d_finite(out)) status |= ST_NONFINITE;
     return out;
+}
+
+template <int N, int MODEL>
+SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
+                                   double inv_eps, double* __restrict__ vvd, int& status) {
+    CMat<N> e;
+    bool ok;
+    {
+        if (MODEL == MODEL_UPPER) {
+            Tri<N, false> l1, l2;
+            ok = chol_real<N>(z1.im, l1);
+            ok = chol_real<N>(z2.im, l2) && ok;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                    e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+                }
+            solve_left<N, false>(l1, e);
+            solve_right_t<N, false>(l2, e);
+        } else {
+            Tri<N, true> c1, c2;
+            ok = chol_id_minus_wwh<N>(z1, c1);
+            ok = chol_id_minus_wwh<N>(z2, c2) && ok;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                    e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+                }
+            solve_left<N, true>(c1, e);
+            solve_right_t<N, true>(c2, e);
+        }
+    }
+    return distance_from_e<N, MODEL>(e, ok, metric, w, inv_eps, vvd, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed points for the all-pairs matrix (Runner.build_distance_matrix, runner.py:142-154): every point enters
+// N pairs, so its factor is computed ONCE -- Y = L L^T (upper) / I - W W^H = C C^H (bounded) -- and stored INVERTED
+// next to the point's upper triangle:
+//     [ Re z (i <= j, row-major) | Im z (i <= j) | A = L^-1: diagonal, then the strict lower part (re[, im]) ]
+// PACK_LEN doubles per point.  A pair then costs E = A1 (Z2 - Z1) A2^T (two triangular products, no division, no
+// square root) + distance_from_e.
+// ---------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+struct PointPack {
+    static constexpr int TRI = N * (N + 1) / 2;
+    static constexpr int LOW = N * (N - 1) / 2;
+    static constexpr int OFF_IM = TRI;
+    static constexpr int OFF_DIAG = 2 * TRI;
+    static constexpr int OFF_LRE = 2 * TRI + N;
+    static constexpr int OFF_LIM = 2 * TRI + N + LOW;                       // bounded only
+    static constexpr int LEN = 2 * TRI + N + (MODEL == MODEL_UPPER ? LOW : 2 * LOW);
+};
+SYMPA_HD constexpr int tri_index(int n, int i, int j) { return i * n - i * (i - 1) / 2 + (j - i); }   // i <= j, row-major upper
+SYMPA_HD constexpr int low_index(int i, int j) { return i * (i - 1) / 2 + j; }                          // j < i, row-major strict lower
+
+// Packs one point; returns false when its factor does not exist (point outside the manifold).
+template <int N, int MODEL>
+SYMPA_HD bool pack_point(const CMat<N>& z, double (&p)[PointPack<N, MODEL>::LEN]) {
+    using P = PointPack<N, MODEL>;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = i; j < N; ++j) {
+            p[tri_index(N, i, j)] = z.re[i][j];
+            p[P::OFF_IM + tri_index(N, i, j)] = z.im[i][j];
+        }
+    Tri<N, MODEL != MODEL_UPPER> l;
+    bool ok;
+    if constexpr (MODEL == MODEL_UPPER) ok = chol_real<N>(z.im, l);
+    else ok = chol_id_minus_wwh<N>(z, l);
+    // A = L^-1, column by column:  A[j][j] = 1 / L[j][j],   A[i][j] = -(1 / L[i][i]) sum_{k=j}^{i-1} L[i][k] A[k][j]
+    double ar[N][N], ai[N][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        ar[j][j] = l.rdiag[j];
+        ai[j][j] = 0.0;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) {
+                tr = d_fma(l.re[i][k], ar[k][j], tr);
+                if (MODEL != MODEL_UPPER) {
+                    tr = d_fma(-l.im[i][k], ai[k][j], tr);
+                    ti = d_fma(l.re[i][k], ai[k][j], ti);
+                    ti = d_fma(l.im[i][k], ar[k][j], ti);
+                }
+            }
+            ar[i][j] = -tr * l.rdiag[i];
+            ai[i][j] = -ti * l.rdiag[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        p[P::OFF_DIAG + i] = ar[i][i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            p[P::OFF_LRE + low_index(i, j)] = ar[i][j];
+            if constexpr (MODEL != MODEL_UPPER) p[P::OFF_LIM + low_index(i, j)] = ai[i][j];
+        }
+    }
+    return ok;
+}
+
+// E = A1 (Z2 - Z1) A2^T from two packed points.  P1 / P2 are any indexable sources of doubles (registers, or scalar
+// registers for the wave-uniform row point of the all-pairs kernel).
+template <int N, int MODEL, class P1, class P2>
+SYMPA_HD void e_from_packed(const P1& p1, const P2& p2, CMat<N>& e) {
+    using P = PointPack<N, MODEL>;
+    constexpr bool CPLX = MODEL != MODEL_UPPER;
+    // D = Z2 - Z1 (symmetric: upper triangle)
+    double dr[N][N], di[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = i; j < N; ++j) {
+            dr[i][j] = p2[tri_index(N, i, j)] - p1[tri_index(N, i, j)];
+            di[i][j] = p2[P::OFF_IM + tri_index(N, i, j)] - p1[P::OFF_IM + tri_index(N, i, j)];
+            dr[j][i] = dr[i][j];
+            di[j][i] = di[i][j];
+        }
+    // T = A1 D   (A1 lower triangular)
+    double tr[N][N], ti[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            double xr = p1[P::OFF_DIAG + r] * dr[r][c], xi = p1[P::OFF_DIAG + r] * di[r][c];
+#pragma unroll
+            for (int k = 0; k < r; ++k) {
+                const double lr = p1[P::OFF_LRE + low_index(r, k)];
+                xr = d_fma(lr, dr[k][c], xr);
+                xi = d_fma(lr, di[k][c], xi);
+                if constexpr (CPLX) {
+                    const double li = p1[P::OFF_LIM + low_index(r, k)];
+                    xr = d_fma(-li, di[k][c], xr);
+                    xi = d_fma(li, dr[k][c], xi);
+                }
+            }
+            tr[r][c] = xr;
+            ti[r][c] = xi;
+        }
+    // E = T A2^T (plain transpose):  E[r][c] = sum_{k <= c} T[r][k] A2[c][k]
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            double xr = tr[r][c] * p2[P::OFF_DIAG + c], xi = ti[r][c] * p2[P::OFF_DIAG + c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) {
+                const double lr = p2[P::OFF_LRE + low_index(c, k)];
+                xr = d_fma(tr[r][k], lr, xr);
+                xi = d_fma(ti[r][k], lr, xi);
+                if constexpr (CPLX) {
+                    const double li = p2[P::OFF_LIM + low_index(c, k)];
+                    xr = d_fma(-ti[r][k], li, xr);
+                    xi = d_fma(tr[r][k], li, xi);
+                }
+            }
+            e.re[r][c] = xr;
+            e.im[r][c] = xi;
+        }
 }
 
 // Same, reading the two points straight from memory (lane-per-row loads; used for n > 4 and on the host).

@@ -85,6 +85,7 @@ def _weights(metric, weights, n, device):
 FLAG_LOW_LDS = 1
 FLAG_GENERIC = 2      # spd: force the runtime-n one-lane-per-pair kernel
 FLAG_ANY_ORDER = 4    # forward: dispatch without the in-order barrier bit (independent batches of one stream overlap)
+FLAG_NO_SYMMETRY = 16  # all_pairs_dist(packed=True): evaluate (i, j) and (j, i) separately
 FLAG_FUSE = 8         # BatchedForward: up to MAX_FUSED_BATCHES consecutive batches per kernel launch
 MAX_FUSED_BATCHES = 32
 
@@ -485,7 +486,7 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None,
 
 
 def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0, row_begin=0,
-                   row_count=None, eps=None, out=None):
+                   row_count=None, eps=None, out=None, packed=None, workspace=None, flags=0):
     """Rows [row_begin, row_begin + row_count) of the N x N distance matrix (C-ABI sympa_all_pairs_dist;
     reference Runner.build_distance_matrix, runner.py:142-154).  Returns [row_count, N] fp64."""
     lib = _lib.load()
@@ -502,6 +503,30 @@ def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None
         sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(tab.device)
+    # per-point factor reuse (C-ABI sympa_all_pairs_dist_packed) where the build has it; packed=False forces the
+    # pairwise kernel in index-free mode (the tests compare the two)
+    need = lib.sympa_all_pairs_workspace_bytes(num_rows, n, MODEL_IDS[model]) if model in MODEL_IDS else 0
+    if packed is None:
+        packed = need > 0
+    if packed:
+        if need <= 0:
+            raise _lib.SympaHipError(f"no packed all-pairs kernel for dims {n}")
+        if workspace is None:
+            workspace = torch.empty(need // 8, dtype=torch.float64, device=tab.device)
+        elif workspace.numel() * workspace.element_size() < need or not workspace.is_cuda:
+            raise ValueError("workspace too small")
+        with torch.cuda.device(tab.device):
+            rc = lib.sympa_all_pairs_dist_packed(tab.data_ptr(), num_rows, n, int(row_begin), row_count,
+                                                 MODEL_IDS[model], METRIC_IDS[metric],
+                                                 None if w is None else w.data_ptr(), eps,
+                                                 None if sc is None else sc.data_ptr(), float(scale_coef),
+                                                 out.data_ptr(), workspace.data_ptr(),
+                                                 workspace.numel() * workspace.element_size(), st.data_ptr(), int(flags),
+                                                 _stream())
+        _lib.check(rc)
+        if _debug:
+            check_status(tab.device)
+        return out
     with torch.cuda.device(tab.device):
         rc = lib.sympa_all_pairs_dist(tab.data_ptr(), num_rows, n, int(row_begin), row_count, MODEL_IDS[model],
                                       METRIC_IDS[metric], None if w is None else w.data_ptr(), eps,

@@ -41,6 +41,45 @@ extern "C" int sympa_hostsim_dist(const double* z1, const double* z2, int64_t b,
     }
 }
 
+namespace {
+template <int N, int MODEL>
+void run_packed(const double* z1, const double* z2, int64_t b, int metric, const double* w, double eps, double* out,
+                int32_t* status) {
+    int st = 0;
+    for (int64_t i = 0; i < b; ++i) {
+        sympa::CMat<N> a, c, e;
+        sympa::load_point<N>(z1 + i * 2 * N * N, a);
+        sympa::load_point<N>(z2 + i * 2 * N * N, c);
+        double p1[sympa::PointPack<N, MODEL>::LEN], p2[sympa::PointPack<N, MODEL>::LEN];
+        const bool ok1 = sympa::pack_point<N, MODEL>(a, p1);
+        const bool ok2 = sympa::pack_point<N, MODEL>(c, p2);
+        sympa::e_from_packed<N, MODEL>(p1, p2, e);
+        out[i] = sympa::distance_from_e<N, MODEL>(e, ok1 && ok2, metric, w, 1.0 / eps, nullptr, st);
+    }
+    if (status) *status = st;
+}
+template <int N>
+void run_packed_n(const double* z1, const double* z2, int64_t b, int model, int metric, const double* w, double eps,
+                  double* out, int32_t* status) {
+    if (model == sympa::MODEL_UPPER) run_packed<N, sympa::MODEL_UPPER>(z1, z2, b, metric, w, eps, out, status);
+    else run_packed<N, sympa::MODEL_BOUNDED>(z1, z2, b, metric, w, eps, out, status);
+}
+}  // namespace
+
+// the all-pairs kernel's per-pair path: both points packed (inverted factor), E = A1 (Z2 - Z1) A2^T
+extern "C" int sympa_hostsim_dist_packed(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
+                                         const double* w, double eps, double* out, int32_t* status) {
+    switch (n) {
+        case 1: run_packed_n<1>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        case 2: run_packed_n<2>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        case 3: run_packed_n<3>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        case 4: run_packed_n<4>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        case 5: run_packed_n<5>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        case 6: run_packed_n<6>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        default: return -2;
+    }
+}
+
 extern "C" int sympa_hostsim_dist_generic(const double* z1, const double* z2, int64_t b, int n, int model, int metric,
                                           const double* w, double eps, double* out, double* vvd, int32_t* status) {
     if (n < 1 || n > sympa::GENERIC_MAX_N) return -2;

@@ -212,8 +212,9 @@ def test_all_pairs_matrix_equals_runner_loop(dev, model, dims):
         want[node] = d
     assert full.shape == (n_nodes, n_nodes) and torch.all(full.diagonal() == 0)
     assert rel_err(full.cpu(), want) < (TOL if dims <= 6 else 1e-7)
-    # n >= 5: the lockstep QL makes the last bits depend on the pairs that share a wave
-    assert torch.equal(block, full[17:57]) if dims <= 4 else rel_err(block.cpu(), full[17:57].cpu()) < 1e-12
+    # n >= 5: the lockstep QL makes the last bits depend on the pairs that share a wave; n <= 4: the full matrix stores
+    # d(j, i) for the entries below the diagonal tiles (packed kernel), a row block evaluates (i, j) itself
+    assert rel_err(block.cpu(), full[17:57].cpu()) < 1e-12
     assert rel_err(full.cpu(), full.cpu().T) < 1e-10
 
 
@@ -347,7 +348,7 @@ def test_low_lds_gather_variants_bit_identical(dev, model, n):
     # all-pairs matrix with N >= 363 rows (deep grid -> low form) against the pairwise kernel in its default form
     N2 = 400
     t2 = table[:N2].contiguous()
-    mat = ops.all_pairs_dist(t2, model, "riem")
+    mat = ops.all_pairs_dist(t2, model, "riem", packed=False)
     ii, jj = torch.meshgrid(torch.arange(N2, device=dev), torch.arange(N2, device=dev), indexing="ij")
     trip = torch.stack((ii.reshape(-1), jj.reshape(-1)), 1)
     chunks = [ops.model_forward(t2, trip[k:k + 60000].contiguous(), model, "riem", flags=0)
@@ -452,3 +453,42 @@ def test_integration_md_stub_runs_on_the_gpu(dev):
             ref.sum().backward()
             assert torch.equal(d.detach(), ref.detach())
             assert torch.equal(z1.grad, y1.grad) and torch.equal(z2.grad, y2.grad)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("model", MODELS)
+def test_all_pairs_packed_kernel(dev, model, n):
+    """sympa_all_pairs_dist_packed (every point factored once, inverted factor, wave-uniform row point, symmetric full
+    matrix) against the pairwise kernel in index-free mode and against the oracle; ragged N, row blocks at odd offsets."""
+    from sympa_amd import data, ops
+    N = 333
+    table = data.trained_like_table(N, n, model=model, seed=17).to(dev)
+    scale = torch.tensor([0.8], device=dev)
+    w = torch.linspace(-0.2, 1.1, n).to(dev)
+    for metric in METRICS:
+        full = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=True)
+        ref = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=False)
+        ops.check_status(dev)
+        assert torch.all(full.diagonal() == 0)
+        if n >= 3:
+            assert torch.equal(full, full.T)                 # symmetric mode: d(i, j) evaluated once, stored twice
+            both = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=True, flags=ops.FLAG_NO_SYMMETRY)
+            assert rel_err(both.cpu(), ref.cpu()) < 1e-11 and torch.all(both.diagonal() == 0)
+        # symmetric mode stores d(i, j) also at (j, i), where the pairwise kernel evaluates d(j, i): two runs of the
+        # Jacobi iteration on different matrices with the same spectrum (measured agreement ~3e-11 at n = 4)
+        assert rel_err(full.cpu(), ref.cpu()) < (2e-10 if n >= 3 else 1e-11), (model, n, metric)
+        for rb, rc in ((0, 1), (5, 64), (63, 66), (100, 233), (332, 1)):
+            blk = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, row_begin=rb, row_count=rc, packed=True)
+            assert blk.shape == (rc, N)
+            assert rel_err(blk.cpu(), ref[rb:rb + rc].cpu()) < 1e-11, (model, n, metric, rb, rc)
+    ii, jj = torch.meshgrid(torch.arange(40), torch.arange(N), indexing="ij")
+    want = so.model_forward(table.cpu(), torch.stack((ii.reshape(-1), jj.reshape(-1)), 1), model, "riem",
+                            scale=scale.cpu(), scale_coef=2.0).reshape(40, N)
+    got = ops.all_pairs_dist(table, model, "riem", None, scale, 2.0, packed=True)[:40].cpu()
+    assert rel_err(got, want, atol=1e-9) < TOL
+    # a point outside the manifold is flagged by the pack kernel
+    bad = table.clone()
+    bad[7, 1] = -bad[7, 1] if model == "upper" else 3.0 * bad[7, 1] + 2.0
+    ops.all_pairs_dist(bad, model, "riem", packed=True)
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)

@@ -112,3 +112,28 @@ def test_nonfinite_input_generic_large_n(n):
         for metric in ("riem", "finf", "fmin"):
             out, _, st = hostsim_dist(z1.numpy(), z2.numpy(), model, metric, generic=True)
             assert np.isnan(out[0]) and (st & 2)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("model", MODELS)
+def test_packed_point_path_of_the_all_pairs_kernel(model, n):
+    """All-pairs matrix (runner.py:142-154): points are packed once with their INVERTED Cholesky factor and a pair costs
+    E = A1 (Z2 - Z1) A2^T.  Same distances as the solve-based pairwise arithmetic and as the oracle; goldens too."""
+    from tests.helpers import hostsim_dist_packed
+    g = torch.Generator().manual_seed(500 + n)
+    for s in (1e-3, 0.3, 0.8):
+        z1, z2 = points(model, 60, n, s, g), points(model, 60, n, s, g)
+        z2[:5] = z1[:5]                                    # d(x, x) = 0 exactly
+        for metric in ("riem", "finf", "wsum"):
+            w = torch.linspace(-0.3, 1.2, n)
+            got, st = hostsim_dist_packed(z1.numpy(), z2.numpy(), model, metric, w.numpy())
+            ref, _, _ = hostsim_dist(z1.numpy(), z2.numpy(), model, metric, w.numpy())
+            assert st == 0 and np.all(got[:5] == 0.0)
+            assert rel_err(got, ref) < 1e-10, (model, n, s, metric)
+            assert rel_err(got, so.manifold_dist(model, z1, z2, metric, w)) < TOL
+    if n in (2, 3, 4):
+        gold = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
+        for case in gold["case_names"]:
+            got, st = hostsim_dist_packed(gold[f"{case}__z1"], gold[f"{case}__z2"], model, "riem")
+            tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
+            assert st == 0 and rel_err(got, gold[f"{case}__riem"]) < tol, (model, n, case)
