@@ -191,6 +191,9 @@ int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n,
                                    double* out, int32_t* status, int flags, void* stream);
 int sympa_scatter_add_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int n,
                            int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream);
+/* the same for rows of any length (spd: row_doubles = n^2) */
+int sympa_scatter_add_flat_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int row_doubles,
+                                int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream);
 
 /* ---- optimiser-side manifold operations over table rows (one [2,n,n] point per row) --------------------
  * egrad2rgrad: UpperHalfManifold.egrad2rgrad (sympa/manifolds/upper_half.py:25-40, Y G Y on both planes) /
@@ -234,6 +237,28 @@ int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, doubl
 int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                             const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
                             double* out, int32_t* status, int flags, void* stream);
+
+/* ---- SPD model, training path (PARITY UNPINNED like the forward; formulas restated from geoopt's published source,
+ * pinned by 50-digit finite differences, tests/golden/spd_n*.npz) ----
+ * sympa_spd_backward_rows: backward of SymmetricPositiveDefinite.dist / of Model.forward for the spd model
+ * (sympa/model.py:16-41 under runner.py:105).  Pair i = (x[src[i]], y[dst[i]]) (src = dst = NULL: rows i of x and y).
+ * Either grad_out [b] (dLoss/d out) or graph_dist [b] is given; with graph_dist the AverageDistortionLoss of
+ * sympa/losses.py:10-19 is fused in: loss[0] += loss_scale * sum |(out / graph_dist)^2 - 1|.
+ * grad_x_rows / grad_y_rows [b, n, n] are WRITTEN with the (symmetric) gradient rows of the two points of each pair;
+ * accumulate them into a table gradient with sympa_scatter_add_flat_rows.  grad_scale [1] accumulated, out [b] optional. */
+int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, int n, const int64_t* src,
+                            int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
+                            double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
+                            double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
+                            int32_t* status, int flags, void* stream);
+/* geoopt SymmetricPositiveDefinite.egrad2rgrad (x sym(u) x), .projx (V |lambda| V^T of sym(x); projected_count += rows with
+ * a negative eigenvalue), and one geoopt.optim.RiemannianSGD step over the table in place,
+ *     x <- retr(x, -lr * egrad2rgrad(x, grad + weight_decay * x)),   retr(x, u) = sym(x + u + u x^-1 u / 2),
+ * with the gradient clip of runner.py:115 folded in when total_sqnorm (device, squared total norm) is given. */
+int sympa_spd_egrad2rgrad(const double* x, const double* u, int64_t b, int n, double* out, void* stream);
+int sympa_spd_projx(const double* x, int64_t b, int n, double* out, int32_t* projected_count, int32_t* status, void* stream);
+int sympa_spd_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, double lr, double weight_decay,
+                        const double* total_sqnorm, double max_norm, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

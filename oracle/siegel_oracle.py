@@ -335,3 +335,24 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0):
     if scale is None:
         scale = torch.tensor([scale_coef * 1.0], dtype=table.dtype)
     return d * get_scale(scale, scale_coef)
+
+
+def spd_egrad2rgrad(x, u):
+    """geoopt SymmetricPositiveDefinite.egrad2rgrad: x @ proju(x, u) @ x with proju = sym (restated; unpinned)."""
+    return x @ sym(u) @ x
+
+
+def spd_retr(x, u):
+    """geoopt SymmetricPositiveDefinite.retr: sym(x + u + 1/2 u x^-1 u) (restated; unpinned)."""
+    return sym(x + u + 0.5 * u @ torch.linalg.inv(x) @ u)
+
+
+def spd_projx(x):
+    """geoopt SymmetricPositiveDefinite.projx: sym_funcm(sym(x), abs) (restated; unpinned)."""
+    return _sym_funcm(sym(x), torch.abs)
+
+
+def spd_rsgd_step(table, grad, lr, weight_decay=0.0):
+    """geoopt.optim.RiemannianSGD.step (momentum 0, stabilize None) on an spd table."""
+    g = grad + weight_decay * table
+    return spd_retr(table, -lr * spd_egrad2rgrad(table, g))

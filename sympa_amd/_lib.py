@@ -32,6 +32,11 @@ SYMBOLS = (
     "sympa_rsgd_step_clipped",
     "sympa_spd_dist_fwd",
     "sympa_spd_model_forward",
+    "sympa_scatter_add_flat_rows",
+    "sympa_spd_backward_rows",
+    "sympa_spd_egrad2rgrad",
+    "sympa_spd_projx",
+    "sympa_spd_rsgd_step",
 )
 
 _c_double_p = ctypes.c_void_p
@@ -142,6 +147,22 @@ def load():
     lib.sympa_spd_model_forward.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p,
                                             ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p,
                                             _c_i32_p, ctypes.c_int, ctypes.c_void_p]
+    lib.sympa_scatter_add_flat_rows.restype = ctypes.c_int
+    lib.sympa_scatter_add_flat_rows.argtypes = [_c_double_p, _c_i64_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_int64, ctypes.c_double, _c_double_p, _c_i32_p, ctypes.c_void_p]
+    lib.sympa_spd_backward_rows.restype = ctypes.c_int
+    lib.sympa_spd_backward_rows.argtypes = [
+        _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64,
+        ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_double, _c_double_p,
+        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+    ]
+    lib.sympa_spd_egrad2rgrad.restype = ctypes.c_int
+    lib.sympa_spd_egrad2rgrad.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, ctypes.c_void_p]
+    lib.sympa_spd_projx.restype = ctypes.c_int
+    lib.sympa_spd_projx.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, _c_i32_p, _c_i32_p, ctypes.c_void_p]
+    lib.sympa_spd_rsgd_step.restype = ctypes.c_int
+    lib.sympa_spd_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_double, _c_double_p, ctypes.c_double, _c_i32_p, ctypes.c_void_p]
     _lib = lib
     return lib
 

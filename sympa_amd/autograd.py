@@ -66,3 +66,56 @@ def model_forward(table, triplets, model, metric, weights=None, scale=None, scal
     if _needs_grad(table, weights, scale):
         return _ModelForwardFn.apply(table, triplets, weights, scale, model, metric, scale_coef)
     return ops.model_forward(table, triplets, model, metric, weights, scale, scale_coef)
+
+
+class _SpdDistFn(torch.autograd.Function):
+    """SymmetricPositiveDefinite.dist(x, y) with the analytic backward (sympa_spd_backward_rows)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        ctx.save_for_backward(x, y)
+        return ops.spd_dist_forward(x, y)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, y = ctx.saved_tensors
+        rows, _ = ops.spd_backward_rows(x, y, grad_out=grad_out)
+        b = x.shape[0]
+        return rows[:b], rows[b:]
+
+
+def spd_dist(x, y):
+    if _needs_grad(x, y):
+        return _SpdDistFn.apply(x, y)
+    return ops.spd_dist_forward(x, y)
+
+
+class _SpdModelForwardFn(torch.autograd.Function):
+    """Model.forward for the spd model: dense [N, n, n] table gradient = per-pair rows + scatter-add kernel."""
+
+    @staticmethod
+    def forward(ctx, table, triplets, scale, scale_coef):
+        ctx.save_for_backward(table, triplets, scale if scale is not None else torch.empty(0, device=table.device))
+        ctx.cfg = (scale_coef, scale is not None)
+        return ops.spd_model_forward(table, triplets, scale, scale_coef)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        table, triplets, scale = ctx.saved_tensors
+        scale_coef, has_scale = ctx.cfg
+        scale = scale if has_scale else None
+        gs = torch.zeros(1, dtype=torch.float64, device=table.device) if has_scale else None
+        rows, _ = ops.spd_backward_rows(table, table, triplets, grad_out=grad_out, scale=scale, scale_coef=scale_coef,
+                                        grad_scale=gs)
+        gt = torch.zeros_like(table)
+        b = triplets.shape[0]
+        idx = torch.cat((triplets[:, 0], triplets[:, 1])).contiguous()
+        ops.scatter_add_flat_rows_(gt, rows.reshape(2 * b, -1), idx)
+        return (gt if ctx.needs_input_grad[0] else None, None,
+                gs.reshape(scale.shape) if (has_scale and ctx.needs_input_grad[2]) else None, None)
+
+
+def spd_model_forward(table, triplets, scale=None, scale_coef=1.0):
+    if _needs_grad(table, scale):
+        return _SpdModelForwardFn.apply(table, triplets, scale, scale_coef)
+    return ops.spd_model_forward(table, triplets, scale, scale_coef)

@@ -172,11 +172,18 @@ int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream
 
 int sympa_scatter_add_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int n,
                            int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream) {
-    if (count < 0 || n < 1 || n > SYMPA_MAX_DIMS_GENERIC) return fail(SYMPA_ERR_BAD_ARG, "bad row count / dims");
+    if (n < 1 || n > SYMPA_MAX_DIMS_GENERIC) return fail(SYMPA_ERR_BAD_ARG, "bad dims");
+    return sympa_scatter_add_flat_rows(rows, idx, idx_stride, count, 2 * n * n, num_rows, alpha, grad_table, status, stream);
+}
+
+int sympa_scatter_add_flat_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int row_doubles,
+                                int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream) {
+    if (count < 0 || row_doubles < 1 || row_doubles > 2 * SYMPA_MAX_DIMS_GENERIC * SYMPA_MAX_DIMS_GENERIC)
+        return fail(SYMPA_ERR_BAD_ARG, "bad row count / row length");
     if (count == 0) return 0;
     if (rows == nullptr || idx == nullptr || grad_table == nullptr || num_rows <= 0)
         return fail(SYMPA_ERR_BAD_ARG, "null buffer / empty table");
-    const int rowd = 2 * n * n;
+    const int rowd = row_doubles;
     const int64_t want = (count * rowd + BLOCK - 1) / BLOCK;
     const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows, idx,

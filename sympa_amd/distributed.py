@@ -101,7 +101,7 @@ class GradientExchange:
             self.small = torch.zeros(n_small, dtype=torch.float64, device=dev) if n_small else None
         if scatter_fn is None:
             from sympa_amd import ops
-            scatter_fn = ops.scatter_add_rows_          # HIP kernel; raises on CPU tensors (no CPU path in the product)
+            scatter_fn = ops.scatter_add_flat_rows_     # HIP kernel; raises on CPU tensors (no CPU path in the product)
         self.scatter_fn = scatter_fn
 
     # bytes this rank SENDS per step (ring all-reduce: 2 (G-1)/G of the buffer; all-gather: its own block to G-1 peers)

@@ -2,8 +2,9 @@
 
 In the reference this class IS geoopt.manifolds.SymmetricPositiveDefinite() (default affine-invariant metric):
 none of its arithmetic is in the reference tree, geoopt is not installed here, and no reference test touches
-it -- parity is UNPINNED: the oracle restates geoopt's published formulas and the kernel is checked
-against that restatement only.  Forward distance = HIP kernel; no backward kernel yet (differentiating raises)."""
+it -- parity is UNPINNED with respect to geoopt: the oracle restates geoopt's published formulas, and the
+kernels are checked against that restatement and against 50-digit mpmath evaluations of the same formulas
+(tests/golden/spd_n*.npz).  dist (forward and backward), egrad2rgrad, retr, projx are HIP kernels."""
 import torch
 
 from sympa_amd import ops
@@ -28,11 +29,22 @@ class SymmetricPositiveDefinite(Manifold):
         self.projected_points = 0
 
     def dist(self, x, y, *, keepdim=False):
-        """|| log(x^-1/2 y x^-1/2) ||_F  (geoopt SymmetricPositiveDefinite.dist, AIM)."""
-        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
-            raise NotImplementedError("the spd model has a forward kernel only (no backward yet)")
-        d = ops.spd_dist_forward(x, y)
+        """|| log(x^-1/2 y x^-1/2) ||_F  (geoopt SymmetricPositiveDefinite.dist, AIM); differentiable."""
+        from sympa_amd import autograd as sa
+        d = sa.spd_dist(x, y)
         return d.unsqueeze(-1).unsqueeze(-1) if keepdim else d
+
+    def egrad2rgrad(self, x, u):
+        """geoopt: x @ sym(u) @ x."""
+        return ops.spd_egrad2rgrad(x, u)
+
+    def proju(self, x, u):
+        return _sym(u)
+
+    def retr(self, x, u):
+        """geoopt: sym(x + u + 1/2 u x^-1 u), evaluated by the step kernel with lr = -1 on egrad-free input: host-side
+        torch here (init / tests); the optimiser uses the fused sympa_spd_rsgd_step."""
+        return _sym(x + u + 0.5 * u @ torch.linalg.inv(x) @ u)
 
     def _check_shape(self, shape, name):
         ok = len(shape) >= 2 and shape[-1] == shape[-2]
@@ -44,10 +56,13 @@ class SymmetricPositiveDefinite(Manifold):
         ok = bool((torch.linalg.eigvalsh(x) > -atol).all())
         return ok, None if ok else "eigenvalues of x are not all greater than 0."
 
-    def projx(self, x):     # geoopt: symmetrise and clamp the eigenvalues (host-side helper, not a hot path)
+    def projx(self, x):
+        """geoopt: sym_funcm(sym(x), abs) -- HIP kernel for device tensors, torch on the host (initialisation)."""
+        if x.is_cuda:
+            return ops.spd_projx(x)
         s = _sym(x)
         lam, v = torch.linalg.eigh(s)
-        return v @ torch.diag_embed(lam.clamp(min=1e-15)) @ v.transpose(-1, -2)
+        return v @ torch.diag_embed(lam.abs()) @ v.transpose(-1, -2)
 
     def random(self, *size, dtype=None, device=None, **kwargs):
         """geoopt SymmetricPositiveDefinite.random: expm(sym(0.5 * randn))."""

@@ -27,10 +27,7 @@ class Model(nn.Module):
         (model.py:16-30)."""
         man = self.manifold
         if man.model_name == "spd":
-            from sympa_amd import ops
-            if torch.is_grad_enabled() and (self.embeddings.embeds.requires_grad or self.scale.requires_grad):
-                raise NotImplementedError("the spd model has a forward kernel only: use torch.no_grad()")
-            return ops.spd_model_forward(self.embeddings.embeds, input_triplet, self.scale, self.scale_coef)
+            return sa.spd_model_forward(self.embeddings.embeds, input_triplet, self.scale, self.scale_coef)
         weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
         return sa.model_forward(self.embeddings.embeds, input_triplet, man.model_name, man.metric.kind.value,
                                 weights, self.scale, self.scale_coef)
@@ -46,6 +43,25 @@ class Model(nn.Module):
         dev = table.device
         if table.grad is None:
             table.grad = torch.zeros_like(table.data)
+        if man.model_name == "spd":
+            # two launches: per-pair gradient rows (backward + loss fused), then the coalesced scatter-add
+            gs = None
+            if self.scale.requires_grad:
+                if self.scale.grad is None:
+                    self.scale.grad = torch.zeros_like(self.scale.data)
+                gs = self.scale.grad
+            loss = torch.zeros(1, dtype=torch.float64, device=dev)
+            b = input_triplet.shape[0]
+            n = table.shape[-1]
+            ws = getattr(self, "_spd_rows", None)
+            if ws is None or ws.shape[0] < 2 * b or ws.device != dev:
+                ws = torch.empty(2 * b, n, n, dtype=torch.float64, device=dev)
+                self._spd_rows = ws
+            ops.spd_backward_rows(table.data, table.data, input_triplet, graph_dist=graph_distances, scale=self.scale.data,
+                                  scale_coef=self.scale_coef, loss_scale=loss_scale, loss=loss, grad_scale=gs, rows=ws)
+            idx = torch.cat((input_triplet[:, 0], input_triplet[:, 1])).contiguous()
+            ops.scatter_add_flat_rows_(table.grad, ws[:2 * b].reshape(2 * b, -1), idx)
+            return loss
         wsum = man.metric.kind is MetricType.WEIGHTED_SUM
         weights = gw = None
         if wsum:
@@ -71,6 +87,17 @@ class Model(nn.Module):
         from sympa_amd import ops
         man = self.manifold
         table = self.embeddings.embeds
+        if man.model_name == "spd":
+            gs = None
+            if self.scale.requires_grad:
+                if self.scale.grad is None:
+                    self.scale.grad = torch.zeros_like(self.scale.data)
+                gs = self.scale.grad
+            loss = torch.zeros(1, dtype=torch.float64, device=table.device)
+            ops.spd_backward_rows(table.data, table.data, input_triplet, graph_dist=graph_distances, scale=self.scale.data,
+                                  scale_coef=self.scale_coef, loss_scale=loss_scale, loss=loss, grad_scale=gs,
+                                  rows=grad_rows.view(-1, table.shape[-1], table.shape[-1]))
+            return loss
         wsum = man.metric.kind is MetricType.WEIGHTED_SUM
         weights = gw = None
         if wsum:

@@ -588,3 +588,119 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, fla
     if _debug:
         check_status(tab.device)
     return out
+
+
+def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale=None, scale_coef=1.0, loss_scale=1.0,
+                      loss=None, grad_scale=None, rows=None, want_out=False):
+    """Backward of the spd distance (C-ABI sympa_spd_backward_rows).  triplets None: pair i = (x[i], y[i]); otherwise
+    x is y is the [N, n, n] table and pair i = (table[triplets[i, 0]], table[triplets[i, 1]]).  Give grad_out [b] or
+    graph_dist [b] (fused AverageDistortionLoss, accumulated into `loss`).  Returns (rows [2b, n, n], out or None):
+    rows [0, b) = gradient rows of the first points, [b, 2b) of the second."""
+    lib = _lib.load()
+    _need_gpu(x, "x"); _need_gpu(y, "y")
+    if x.dtype != torch.float64 or x.dim() != 3 or x.shape[1] != x.shape[2]:
+        raise ValueError(f"spd points / table must be float64 [., n, n], got {tuple(x.shape)}")
+    x = x.detach(); y = y.detach()
+    x = x if x.is_contiguous() else x.contiguous()
+    y = y if y.is_contiguous() else y.contiguous()
+    n = x.shape[1]
+    dev = x.device
+    if triplets is not None:
+        if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
+            raise TypeError("triplets must be an int64 [b, >=2] tensor")
+        if triplets.stride(1) != 1:
+            triplets = triplets.contiguous()
+        b = triplets.shape[0]
+        stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+        sp, dp = triplets.data_ptr(), triplets.data_ptr() + 8
+    else:
+        b, stride, sp, dp = x.shape[0], 0, None, None
+    if rows is None:
+        rows = torch.empty(2 * b, n, n, dtype=torch.float64, device=dev)
+    elif rows.numel() < 2 * b * n * n or not rows.is_contiguous():
+        raise ValueError("rows buffer too small")
+    out = torch.empty(b, dtype=torch.float64, device=dev) if want_out else None
+    if b == 0:
+        return rows, out
+    go = None if grad_out is None else grad_out.detach().to(torch.float64).contiguous()
+    gd = None if graph_dist is None else graph_dist.detach().to(torch.float64).contiguous()
+    sc = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=dev, dtype=torch.float64).contiguous()
+    st = _status_buf(dev)
+    with torch.cuda.device(dev):
+        rc = lib.sympa_spd_backward_rows(
+            x.data_ptr(), y.data_ptr(), x.shape[0], n, sp, stride, dp, stride, b, None if sc is None else sc.data_ptr(),
+            float(scale_coef), None if go is None else go.data_ptr(), None if gd is None else gd.data_ptr(),
+            float(loss_scale), None if loss is None else loss.data_ptr(), rows.data_ptr(),
+            rows.data_ptr() + b * n * n * 8, None if grad_scale is None else grad_scale.data_ptr(),
+            None if out is None else out.data_ptr(), st.data_ptr(), 0, _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(dev)
+    return rows, out
+
+
+def scatter_add_flat_rows_(grad_table, rows, idx, alpha=1.0):
+    """grad_table[idx[r]] += alpha * rows[r] for rows of any length (C-ABI sympa_scatter_add_flat_rows)."""
+    lib = _lib.load()
+    _need_gpu(grad_table, "grad_table"); _need_gpu(rows, "rows"); _need_gpu(idx, "idx")
+    if grad_table.dtype != torch.float64 or rows.dtype != torch.float64 or idx.dtype != torch.int64:
+        raise TypeError("float64 rows / table and int64 indices expected")
+    if not (grad_table.is_contiguous() and rows.is_contiguous() and idx.dim() == 1):
+        raise ValueError("contiguous tensors and a 1-d index list expected")
+    count = idx.shape[0]
+    rowd = grad_table[0].numel()
+    if rows.numel() < count * rowd:
+        raise ValueError("rows must hold one gradient row per index")
+    st = _status_buf(grad_table.device)
+    with torch.cuda.device(grad_table.device):
+        rc = lib.sympa_scatter_add_flat_rows(rows.data_ptr(), idx.data_ptr(), idx.stride(0), count, rowd,
+                                             grad_table.shape[0], float(alpha), grad_table.data_ptr(), st.data_ptr(), _stream())
+    _lib.check(rc)
+    return grad_table
+
+
+def _spd_rows(t, name):
+    _need_gpu(t, name)
+    if t.dtype != torch.float64 or t.dim() != 3 or t.shape[1] != t.shape[2]:
+        raise ValueError(f"{name} must be a float64 [b, n, n] tensor, got {tuple(t.shape)} {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def spd_egrad2rgrad(x, u):
+    lib = _lib.load()
+    x, u = _spd_rows(x.detach(), "x"), _spd_rows(u.detach(), "u")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.sympa_spd_egrad2rgrad(x.data_ptr(), u.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream())
+    _lib.check(rc)
+    return out
+
+
+def spd_projx(x, counter=None):
+    lib = _lib.load()
+    x = _spd_rows(x.detach(), "x")
+    out = torch.empty_like(x)
+    st = _status_buf(x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.sympa_spd_projx(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(),
+                                 None if counter is None else counter.data_ptr(), st.data_ptr(), _stream())
+    _lib.check(rc)
+    return out
+
+
+def spd_rsgd_step_(table, grad, lr, weight_decay=0.0, clip_sqnorm=None, max_norm=None):
+    """In-place geoopt RiemannianSGD step over an spd table (C-ABI sympa_spd_rsgd_step)."""
+    lib = _lib.load()
+    _need_gpu(table, "table")
+    if not table.is_contiguous():
+        raise ValueError("table must be contiguous for the in-place step")
+    grad = _spd_rows(grad.detach(), "grad")
+    st = _status_buf(table.device)
+    with torch.cuda.device(table.device):
+        rc = lib.sympa_spd_rsgd_step(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[1], float(lr),
+                                     float(weight_decay), None if clip_sqnorm is None else clip_sqnorm.data_ptr(),
+                                     float(max_norm) if max_norm is not None else 0.0, st.data_ptr(), _stream())
+    _lib.check(rc)
+    return table

@@ -11,6 +11,7 @@ import torch
 
 from sympa_amd import ops
 from sympa_amd.manifolds.siegel_manifold import SiegelManifold
+from sympa_amd.manifolds.spd import SymmetricPositiveDefinite
 
 
 class RiemannianSGD(torch.optim.Optimizer):
@@ -50,7 +51,11 @@ class RiemannianSGD(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 manifold = getattr(p, "manifold", None)
-                if isinstance(manifold, SiegelManifold) and p.is_cuda and sq is not None:
+                if isinstance(manifold, SymmetricPositiveDefinite) and p.is_cuda:
+                    # geoopt's SPD step: retr(x, -lr x sym(g + wd x) x), one kernel over the table
+                    ops.spd_rsgd_step_(p.data, p.grad, lr, wd, clip_sqnorm=sq,
+                                       max_norm=self.clip_max_norm if sq is not None else None)
+                elif isinstance(manifold, SiegelManifold) and p.is_cuda and sq is not None:
                     ops.rsgd_step_(p.data, p.grad, manifold.model_name, lr, wd, counter=manifold.projected_counter(p.device),
                                    clip_sqnorm=sq, max_norm=self.clip_max_norm)
                 elif isinstance(manifold, SiegelManifold) and p.is_cuda:

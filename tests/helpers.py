@@ -61,7 +61,8 @@ def hostsim():
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_table_math.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_generic.hpp"),
-                os.path.join(ROOT, "sympa_amd", "csrc", "spd_math.hpp")]
+                os.path.join(ROOT, "sympa_amd", "csrc", "spd_math.hpp"),
+                os.path.join(ROOT, "sympa_amd", "csrc", "spd_math_bwd.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], cwd=d)
         _hostsim = ctypes.CDLL(so)
@@ -159,3 +160,36 @@ def hostsim_spd_dist(x, y):
                                     P(out.ctypes.data), ctypes.byref(st))
     assert rc == 0
     return out, st.value
+
+
+def hostsim_spd_bwd(x, y):
+    """(dist, d dist / dx, d dist / dy) from the g++ build of spd_math_bwd.hpp"""
+    lib = hostsim()
+    P = ctypes.c_void_p
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros(x.shape[0])
+    gx, gy = np.zeros_like(x), np.zeros_like(y)
+    st = ctypes.c_int32(0)
+    rc = lib.sympa_hostsim_spd_bwd(P(x.ctypes.data), P(y.ctypes.data), ctypes.c_int64(x.shape[0]), x.shape[1],
+                                   P(out.ctypes.data), P(gx.ctypes.data), P(gy.ctypes.data), ctypes.byref(st))
+    assert rc == 0
+    return out, gx, gy, st.value
+
+
+def hostsim_spd_table(op, x, g=None, lr=0.0, wd=0.0):
+    """op: 'projx' | 'rsgd' | 'egrad2rgrad' -> (rows, moved)"""
+    lib = hostsim()
+    P = ctypes.c_void_p
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    gp = None
+    if g is not None:
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        gp = P(g.ctypes.data)
+    moved = ctypes.c_int32(0)
+    st = lib.sympa_hostsim_spd_table({"projx": 0, "rsgd": 1, "egrad2rgrad": 2}[op], x.shape[1], P(x.ctypes.data), gp,
+                                     P(out.ctypes.data), ctypes.c_int64(x.shape[0]), ctypes.c_double(lr),
+                                     ctypes.c_double(wd), ctypes.byref(moved))
+    assert st == 0, st
+    return out, moved.value

@@ -8,6 +8,7 @@
 #include "../../sympa_amd/csrc/siegel_table_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_generic.hpp"
 #include "../../sympa_amd/csrc/spd_math.hpp"
+#include "../../sympa_amd/csrc/spd_math_bwd.hpp"
 
 namespace {
 template <int N>
@@ -180,4 +181,35 @@ extern "C" int sympa_hostsim_spd_dist(const double* x, const double* y, int64_t 
     for (int64_t i = 0; i < b; ++i) out[i] = sympa::spd_pair_distance(w, x + i * n * n, y + i * n * n, n, st);
     if (status) *status = st;
     return 0;
+}
+
+extern "C" int sympa_hostsim_spd_bwd(const double* x, const double* y, int64_t b, int n, double* out, double* gx, double* gy,
+                                     int32_t* status) {
+    if (n < 1 || n > sympa::SPD_MAX_N) return -2;
+    int st = 0;
+    sympa::SpdBwdWork w;
+    for (int64_t i = 0; i < b; ++i)
+        out[i] = sympa::spd_pair_backward(w, x + i * n * n, y + i * n * n, n, gx + i * n * n, gy + i * n * n, st);
+    if (status) *status = st;
+    return 0;
+}
+
+// op 0: projx, 1: rsgd step (in place on a copy written to out), 2: egrad2rgrad
+extern "C" int sympa_hostsim_spd_table(int op, int n, const double* x, const double* g, double* out, int64_t b, double lr,
+                                       double wd, int32_t* moved) {
+    if (n < 1 || n > sympa::SPD_MAX_N) return -2;
+    int st = 0, mv = 0;
+    sympa::SpdRowWork w;
+    for (int64_t i = 0; i < b; ++i) {
+        const double* px = x + i * n * n;
+        double* po = out + i * n * n;
+        if (op == 0) mv += sympa::spd_row_projx(w, px, n, po, st) ? 1 : 0;
+        else if (op == 2) sympa::spd_row_egrad2rgrad(w, px, g + i * n * n, n, po);
+        else {
+            for (int k = 0; k < n * n; ++k) po[k] = px[k];
+            sympa::spd_row_rsgd(w, po, g + i * n * n, n, lr, wd, 1.0, st);
+        }
+    }
+    if (moved) *moved = mv;
+    return st;
 }

@@ -168,3 +168,154 @@ def test_gpu_spd_full_size_properties():
     k = 512
     want = so.spd_dist(table[trip[:k, 0]].cpu(), table[trip[:k, 1]].cpu())
     assert rel_err(d_xy[:k].cpu(), want) < 1e-11
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16])
+def test_oracle_and_cpu_build_against_mpmath_goldens(n):
+    """tests/golden/spd_n*.npz (tools/make_golden_spd.py): the published AIM formula evaluated with mpmath at 50 digits,
+    independently of every code path here.  (Still UNPINNED with respect to geoopt itself, which is not available.)"""
+    from tests.helpers import GOLDEN
+    g = np.load(f"{GOLDEN}/spd_n{n}.npz")
+    for case in g["case_names"]:
+        x, y, want = g[f"{case}__x"], g[f"{case}__y"], g[f"{case}__dist_exact50"]
+        out, st = hostsim_spd_dist(x, y)
+        assert st == 0
+        # measured against the 50-digit values: 0 (to the 1e-13 floor) on every well-conditioned case, <= 5e-12 with
+        # cond(x) = 1e6, and 5e-8 on "s1.5" at n = 16, where x^-1 y spans ~28 orders of magnitude (the eigh-based oracle
+        # reads 8e-8 there): fp64 conditioning of the pair, not of the algorithm
+        tol = {"s1.5": 2e-7, "cond1e6": 1e-10}.get(str(case), 1e-11)
+        assert rel_err(out, want, atol=1e-13) < tol, (n, case)
+        oracle = so.spd_dist(torch.from_numpy(x), torch.from_numpy(y))
+        assert rel_err(oracle, want, atol=1e-12) < 10 * tol, (n, case)
+        if case == "same":
+            assert np.all(out == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8, 16])
+def test_gpu_spd_against_mpmath_goldens(n):
+    from sympa_amd import ops
+    from tests.helpers import GOLDEN
+    dev = torch.device("cuda:0")
+    g = np.load(f"{GOLDEN}/spd_n{n}.npz")
+    for case in g["case_names"]:
+        x, y, want = torch.from_numpy(g[f"{case}__x"]), torch.from_numpy(g[f"{case}__y"]), g[f"{case}__dist_exact50"]
+        for flags in (0, ops.FLAG_GENERIC):
+            got = ops.spd_dist_forward(x.to(dev), y.to(dev), flags=flags).cpu()
+            ops.check_status(dev)
+            # (cond1e6: the sixteen-lanes-per-pair kernel sums in a different order, 1.0e-10 measured at n = 16)
+            tol = {"s1.5": 2e-7, "cond1e6": 1e-9}.get(str(case), 1e-11)
+            assert rel_err(got, want, atol=1e-13) < tol, (n, case, flags)
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16])
+def test_hostsim_spd_backward(n):
+    """d dist / dx, d dist / dy of spd_math_bwd.hpp: against torch autograd through the oracle's eigh-based formula, and
+    (n in the golden set) against 50-digit mpmath central differences along symmetric directions."""
+    from tests.helpers import GOLDEN, hostsim_spd_bwd
+    g = torch.Generator().manual_seed(600 + n)
+    for s in (1e-3, 0.3, 0.8):
+        x, y = spd_points(20, n, s, g), spd_points(20, n, s, g)
+        xa, ya = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        d = so.spd_dist(xa, ya)
+        d.sum().backward()
+        out, gx, gy, st = hostsim_spd_bwd(x.numpy(), y.numpy())
+        assert st == 0 and rel_err(out, d.detach()) < 1e-9
+        symt = lambda t: 0.5 * (t + t.transpose(-1, -2))
+        for got, want in ((gx, symt(xa.grad)), (gy, symt(ya.grad))):
+            err = np.abs(got - want.numpy()).reshape(20, -1).max(1) / np.abs(want.numpy()).reshape(20, -1).max(1)
+            assert err.max() < 1e-6 and np.median(err) < 1e-9, (n, s, err.max())
+    out, gx, gy, st = hostsim_spd_bwd(x.numpy(), x.numpy())      # dist = 0: zero subgradient, no NaN
+    assert st == 0 and np.all(out == 0) and np.all(gx == 0) and np.all(gy == 0)
+    if n in (2, 4, 8, 16):
+        gold = np.load(f"{GOLDEN}/spd_n{n}.npz")
+        x, y, dirs = gold["grad__x"], gold["grad__y"], gold["grad__dirs"]
+        _, gx, gy, st = hostsim_spd_bwd(x, y)
+        ddx = np.einsum("kij,ktij->kt", gx, dirs)
+        ddy = np.einsum("kij,ktij->kt", gy, dirs)
+        assert np.abs(ddx - gold["grad__ddx_exact50"]).max() < 1e-10 * np.abs(gold["grad__ddx_exact50"]).max()
+        assert np.abs(ddy - gold["grad__ddy_exact50"]).max() < 1e-10 * np.abs(gold["grad__ddy_exact50"]).max()
+
+
+@pytest.mark.parametrize("n", [2, 5, 16])
+def test_hostsim_spd_table_ops(n):
+    from tests.helpers import hostsim_spd_table
+    g = torch.Generator().manual_seed(700 + n)
+    x = spd_points(30, n, 0.4, g)
+    u = torch.randn(30, n, n, generator=g, dtype=torch.float64)
+    out, _ = hostsim_spd_table("egrad2rgrad", x.numpy(), u.numpy())
+    assert rel_err(out, so.spd_egrad2rgrad(x, u), atol=1e-14) < 1e-11
+    step, _ = hostsim_spd_table("rsgd", x.numpy(), u.numpy(), lr=0.05, wd=0.01)
+    want = so.spd_rsgd_step(x, u, 0.05, 0.01)
+    assert rel_err(step, want, atol=1e-13) < 1e-10
+    assert (torch.linalg.eigvalsh(torch.from_numpy(step)) > 0).all()          # the retraction stays on the manifold
+    bad = x.clone()
+    bad[3] = -bad[3]
+    bad[5] = bad[5] + 0.1 * torch.triu(torch.ones(n, n), 1)                     # asymmetric
+    proj, moved = hostsim_spd_table("projx", bad.numpy())
+    assert moved == 1
+    assert rel_err(proj, so.spd_projx(bad), atol=1e-13) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 5, 16])
+def test_gpu_spd_backward_and_table_ops(n):
+    """GPU kernels of the spd training path == the g++ build of the same arithmetic == oracle autograd / restated geoopt
+    formulas; Model.forward under autograd and the fused loss step give the same dense table gradient."""
+    from sympa_amd import ops
+    from sympa_amd.losses import AverageDistortionLoss
+    from sympa_amd.manifolds import SymmetricPositiveDefinite
+    from sympa_amd.model import Model
+    from tests.helpers import hostsim_spd_bwd, hostsim_spd_table
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(800 + n)
+    b = 150
+    x, y = spd_points(b, n, 0.4, g), spd_points(b, n, 0.4, g)
+    coeff = torch.rand(b, generator=g, dtype=torch.float64) + 0.5
+    man = SymmetricPositiveDefinite()
+    xa, ya = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    d = man.dist(xa, ya)
+    (d * coeff.to(dev)).sum().backward()
+    ho, hgx, hgy, st = hostsim_spd_bwd(x.numpy(), y.numpy())
+    assert st == 0 and rel_err(d.detach().cpu(), ho) < 1e-11
+    assert rel_err(xa.grad.cpu(), hgx * coeff.numpy()[:, None, None], atol=1e-13) < 1e-9
+    assert rel_err(ya.grad.cpu(), hgy * coeff.numpy()[:, None, None], atol=1e-13) < 1e-9
+    # table ops
+    u = torch.randn(b, n, n, generator=g, dtype=torch.float64)
+    assert rel_err(man.egrad2rgrad(x.to(dev), u.to(dev)).cpu(), so.spd_egrad2rgrad(x, u), atol=1e-13) < 1e-10
+    tab = x.clone().to(dev)
+    ops.spd_rsgd_step_(tab, u.to(dev), 0.05, 0.01)
+    assert rel_err(tab.cpu(), so.spd_rsgd_step(x, u, 0.05, 0.01), atol=1e-13) < 1e-10
+    bad = x.clone(); bad[3] = -bad[3]
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert rel_err(ops.spd_projx(bad.to(dev), cnt).cpu(), so.spd_projx(bad), atol=1e-13) < 1e-10 and int(cnt) == 1
+    ops.check_status(dev)
+
+    class A:
+        manifold, metric, dims, num_points = "spd", "riem", n, 40
+        scale_coef, scale_init, train_scale = 1.0, 1.3, True
+    torch.manual_seed(3)
+    m1, m2 = Model(A), Model(A)
+    pts = spd_points(40, n, 0.3, g)
+    for m in (m1, m2):
+        with torch.no_grad():
+            m.embeddings.embeds.data = pts.clone()
+    m1, m2 = m1.to(dev), m2.to(dev)
+    trip = torch.stack((torch.randint(0, 40, (300,), generator=g), torch.randint(0, 40, (300,), generator=g)), 1)
+    trip = trip[trip[:, 0] != trip[:, 1]].to(dev)
+    gd = torch.randint(1, 9, (trip.shape[0],), generator=g).to(torch.float64).to(dev)
+    loss1 = AverageDistortionLoss().calculate_loss(gd, m1(trip))
+    loss1.backward()
+    loss2 = m2.fused_loss_backward(trip, gd)
+    ops.check_status(dev)
+    assert abs(float(loss2) - float(loss1)) < 1e-10 * abs(float(loss1))
+    assert rel_err(m2.embeddings.embeds.grad.cpu(), m1.embeddings.embeds.grad.cpu(), atol=1e-13) < 1e-10
+    assert rel_err(m2.scale.grad.cpu(), m1.scale.grad.cpu()) < 1e-10
+    # against torch autograd through the oracle (table and scale)
+    table = pts.clone().requires_grad_(True)
+    scale = m1.scale.detach().cpu().clone().requires_grad_(True)
+    ref = so.spd_model_forward(table, trip.cpu(), scale, 1.0)
+    so.distortion_loss(gd.cpu(), ref).backward()
+    symt = lambda t: 0.5 * (t + t.transpose(-1, -2))
+    assert rel_err(m1.embeddings.embeds.grad.cpu(), symt(table.grad), atol=1e-10) < 1e-6
+    assert rel_err(m1.scale.grad.cpu(), scale.grad) < 1e-8

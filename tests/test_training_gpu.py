@@ -63,3 +63,17 @@ def test_gradient_exchange_step_equals_plain_step(mode):
     assert len(h_plain) == len(h_ex) == 4
     for a, b in zip(h_ex, h_plain):
         assert abs(a[1] - b[1]) < 1e-8 * abs(b[1]) and abs(a[2] - b[2]) < 1e-8 * abs(b[2]), (a, b)
+
+
+def test_spd_model_trains():
+    """configs[4]'s model family end to end: spd forward kernel, fused backward rows + scatter, geoopt-style RSGD step
+    (retr(x, u) = sym(x + u + u x^-1 u / 2)): the distortion of the 125-node grid drops and every point stays SPD."""
+    import train_siegel
+    args = train_siegel.parser().parse_args(["--graph", "grid3d-125", "--manifold", "spd", "--metric", "riem",
+                                             "--dims", "3", "--epochs", "30", "--batch_size", "512",
+                                             "--val_every", "10", "--learning_rate", "0.02", "--burnin", "5"])
+    model, hist = train_siegel.train(args, log=lambda *_: None)
+    first, last = hist[0][2], hist[-1][2]
+    assert last < 0.7 * first, hist
+    ok, point, reason = model.check_all_points()
+    assert ok, reason
