@@ -18,7 +18,7 @@
 //   upper  : Ybar_k += Abar_k (real);    X2bar += Re Dbar, Y2bar += Im Dbar, X1bar -= ..., Y1bar -= ...
 //   bounded: Wbar_k  = -/+ Dbar - 2 Abar_k W_k
 // and finally every plane is symmetrised.  Derivation and the numpy prototype that was checked against
-// the reference's autograd to 1e-11: DESIGN.md section 9.  Eigenvectors come from the same Jacobi
+// the reference's autograd to 1e-11: DESIGN.md section 8.  Eigenvectors come from the same Jacobi
 // iteration with the rotations accumulated, run to ||off|| <= 1e-11 ||diag|| (no finishing shortcut).
 #pragma once
 

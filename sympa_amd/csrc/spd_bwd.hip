@@ -1,6 +1,6 @@
 // gfx950 kernels + C-ABI of the SPD model's training path (spd_math_bwd.hpp): backward of the affine-invariant
 // distance with the fused AverageDistortionLoss, and the optimiser-side row operations (egrad2rgrad, projx, RSGD step).
-// One pair / one table row per lane, runtime n <= 16, per-lane scratch: functional, not tuned (DESIGN.md section 13).
+// One pair / one table row per lane, runtime n <= 16, per-lane scratch: functional, not tuned (DESIGN.md section 12).
 // PARITY UNPINNED with respect to geoopt (absent); pinned by mpmath finite differences and autograd through the oracle.
 #include "siegel_common.hpp"
 #include "spd_math_bwd.hpp"

@@ -34,3 +34,38 @@ for name, fl in (("specialised", 0), ("generic", ops.FLAG_GENERIC)):
     bytes_per_pair = 2 * n * n * 8 + 16 + 8
     print(f"spd n={n} b={b} rows={rows} {name}: {dt * 1e3:.3f} ms  {b / dt / 1e6:.1f} M pairs/s  "
           f"{b * bytes_per_pair / dt / 1e9:.0f} GB/s algorithmic ({b * bytes_per_pair / dt / 8e12:.3f} of the HBM roof)")
+
+# training path: fused loss + backward rows + scatter, then the RSGD step (one lane per pair / row, scratch)
+if "--train" in sys.argv:
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "spd", "riem", n, rows
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = table.cpu()
+    m = m.to(dev)
+    bt = min(b, 65536)
+    gd = torch.randint(1, 9, (bt,), generator=g).to(torch.float64).to(dev)
+    m.embeddings.embeds.grad = torch.zeros_like(m.embeddings.embeds.data)
+    for _ in range(2):
+        m.fused_loss_backward(trip[:bt], gd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.fused_loss_backward(trip[:bt], gd)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(f"spd n={n} fused loss+backward (rows + scatter) b={bt}: {dt * 1e3:.2f} ms  {bt / dt / 1e6:.2f} M pairs/s")
+    grad = m.embeddings.embeds.grad
+    for _ in range(2):
+        ops.spd_rsgd_step_(m.embeddings.embeds.data, grad * 1e-6, 1e-3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ops.spd_rsgd_step_(m.embeddings.embeds.data, grad * 1e-6, 1e-3)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(f"spd n={n} RSGD step over {rows} rows: {dt * 1e3:.2f} ms")
+    ops.check_status(dev)
