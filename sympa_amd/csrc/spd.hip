@@ -38,12 +38,14 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
 
 // n = 16: sixteen lanes per pair for the O(n^3) part, one lane per pair for the QL iteration (spd_coop.hpp).
 // One wave per block, 64 pairs per wave, 16 KB of LDS.  Lane 16 g + t owns pair 4 t + g of the wave's 64.
-// PADDED (6 <= n < 16): the same arithmetic on diag(X, I), diag(Y, I) -- the extra eigenvalues of
-// L^-1 (Y - X) L^-T are exact zeros and add nothing to the distance.  Rows are n*n*8 bytes then, not the 2 KB image
+// M < 16 (6 <= n < 16, one instantiation per n): the row-per-lane routines are templates over the matrix size, lanes
+// r >= M of a group are phantoms (spd_coop.hpp), the time goes with M^2.  Rows are n*n*8 bytes then, not the 2 KB image
 // the DMA tile is made for, so each lane loads the elements of its row itself (upper triangle: (min, max)).
-template <bool PADDED>
-__global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a, const int n) {
+template <int M>
+__global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
     using namespace spd_coop;
+    constexpr bool PADDED = M < N;      // historical name: "not the 2 KB image of n = 16"
+    constexpr int n = M;
     __shared__ __attribute__((aligned(16))) char tile[LDS_BYTES];
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a, const 
         voff[h] = (unsigned)(rr * 128 + c * 16);
     }
     // byte offset of element (r, j) of my pair's X image (upper triangle only: (min, max))
-    int eoff[N];
+    int eoff[M];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < M; ++j) {
         const int lo = r < j ? r : j, hi = r < j ? j : r;
         eoff[j] = g * 4096 + tile_slot(lo, hi >> 1) * 16 + (hi & 1) * 8;
     }
@@ -87,38 +89,35 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a, const 
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 1024), 16, 0, 0);
         }
     };
-    double d[N], e2[N];
+    double d[M], e2[M];
 #pragma unroll
-    for (int k = 0; k < N; ++k) { d[k] = 0.0; e2[k] = 0.0; }
+    for (int k = 0; k < M; ++k) { d[k] = 0.0; e2[k] = 0.0; }
     bool ok = true;
     if constexpr (!PADDED) issue(0);
     for (int t = 0; t < ROUNDS; ++t) {
-        double x[N], y[N];
+        double x[M], y[M];
         if constexpr (PADDED) {
             const int rowx = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row1);     // rows of my group's pair
             const int rowy = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row2);
             const double* px = a.base1 + (size_t)(unsigned)rowx * (unsigned)(n * n);
             const double* py = a.base2 + (size_t)(unsigned)rowy * (unsigned)(n * n);
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
+            for (int j = 0; j < M; ++j) {
                 const int lo = r < j ? r : j, hi = r < j ? j : r;
-                const bool inside = hi < n;
-                const int e = inside ? lo * n + hi : 0;
-                const double ident = (r == j) ? 1.0 : 0.0;
-                const double vx = px[e], vy = py[e];
-                x[j] = inside ? vx : ident;
-                y[j] = inside ? vy : ident;
+                const int e = (hi < n) ? lo * n + hi : 0;          // a phantom lane (r >= M) reads element 0
+                x[j] = px[e];
+                y[j] = py[e];
             }
         } else {
             __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this round's images have landed
             wave_lds_fence();
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
+            for (int j = 0; j < M; ++j) {
                 x[j] = *reinterpret_cast<const double*>(tile + eoff[j]);
                 y[j] = *reinterpret_cast<const double*>(tile + 2048 + eoff[j]);
             }
         }
-        double rd[N], m[N];
+        double rd[M], m[M];
         const bool pd = reduce_pair_front(x, y, rd, m, reinterpret_cast<double*>(tile + g * 2048), r);
         // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -129,10 +128,10 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a, const 
         reduce_pair_back(m, x, rd, r, keep, d, e2);
     }
     // one pair per lane: QL on the tridiagonal forms, then the norm of the logarithms
-    const bool conv = sympa::tridiag_ql_lockstep<N>(d, e2);
+    const bool conv = sympa::tridiag_ql_lockstep<M>(d, e2);
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
+    for (int k = 0; k < M; ++k) {
         ok = ok && (d[k] > -1.0);
         const double lg = sympa::d_log1p_signed(d[k]);
         acc = sympa::d_fma(lg, lg, acc);
@@ -160,15 +159,20 @@ int launch_spd(const DistArgs& a, int n, void* stream) {
     if (a.base1 == nullptr || a.base2 == nullptr || a.out == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
     if (n < 1 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: dims outside [1, 16]");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
-    if (n == spd_coop::N && !(a.flags & SYMPA_FLAG_GENERIC))
-        hipLaunchKernelGGL(spd16_coop_kernel<false>, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
-                           reinterpret_cast<hipStream_t>(stream), a, n);
-    else if (n >= 6 && n < spd_coop::N && !(a.flags & SYMPA_FLAG_GENERIC))     // measured crossover: n = 6
-        hipLaunchKernelGGL(spd16_coop_kernel<true>, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
-                           reinterpret_cast<hipStream_t>(stream), a, n);
-    else
-        hipLaunchKernelGGL(spd_dist_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0,
-                           reinterpret_cast<hipStream_t>(stream), a, n);
+    const dim3 grid((unsigned)((a.b + 63) / 64));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n >= 6 && !(a.flags & SYMPA_FLAG_GENERIC)) {     // measured crossover against the one-lane-per-pair kernel: n = 6
+        switch (n) {
+#define SYMPA_SPD_COOP_CASE(MM) case MM: hipLaunchKernelGGL(spd16_coop_kernel<MM>, grid, dim3(64), 0, s, a); break;
+            SYMPA_SPD_COOP_CASE(6) SYMPA_SPD_COOP_CASE(7) SYMPA_SPD_COOP_CASE(8) SYMPA_SPD_COOP_CASE(9)
+            SYMPA_SPD_COOP_CASE(10) SYMPA_SPD_COOP_CASE(11) SYMPA_SPD_COOP_CASE(12) SYMPA_SPD_COOP_CASE(13)
+            SYMPA_SPD_COOP_CASE(14) SYMPA_SPD_COOP_CASE(15) SYMPA_SPD_COOP_CASE(16)
+#undef SYMPA_SPD_COOP_CASE
+            default: break;
+        }
+    } else {
+        hipLaunchKernelGGL(spd_dist_kernel, grid, dim3(64), 0, s, a, n);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
