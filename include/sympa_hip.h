@@ -201,6 +201,12 @@ int sympa_scatter_add_flat_rows(const double* rows, const int64_t* idx, int64_t 
  */
 int sympa_egrad2rgrad(const double* z, const double* u, int64_t b, int n, int model, double* out, void* stream);
 
+/* inner(z, u, u) per row: UpperHalfManifold.inner (sympa/manifolds/upper_half.py:68-91, tr[y^-1 u y^-1 conj(u)]) /
+ * BoundedDomainManifold.inner (sympa/manifolds/bounded_domain.py:86-116) for any complex tangent vector u:
+ * out[i] = squared Riemannian norm of u[i] at z[i].  The second moment of geoopt's RiemannianAdam (train.py:69-70). */
+int sympa_tangent_sqnorm(const double* z, const double* u, int64_t b, int n, int model, double* out, int32_t* status,
+                         void* stream);
+
 /* projx: SiegelManifold.projx + UpperHalfManifold.projx (siegel_manifold.py:130-137, upper_half.py:42-66,
  * csym_math.py:252-278): symmetrise, clamp the eigenvalues of Im z at eps, rows already inside are left
  * untouched; BoundedDomainManifold.projx as intended by bounded_domain.py:55-84: clamp the Takagi values

@@ -356,3 +356,39 @@ def spd_rsgd_step(table, grad, lr, weight_decay=0.0):
     """geoopt.optim.RiemannianSGD.step (momentum 0, stabilize None) on an spd table."""
     g = grad + weight_decay * table
     return spd_retr(table, -lr * spd_egrad2rgrad(table, g))
+
+
+def upper_inner(z, u, v=None):
+    """UpperHalfManifold.inner (upper_half.py:68-91): Re tr[y^-1 u y^-1 conj(v)] -> [b]."""
+    v = u if v is None else v
+    iy = torch.linalg.inv(im(z))
+    iyc = pack(iy, torch.zeros_like(iy))
+    res = cmatmul(cmatmul3(iyc, u, iyc), conjugate(v))
+    return torch.diagonal(re(res), dim1=-2, dim2=-1).sum(-1)
+
+
+def bounded_inner(z, u, v=None):
+    """BoundedDomainManifold.inner (bounded_domain.py:86-116): Re tr[(I - conj(z) z)^-1 u (I - z conj(z))^-1 conj(v)]."""
+    v = u if v is None else v
+    ident = identity_like(z)
+    a = cinverse(ident - cmatmul(conjugate(z), z))
+    b = cinverse(ident - cmatmul(z, conjugate(z)))
+    res = cmatmul(cmatmul3(a, u, b), conjugate(v))
+    return torch.diagonal(re(res), dim1=-2, dim2=-1).sum(-1)
+
+
+def radam_step(model, table, grad, state, lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.0):
+    """geoopt.optim.RiemannianAdam.step for a Siegel table (restated from geoopt/optim/radam.py; geoopt is absent):
+    state = {"step", "exp_avg" [N,2,n,n], "exp_avg_sq" [N]}; transp is the identity (siegel_manifold.py:142-154)."""
+    b1, b2 = betas
+    state["step"] += 1
+    g = grad + weight_decay * table
+    g = upper_egrad2rgrad(table, g) if model == "upper" else bounded_egrad2rgrad(table, g)
+    state["exp_avg"] = b1 * state["exp_avg"] + (1 - b1) * g
+    inn = upper_inner(table, g) if model == "upper" else bounded_inner(table, g)
+    state["exp_avg_sq"] = b2 * state["exp_avg_sq"] + (1 - b2) * inn
+    bc1, bc2 = 1 - b1 ** state["step"], 1 - b2 ** state["step"]
+    denom = (state["exp_avg_sq"] / bc2).sqrt() + eps
+    direction = (state["exp_avg"] / bc1) / denom.view(-1, 1, 1, 1)
+    new = table - lr * direction
+    return (upper_projx(new) if model == "upper" else bounded_projx(new))[0]

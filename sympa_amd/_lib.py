@@ -26,6 +26,7 @@ SYMBOLS = (
     "sympa_model_loss_backward_rows",
     "sympa_scatter_add_rows",
     "sympa_egrad2rgrad",
+    "sympa_tangent_sqnorm",
     "sympa_projx",
     "sympa_rsgd_step",
     "sympa_sqnorm_accum",
@@ -128,6 +129,9 @@ def load():
     lib.sympa_egrad2rgrad.restype = ctypes.c_int
     lib.sympa_egrad2rgrad.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
                                       ctypes.c_void_p]
+    lib.sympa_tangent_sqnorm.restype = ctypes.c_int
+    lib.sympa_tangent_sqnorm.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                         _c_i32_p, ctypes.c_void_p]
     lib.sympa_projx.restype = ctypes.c_int
     lib.sympa_projx.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, _c_double_p,
                                 _c_i32_p, _c_i32_p, ctypes.c_void_p]

@@ -20,6 +20,20 @@ __global__ __launch_bounds__(BLOCK) void egrad2rgrad_kernel(const double* z, con
     sympa::store_full<N>(out + i * ROW, r);
 }
 
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void tangent_sqnorm_kernel(const double* z, const double* u, double* out, int64_t b,
+                                                               int32_t* status) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= b) return;
+    constexpr int64_t ROW = 2 * N * N;
+    sympa::CMat<N> a, g;
+    sympa::load_point<N>(z + i * ROW, a);          // the point is symmetric: upper triangle
+    sympa::load_full<N>(u + i * ROW, g);
+    int st = 0;
+    out[i] = sympa::tangent_sqnorm<N, MODEL>(a, g, st);
+    if (st != 0 && status != nullptr) { atomicOr(&status[0], st); atomicAdd(&status[1], 1); }
+}
+
 // OP 0: out = projx(z).   OP 1: table <- retr(table, -lr * egrad2rgrad(table, grad + wd * table)) in place.
 // sum of squares of `count` doubles, accumulated into acc[0] (the total gradient norm of clip_grad_norm_)
 __global__ __launch_bounds__(BLOCK) void sqnorm_kernel(const double* __restrict__ x, int64_t count, double* acc) {
@@ -96,7 +110,10 @@ int launch_table(int op, int model, double* z, const double* g, double* out, int
                  double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm) {
     const unsigned grid = (unsigned)((b + BLOCK - 1) / BLOCK);
     const bool up = model == SYMPA_MODEL_UPPER;
-    if (op == 2) {
+    if (op == 3) {
+        if (up) hipLaunchKernelGGL((tangent_sqnorm_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, status);
+        else hipLaunchKernelGGL((tangent_sqnorm_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, status);
+    } else if (op == 2) {
         if (up) hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
         else hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
     } else if (op == 0) {
@@ -140,6 +157,12 @@ extern "C" {
 int sympa_egrad2rgrad(const double* z, const double* u, int64_t b, int n, int model, double* out, void* stream) {
     if (b > 0 && (u == nullptr || out == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
     return dispatch_table(2, n, model, const_cast<double*>(z), u, out, b, 0.0, 0.0, 0.0, nullptr, nullptr, stream);
+}
+
+int sympa_tangent_sqnorm(const double* z, const double* u, int64_t b, int n, int model, double* out, int32_t* status,
+                         void* stream) {
+    if (b > 0 && (u == nullptr || out == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    return dispatch_table(3, n, model, const_cast<double*>(z), u, out, b, 0.0, 0.0, 0.0, nullptr, status, stream);
 }
 
 int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double* out, int32_t* projected_count,

@@ -220,6 +220,45 @@ SYMPA_HD bool rsgd_row(CMat<N>& z, const CMat<N>& grad, double lr, double weight
 }
 
 // full (non-symmetric) load / store of a [2,n,n] row
+// ---- inner(z, u, u): squared Riemannian norm of a tangent vector -----------------------------------------------
+//   upper  : Re tr[ y^-1 u y^-1 conj(u) ] = Re tr[ Q conj(Q) ],  Q = L^-1 u L^-T,  y = L L^T        upper_half.py:68-91
+//   bounded: Re tr[ (I - conj(z) z)^-1 u (I - z conj(z))^-1 conj(u) ] = Re tr[ conj(Q) Q ],  Q = C^-1 conj(u) C^-T,
+//            I - z z^H = C C^H                                                                 bounded_domain.py:86-116
+// Re tr[Q conj(Q)] = sum_ij (Re q_ij Re q_ji + Im q_ij Im q_ji): the Frobenius norm when u is symmetric (upper: Y G Y
+// is), but the bounded Riemannian gradient A G A (A Hermitian, not real) is NOT symmetric.  Used by RiemannianAdam's second moment
+// (geoopt Manifold.component_inner = inner broadcast over the point).
+template <int N, int MODEL>
+SYMPA_HD double tangent_sqnorm(const CMat<N>& z, const CMat<N>& u, int& status) {
+    CMat<N> e;
+    bool ok;
+    if (MODEL == MODEL_UPPER) {
+        Tri<N, false> l;
+        ok = chol_real<N>(z.im, l);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) { e.re[i][j] = u.re[i][j]; e.im[i][j] = u.im[i][j]; }
+        solve_left<N, false>(l, e);
+        solve_right_t<N, false>(l, e);
+    } else {
+        Tri<N, true> c;
+        ok = chol_id_minus_wwh<N>(z, c);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) { e.re[i][j] = u.re[i][j]; e.im[i][j] = -u.im[i][j]; }
+        solve_left<N, true>(c, e);
+        solve_right_t<N, true>(c, e);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc = d_fma(e.re[i][j], e.re[j][i], d_fma(e.im[i][j], e.im[j][i], acc));
+    if (!ok) status |= ST_NOT_PD;
+    return acc;
+}
+
 template <int N>
 SYMPA_HD void load_full(const double* __restrict__ p, CMat<N>& z) {
 #pragma unroll

@@ -435,6 +435,19 @@ def egrad2rgrad(z, u, model):
     return out
 
 
+def tangent_sqnorm(z, u, model):
+    """inner(z, u, u) per row (C-ABI sympa_tangent_sqnorm; upper_half.py:68-91 / bounded_domain.py:86-116) -> [b]."""
+    lib = _lib.load()
+    z, u = _rows(z.detach(), "z"), _rows(u.detach(), "u")
+    out = torch.empty(z.shape[0], dtype=torch.float64, device=z.device)
+    st = _status_buf(z.device)
+    with torch.cuda.device(z.device):
+        rc = lib.sympa_tangent_sqnorm(z.data_ptr(), u.data_ptr(), z.shape[0], z.shape[2], MODEL_IDS[model], out.data_ptr(),
+                                      st.data_ptr(), _stream())
+    _lib.check(rc)
+    return out
+
+
 def projx(z, model, eps=None, counter=None):
     """Returns projx(z); `counter` (int32[1] device tensor) += rows that were moved."""
     lib = _lib.load()

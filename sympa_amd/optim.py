@@ -72,3 +72,64 @@ class RiemannianSGD(torch.optim.Optimizer):
                         g = g.add(p, alpha=wd)
                     p.add_(g, alpha=-lr)
         return loss
+
+
+class RiemannianAdam(torch.optim.Optimizer):
+    """geoopt.optim.RiemannianAdam for the Siegel models (train.py:69-70: `--optim radam`, lr, eps=1e-7, stabilize=None;
+    geoopt is absent from the reference tree, the step is restated from geoopt/optim/radam.py):
+        g  <- egrad2rgrad(x, grad + weight_decay * x)
+        m  <- b1 m + (1 - b1) g
+        v  <- b2 v + (1 - b2) inner(x, g, g)              (component_inner: one value per point, broadcast)
+        x  <- retr(x, -lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps));   m is transported by the identity
+    (SiegelManifold.transp returns the vector unchanged, siegel_manifold.py:142-154).  egrad2rgrad, inner and retr
+    (= projx(x + u)) are HIP kernels over the table rows; the moment updates are elementwise torch ops on the device.
+    Parameters without a manifold get the ordinary Adam update.  amsgrad is not built."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, stabilize=None):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not built")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, step=0))
+        self._stabilize = stabilize
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            group["step"] += 1
+            bc1 = 1.0 - b1 ** group["step"]
+            bc2 = 1.0 - b2 ** group["step"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                manifold = getattr(p, "manifold", None)
+                siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
+                if isinstance(manifold, SymmetricPositiveDefinite):
+                    raise NotImplementedError("RiemannianAdam on the spd model needs geoopt's parallel transport: use rsgd")
+                if not state:
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device) if siegel \
+                        else torch.zeros_like(p)
+                g = p.grad
+                if wd != 0:
+                    g = g.add(p, alpha=wd)
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if siegel:
+                    g = ops.egrad2rgrad(p.data, g, manifold.model_name)
+                    m.mul_(b1).add_(g, alpha=1.0 - b1)
+                    v.mul_(b2).add_(ops.tangent_sqnorm(p.data, g, manifold.model_name), alpha=1.0 - b2)
+                    denom = v.div(bc2).sqrt_().add_(eps)
+                    direction = m.div(bc1) / denom.view(-1, 1, 1, 1)
+                    counter = manifold.projected_counter(p.device)
+                    p.data.copy_(ops.projx(p.data.add(direction, alpha=-lr), manifold.model_name, counter=counter))
+                else:
+                    m.mul_(b1).add_(g, alpha=1.0 - b1)
+                    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                    denom = v.div(bc2).sqrt_().add_(eps)
+                    p.add_(m.div(bc1) / denom, alpha=-lr)
+        return loss

@@ -152,3 +152,54 @@ def test_gpu_clip_folded_into_the_step_equals_torch_clip(dev, model, max_norm):
         assert (float(total) > max_norm) == (max_norm < 1.0)
         for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
             assert relmax(b.cpu(), a.cpu()) < 1e-10, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 7])
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_tangent_norm_and_riemannian_adam(dev, model, n):
+    """manifold.inner(z, u, u) kernel == the restated upper_half.py:68-91 / bounded_domain.py:86-116, and three steps of
+    RiemannianAdam (train.py:69-70, --optim radam) == the restated geoopt step on the CPU."""
+    from sympa_amd import ops
+    from sympa_amd.model import Model
+    from sympa_amd.optim import RiemannianAdam
+    g = torch.Generator().manual_seed(40 + n)
+    z = points(model, 80, n, 0.3, g)
+    u = torch.randn(80, 2, n, n, generator=g, dtype=torch.float64)       # NOT symmetric: A G A of the bounded model is not
+    inner = so.upper_inner if model == "upper" else so.bounded_inner
+    assert relmax(ops.tangent_sqnorm(z.to(dev), u.to(dev), model).cpu(), inner(z, u)) < 1e-11
+    ops.check_status(dev)
+
+    class A:
+        manifold, metric, dims, num_points = model, "riem", n, 50
+        scale_coef, scale_init, train_scale = 1.0, 1.0, True
+
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = points(model, 50, n, 0.3, g)
+    m = m.to(dev)
+    opt = RiemannianAdam(m.parameters(), lr=0.01, eps=1e-7, stabilize=None)
+    table = m.embeddings.embeds.detach().cpu().clone()
+    scale = m.scale.detach().cpu().clone()
+    st = {"step": 0, "exp_avg": torch.zeros_like(table), "exp_avg_sq": torch.zeros(50, dtype=torch.float64)}
+    ms, vs = torch.zeros_like(scale), torch.zeros_like(scale)
+    for it in range(3):
+        trip = torch.stack((torch.randint(0, 50, (300,), generator=g), torch.randint(0, 50, (300,), generator=g)), 1)
+        trip = trip[trip[:, 0] != trip[:, 1]]
+        gd = torch.randint(1, 7, (trip.shape[0],), generator=g).to(torch.float64)
+        opt.zero_grad()
+        m.fused_loss_backward(trip.to(dev), gd.to(dev))
+        opt.step()
+        t = table.clone().requires_grad_(True)
+        s = scale.clone().requires_grad_(True)
+        so.distortion_loss(gd, so.model_forward(t, trip, model, "riem", scale=s, scale_coef=1.0)).backward()
+        gsym = 0.5 * (t.grad + t.grad.transpose(-1, -2))
+        table = so.radam_step(model, table, gsym, st, 0.01, eps=1e-7)
+        ms = 0.9 * ms + 0.1 * s.grad
+        vs = 0.999 * vs + 0.001 * s.grad * s.grad
+        scale = scale - 0.01 * (ms / (1 - 0.9 ** (it + 1))) / ((vs / (1 - 0.999 ** (it + 1))).sqrt() + 1e-7)
+        assert relmax(m.embeddings.embeds.detach().cpu(), table) < 1e-6, (model, n, it)
+        assert relmax(m.scale.detach().cpu(), scale) < 1e-7
+    ops.check_status(dev)
+    ok, _, reason = m.check_all_points()
+    assert ok, reason

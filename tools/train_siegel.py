@@ -20,7 +20,7 @@ import torch.distributed as dist  # noqa: E402
 from sympa_amd import data, ops  # noqa: E402
 from sympa_amd.distributed import GradientExchange, shard_triplets  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
-from sympa_amd.optim import RiemannianSGD  # noqa: E402
+from sympa_amd.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
 from sympa_amd.train_step import GraphedTrainStep  # noqa: E402
 
 
@@ -45,14 +45,18 @@ def train(args, log=print):
     trip, id2node = data.graph_triplets(data.named_graph(args.graph))
     args.num_points = len(id2node)
     model = Model(args).to(dev)
-    opt = RiemannianSGD(model.parameters(), lr=args.learning_rate * world, weight_decay=0.0, stabilize=None)
+    if args.optim == "radam":        # train.py:69-70
+        opt = RiemannianAdam(model.parameters(), lr=args.learning_rate * world, eps=1e-7, stabilize=None)
+    else:                            # train.py:66-68
+        opt = RiemannianSGD(model.parameters(), lr=args.learning_rate * world, weight_decay=0.0, stabilize=None)
     ids_all = trip[:, :2].contiguous().to(dev)
     gd_all = trip[:, 2].to(torch.float64).to(dev)
     batch = max(1, args.batch_size // world)
     history = []
     # single GPU: the whole step is one hipGraph replay; multi-GPU steps have an all-reduce in the middle and run eagerly
     graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev) \
-        if (world == 1 and args.graph_step and args.grad_exchange == "none") else None
+        if (world == 1 and args.graph_step and args.grad_exchange == "none" and args.optim == "rsgd") else None
+    # (RiemannianAdam's bias corrections change every step on the host: its step is not captured)
     # N > 1 (or --grad_exchange given): gradients live in one persistent flat buffer; the table gradient travels dense
     # (one in-place all-reduce) or as touched rows (all-gather of the 2 b per-pair rows), whichever message is smaller
     ex = None
@@ -113,6 +117,7 @@ def parser():
     ap.add_argument("--scale_coef", type=float, default=1.0)
     ap.add_argument("--train_scale", action="store_true", default=False)
     ap.add_argument("--learning_rate", type=float, default=1e-2)
+    ap.add_argument("--optim", default="rsgd", choices=["rsgd", "radam"])
     ap.add_argument("--max_grad_norm", type=float, default=50.0)
     ap.add_argument("--batch_size", type=int, default=512)
     ap.add_argument("--epochs", type=int, default=50)
