@@ -65,7 +65,8 @@ extern "C" {
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
-#define SYMPA_MAX_DIMS_BACKWARD 8 /* largest n with a backward kernel in this build (n >= 5 spill to scratch) */
+#define SYMPA_MAX_DIMS_BACKWARD 16 /* largest n with a backward kernel in this build (n = 7, 8 spill to scratch; n = 9..16 run
+                                      the same adjoint as rolled loops over per-lane scratch arrays) */
 #define SYMPA_MAX_DIMS_ALL_PAIRS_PACKED 4 /* sympa_all_pairs_dist_packed: per-point factor reuse, dims 1..4 */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] run sixteen lanes per pair
                                      (csrc/siegel_coop.hpp); SYMPA_FLAG_GENERIC selects the runtime-n fallback (scratch) */

@@ -20,8 +20,10 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
         case 6: return launch_bwd_n<6>(a, model, scatter, s);
         case 7: return model == SYMPA_MODEL_UPPER ? launch_bwd_n7_upper(a, scatter, s) : launch_bwd_n7_bounded(a, scatter, s);
         case 8: return model == SYMPA_MODEL_UPPER ? launch_bwd_n8_upper(a, scatter, s) : launch_bwd_n8_bounded(a, scatter, s);
-        default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "backward: dims outside [1, SYMPA_MAX_DIMS_BACKWARD]");
+        default: break;
     }
+    if (n > 8 && n <= SYMPA_MAX_DIMS_BACKWARD) return launch_bwd_rolled(a, n, model, scatter, s);
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "backward: dims outside [1, SYMPA_MAX_DIMS_BACKWARD]");
 }
 
 }  // namespace

@@ -38,12 +38,12 @@ __device__ __forceinline__ void scatter_add_rows(const sympa::CMat<N>& g, const 
     const int lane = threadIdx.x & 63;
     if constexpr (ScatterTile<N>::BY_PLANE) {
         constexpr int NN = N * N;
-#pragma unroll
+SYMPA_UNROLL
         for (int plane = 0; plane < 2; ++plane) {
             wave_lds_fence();
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
                 for (int j = 0; j < N; ++j)
                     tile[lane * PITCH + i * N + j] = live ? (plane == 0 ? g.re[i][j] : g.im[i][j]) : 0.0;
             wave_lds_fence();
@@ -59,9 +59,9 @@ __device__ __forceinline__ void scatter_add_rows(const sympa::CMat<N>& g, const 
         return;
     }
     wave_lds_fence();
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             tile[lane * PITCH + i * N + j] = live ? g.re[i][j] : 0.0;
             tile[lane * PITCH + N * N + i * N + j] = live ? g.im[i][j] : 0.0;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArg
     }
     sympa::CMat<N> g1, g2;
     double gw[N];
-#pragma unroll
+SYMPA_UNROLL
     for (int k = 0; k < N; ++k) gw[k] = 0.0;
     // every gradient is linear in go: run the adjoint with go = 1 and scale afterwards (the fused loss
     // needs the distance before it knows go)
@@ -154,14 +154,14 @@ __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArg
     }
     {
         const double gs_ = go * sc;
-#pragma unroll
+SYMPA_UNROLL
         for (int r = 0; r < N; ++r)
-#pragma unroll
+SYMPA_UNROLL
             for (int c = 0; c < N; ++c) {
                 g1.re[r][c] *= gs_; g1.im[r][c] *= gs_;
                 g2.re[r][c] *= gs_; g2.im[r][c] *= gs_;
             }
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < N; ++k) gw[k] *= gs_;
     }
     if (live && f.out != nullptr) f.out[i] = bad ? __builtin_nan("") : dist * sc;
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArg
         }
     } else if (live) {
         // per-pair rows (a pair with an out-of-range index contributes zeros, like the scatter form skips it)
-#pragma unroll
+SYMPA_UNROLL
         for (int r = 0; r < N; ++r)
-#pragma unroll
+SYMPA_UNROLL
             for (int c = 0; c < N; ++c) {
                 a.g1[i * ROW + r * N + c] = bad ? 0.0 : g1.re[r][c];
                 a.g1[i * ROW + N * N + r * N + c] = bad ? 0.0 : g1.im[r][c];
@@ -189,23 +189,23 @@ __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArg
     }
     // reductions over the wave, one atomic per wave
     if (a.gw != nullptr && f.metric == sympa::METRIC_WSUM) {
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < N; ++k) {
             double x = (live && !bad) ? gw[k] : 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
             if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.gw + k, x);
         }
     }
     if (a.gscale != nullptr && f.scale != nullptr) {
         double x = (live && !bad && sc_active) ? go * dist * f.inv_scale_coef : 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
         if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.gscale, x);
     }
     if (a.loss != nullptr && a.graph_dist != nullptr) {
         double x = loss_i;
-#pragma unroll
+SYMPA_UNROLL
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
         if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.loss, x);
     }
@@ -253,5 +253,8 @@ SYMPA_BWD_LARGE(7, bounded)
 SYMPA_BWD_LARGE(8, upper)
 SYMPA_BWD_LARGE(8, bounded)
 #undef SYMPA_BWD_LARGE
+
+// dims 9..16: siegel_bwd_rolled.hip (the same adjoint with rolled loops over scratch arrays)
+int launch_bwd_rolled(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
 
 }  // namespace sympa_hip

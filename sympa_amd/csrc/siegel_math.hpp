@@ -39,6 +39,13 @@
 #define SYMPA_HD inline
 #endif
 
+// Every loop over matrix indices is fully unrolled so that the matrices live in registers (static indices).  One
+// translation unit (siegel_bwd_rolled.hip: backward for dims 9..16) defines SYMPA_UNROLL as `nounroll` before including
+// these headers: the same arithmetic then runs as rolled loops over per-lane scratch arrays.
+#ifndef SYMPA_UNROLL
+#define SYMPA_UNROLL _Pragma("unroll")
+#endif
+
 namespace sympa {
 
 enum Model : int { MODEL_UPPER = 0, MODEL_BOUNDED = 1 };
@@ -140,9 +147,9 @@ struct Tri {
 // ---------------------------------------------------------------------------------------------
 template <int N>
 SYMPA_HD void load_point(const double* __restrict__ p, CMat<N>& z) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             z.re[i][j] = p[(i <= j) ? i * N + j : j * N + i];
             z.im[i][j] = p[N * N + ((i <= j) ? i * N + j : j * N + i)];
@@ -156,18 +163,18 @@ SYMPA_HD void load_point(const double* __restrict__ p, CMat<N>& z) {
 template <int N>
 SYMPA_HD bool chol_real(const double (&y)[N][N], Tri<N, false>& l) {
     bool ok = true;
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) {
         double s = y[j][j];
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < j; ++k) s = d_fma(-l.re[j][k], l.re[j][k], s);
         ok = ok && (s > 0.0);
         const double r = d_rsqrt(s);
         l.rdiag[j] = r;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = j + 1; i < N; ++i) {
             double t = y[j][i];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < j; ++k) t = d_fma(-l.re[i][k], l.re[j][k], t);
             l.re[i][j] = t * r;
         }
@@ -180,15 +187,15 @@ SYMPA_HD bool chol_real(const double (&y)[N][N], Tri<N, false>& l) {
 template <int N>
 SYMPA_HD bool chol_id_minus_wwh(const CMat<N>& w, Tri<N, true>& c) {
     bool ok = true;
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) {
         double s = 1.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int l = 0; l < N; ++l) {
             s = d_fma(-w.re[j][l], w.re[j][l], s);
             s = d_fma(-w.im[j][l], w.im[j][l], s);
         }
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < j; ++k) {
             s = d_fma(-c.re[j][k], c.re[j][k], s);
             s = d_fma(-c.im[j][k], c.im[j][k], s);
@@ -196,11 +203,11 @@ SYMPA_HD bool chol_id_minus_wwh(const CMat<N>& w, Tri<N, true>& c) {
         ok = ok && (s > 0.0);
         const double r = d_rsqrt(s);
         c.rdiag[j] = r;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = j + 1; i < N; ++i) {
             // a_ij = - sum_l w_il conj(w_jl)          (i != j)
             double tr = 0.0, ti = 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int l = 0; l < N; ++l) {
                 tr = d_fma(-w.re[i][l], w.re[j][l], tr);
                 tr = d_fma(-w.im[i][l], w.im[j][l], tr);
@@ -208,7 +215,7 @@ SYMPA_HD bool chol_id_minus_wwh(const CMat<N>& w, Tri<N, true>& c) {
                 ti = d_fma(w.re[i][l], w.im[j][l], ti);
             }
             // minus sum_k c_ik conj(c_jk)
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < j; ++k) {
                 tr = d_fma(-c.re[i][k], c.re[j][k], tr);
                 tr = d_fma(-c.im[i][k], c.im[j][k], tr);
@@ -227,12 +234,12 @@ SYMPA_HD bool chol_id_minus_wwh(const CMat<N>& w, Tri<N, true>& c) {
 // ---------------------------------------------------------------------------------------------
 template <int N, bool COMPLEX>
 SYMPA_HD void solve_left(const Tri<N, COMPLEX>& l, CMat<N>& e) {
-#pragma unroll
+SYMPA_UNROLL
     for (int c = 0; c < N; ++c) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) {
             double tr = e.re[i][c], ti = e.im[i][c];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < i; ++k) {
                 tr = d_fma(-l.re[i][k], e.re[k][c], tr);
                 ti = d_fma(-l.re[i][k], e.im[k][c], ti);
@@ -250,12 +257,12 @@ SYMPA_HD void solve_left(const Tri<N, COMPLEX>& l, CMat<N>& e) {
 // E <- E * L2^-T   (solve X L2^T = E row by row; plain transpose, no conjugation)
 template <int N, bool COMPLEX>
 SYMPA_HD void solve_right_t(const Tri<N, COMPLEX>& l, CMat<N>& e) {
-#pragma unroll
+SYMPA_UNROLL
     for (int r = 0; r < N; ++r) {
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             double tr = e.re[r][j], ti = e.im[r][j];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < j; ++k) {
                 tr = d_fma(-e.re[r][k], l.re[j][k], tr);
                 ti = d_fma(-e.im[r][k], l.re[j][k], ti);
@@ -282,19 +289,19 @@ struct Herm {
 
 template <int N>
 SYMPA_HD void gram(const CMat<N>& e, Herm<N>& h) {
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) {
         double s = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) {
             s = d_fma(e.re[i][j], e.re[i][j], s);
             s = d_fma(e.im[i][j], e.im[i][j], s);
         }
         h.d[j] = s;
-#pragma unroll
+SYMPA_UNROLL
         for (int k = j + 1; k < N; ++k) {
             double tr = 0.0, ti = 0.0;   // sum_i conj(e_ij) e_ik
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i) {
                 tr = d_fma(e.re[i][j], e.re[i][k], tr);
                 tr = d_fma(e.im[i][j], e.im[i][k], tr);
@@ -335,7 +342,7 @@ SYMPA_HD void jacobi_rotate(Herm<N>& h, const int p, const int q) {   // p < q, 
         h.d[q] += ua2;
         h.re[p][q] = 0.0;
         h.im[p][q] = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < N; ++k) {
             if (k == p || k == q) continue;
             // x = h_kp, y = h_kq  (conjugate when the stored element is the transposed one)
@@ -360,9 +367,9 @@ SYMPA_HD void jacobi_sweep(Herm<N>& h) {
         jacobi_rotate<N>(h, 0, 2); jacobi_rotate<N>(h, 1, 3);
         jacobi_rotate<N>(h, 0, 3); jacobi_rotate<N>(h, 1, 2);
     } else {        // cyclic by rows
-#pragma unroll
+SYMPA_UNROLL
         for (int p = 0; p < N - 1; ++p) {
-#pragma unroll
+SYMPA_UNROLL
             for (int q = p + 1; q < N; ++q) jacobi_rotate<N>(h, p, q);
         }
     }
@@ -372,10 +379,10 @@ template <int N>
 SYMPA_HD void herm_norms(const Herm<N>& h, double& off2, double& diag2) {
     off2 = 0.0;
     diag2 = 0.0;
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) {
         diag2 = d_fma(h.d[j], h.d[j], diag2);
-#pragma unroll
+SYMPA_UNROLL
         for (int k = j + 1; k < N; ++k) {
             off2 = d_fma(h.re[j][k], h.re[j][k], off2);
             off2 = d_fma(h.im[j][k], h.im[j][k], off2);
@@ -417,9 +424,9 @@ SYMPA_HD void jacobi_diag_update(Herm<N>& h, const int p, const int q) {
 
 template <int N>
 SYMPA_HD void jacobi_final_sweep(Herm<N>& h) {
-#pragma unroll
+SYMPA_UNROLL
     for (int p = 0; p < N - 1; ++p) {
-#pragma unroll
+SYMPA_UNROLL
         for (int q = p + 1; q < N; ++q) jacobi_diag_update<N>(h, p, q);
     }
 }
@@ -434,14 +441,14 @@ constexpr double FINISH_NEGLIGIBLE2 = 1e-24;
 template <int N>
 SYMPA_HD bool jacobi_can_finish(const Herm<N>& h) {
     double diag2 = 0.0;
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) diag2 = d_fma(h.d[j], h.d[j], diag2);
     const double floor2 = FINISH_NEGLIGIBLE2 * diag2;
     double off2 = 0.0;
     bool ok = true;
-#pragma unroll
+SYMPA_UNROLL
     for (int p = 0; p < N - 1; ++p) {
-#pragma unroll
+SYMPA_UNROLL
         for (int q = p + 1; q < N; ++q) {
             const double a2 = d_fma(h.re[p][q], h.re[p][q], h.im[p][q] * h.im[p][q]);
             const double delta = h.d[q] - h.d[p];
@@ -463,7 +470,7 @@ constexpr int jacobi_blind_sweeps() { return N <= 2 ? 1 : (N <= 4 ? 3 : 4); }
 template <int N>
 SYMPA_HD bool herm_eigenvalues_jacobi(Herm<N>& h) {
     if (N == 1) return true;
-#pragma unroll
+SYMPA_UNROLL
     for (int sweep = 0; sweep < jacobi_blind_sweeps<N>(); ++sweep) jacobi_sweep<N>(h);
     if (N == 2) return true;    // a single rotation diagonalises a 2 x 2 matrix exactly
     bool conv = false;
@@ -491,13 +498,13 @@ SYMPA_HD void herm_get(const Herm<N>& h, int i, int j, double& re, double& im) {
 
 template <int N>
 SYMPA_HD void herm_tridiagonalize(Herm<N>& h, double (&a)[N], double (&b2)[N]) {
-#pragma unroll
+SYMPA_UNROLL
     for (int k = 0; k < N - 2; ++k) {
         constexpr int dummy = 0; (void)dummy;
         // x_i = H[i][k], i = k+1 .. N-1
         double vr[N], vi[N];
         double sig2 = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = k + 1; i < N; ++i) {
             herm_get<N>(h, i, k, vr[i], vi[i]);
             if (i > k + 1) sig2 = d_fma(vr[i], vr[i], d_fma(vi[i], vi[i], sig2));
@@ -518,10 +525,10 @@ SYMPA_HD void herm_tridiagonalize(Herm<N>& h, double (&a)[N], double (&b2)[N]) {
         // p = beta A v
         double qr[N], qi[N];
         double kk = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = k + 1; i < N; ++i) {
             double tr = h.d[i] * vr[i], ti = h.d[i] * vi[i];
-#pragma unroll
+SYMPA_UNROLL
             for (int j = k + 1; j < N; ++j) {
                 if (j == i) continue;
                 double ar, ai;
@@ -533,13 +540,13 @@ SYMPA_HD void herm_tridiagonalize(Herm<N>& h, double (&a)[N], double (&b2)[N]) {
             kk = d_fma(vr[i], qr[i], kk); kk = d_fma(vi[i], qi[i], kk);     // Re(v^H p)
         }
         kk *= 0.5 * beta;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = k + 1; i < N; ++i) { qr[i] = d_fma(-kk, vr[i], qr[i]); qi[i] = d_fma(-kk, vi[i], qi[i]); }
         // A <- A - v q^H - q v^H
-#pragma unroll
+SYMPA_UNROLL
         for (int i = k + 1; i < N; ++i) {
             h.d[i] -= 2.0 * d_fma(vr[i], qr[i], vi[i] * qi[i]);
-#pragma unroll
+SYMPA_UNROLL
             for (int j = i + 1; j < N; ++j) {
                 // v_i conj(q_j) + q_i conj(v_j)
                 double tr = d_fma(vr[i], qr[j], vi[i] * qi[j]);
@@ -564,20 +571,20 @@ SYMPA_HD bool tridiag_ql(double (&d)[N], double (&e2)[N]) {
     int l = 0;
     bool done = false;
     for (int iter = 0; iter < 40 * N; ++iter) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N - 1; ++i)
             if (e2[i] <= TOL * fabs(d[i] * d[i + 1]) + 1e-290) e2[i] = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N - 1; ++i)
             if (l == i && e2[i] == 0.0) l = i + 1;
         done = l >= N - 1;
         if (wave_all(done)) break;
         int m = N - 1;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = N - 2; i >= 0; --i)
             if (i >= l && e2[i] == 0.0) m = i;
         double dl = 0.0, dl1 = 0.0, el = 1.0, dm = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) {
             if (i == l) dl = d[i];
             if (i == l + 1) dl1 = d[i];
@@ -592,7 +599,7 @@ SYMPA_HD bool tridiag_ql(double (&d)[N], double (&e2)[N]) {
         const double rr = d_sqrt(d_fma(sg, sg, 1.0));
         const double sigma = dl - rte * d_rcp(sg + copysign(rr, sg));
         double c = 1.0, sn = 0.0, gamma = dm - sigma, p = gamma * gamma;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = N - 2; i >= 0; --i) {
             if (!done && i >= l && i <= m - 1) {
                 const double bb = e2[i];
@@ -610,7 +617,7 @@ SYMPA_HD bool tridiag_ql(double (&d)[N], double (&e2)[N]) {
             }
         }
         if (!done) {
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i) {
                 if (i == l) d[i] = sigma + gamma;
                 if (i < N - 1 && i == l) e2[i] = sn * p;
@@ -668,7 +675,7 @@ SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
         double sigma = dl - rte * d_rcp(sg + copysign(rr, sg));
         sigma = idle ? dl : sigma;
         double c = 1.0, sn = 0.0, gamma = d[N - 1] - sigma, p = gamma * gamma;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = N - 2; i >= L; --i) {
             const double bb = e2[i];
             const double r = p + bb;
@@ -714,7 +721,7 @@ SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
         double a[N], b2[N];
         herm_tridiagonalize<N>(h, a, b2);
         const bool ok = tridiag_ql_lockstep<N>(a, b2);
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) h.d[i] = a[i];
         return ok;
     }
@@ -740,9 +747,9 @@ SYMPA_HD double vvd_from_sinh2(double lambda, double inv_eps) {
 template <int N>
 SYMPA_HD void sort_ascending(double (&v)[N]) {
     // odd-even transposition network: N rounds, static indices
-#pragma unroll
+SYMPA_UNROLL
     for (int round = 0; round < N; ++round) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = (round & 1); i + 1 < N; i += 2) {
             const double lo = fmin(v[i], v[i + 1]);
             const double hi = fmax(v[i], v[i + 1]);
@@ -757,29 +764,29 @@ template <int N>
 SYMPA_HD double reduce_metric(double (&v)[N], int metric, const double* __restrict__ w) {
     double acc = 0.0;
     if (metric == METRIC_RIEM) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) acc = d_fma(v[i], v[i], acc);
         return d_sqrt(acc);
     }
     if (metric == METRIC_FONE) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) acc += v[i];
         return acc;
     }
     if (metric == METRIC_FINF) {
         acc = v[0];
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 1; i < N; ++i) acc = fmax(acc, v[i]);
         return acc;
     }
     sort_ascending<N>(v);
     if (metric == METRIC_FMIN) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) acc = d_fma(2.0 * i, v[i], acc);
         return acc;
     }
     // METRIC_WSUM: sum relu(w_i) v_i
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) acc = d_fma(fmax(w[i], 0.0), v[i], acc);
     return acc;
 }
@@ -802,19 +809,19 @@ SYMPA_HD double distance_from_e(const CMat<N>& e, const bool ok, int metric, con
     // eigenvalues; fmax(lambda, 0) below would turn a NaN into distance 0, so finiteness is tested BEFORE the clamp
     // (the reference yields NaN and fails its assert, siegel_manifold.py:64-66).
     bool finite = true;
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {
         finite = finite && d_finite(h.d[i]);
         v[i] = vvd_from_sinh2(fmax(h.d[i], 0.0) * scale, inv_eps);
     }
     if (!finite) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) v[i] = __builtin_nan("");
     }
 
     if (vvd != nullptr) {
         sort_ascending<N>(v);
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) vvd[i] = v[i];
     }
     double out = reduce_metric<N>(v, metric, w);
@@ -835,9 +842,9 @@ SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int met
             Tri<N, false> l1, l2;
             ok = chol_real<N>(z1.im, l1);
             ok = chol_real<N>(z2.im, l2) && ok;
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
                 for (int j = 0; j < N; ++j) {
                     e.re[i][j] = z2.re[i][j] - z1.re[i][j];
                     e.im[i][j] = z2.im[i][j] - z1.im[i][j];
@@ -848,9 +855,9 @@ SYMPA_HD double pair_distance_mats(const CMat<N>& z1, const CMat<N>& z2, int met
             Tri<N, true> c1, c2;
             ok = chol_id_minus_wwh<N>(z1, c1);
             ok = chol_id_minus_wwh<N>(z2, c2) && ok;
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
                 for (int j = 0; j < N; ++j) {
                     e.re[i][j] = z2.re[i][j] - z1.re[i][j];
                     e.im[i][j] = z2.im[i][j] - z1.im[i][j];
@@ -887,9 +894,9 @@ SYMPA_HD constexpr int low_index(int i, int j) { return i * (i - 1) / 2 + j; }  
 template <int N, int MODEL>
 SYMPA_HD bool pack_point(const CMat<N>& z, double (&p)[PointPack<N, MODEL>::LEN]) {
     using P = PointPack<N, MODEL>;
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = i; j < N; ++j) {
             p[tri_index(N, i, j)] = z.re[i][j];
             p[P::OFF_IM + tri_index(N, i, j)] = z.im[i][j];
@@ -900,14 +907,14 @@ SYMPA_HD bool pack_point(const CMat<N>& z, double (&p)[PointPack<N, MODEL>::LEN]
     else ok = chol_id_minus_wwh<N>(z, l);
     // A = L^-1, column by column:  A[j][j] = 1 / L[j][j],   A[i][j] = -(1 / L[i][i]) sum_{k=j}^{i-1} L[i][k] A[k][j]
     double ar[N][N], ai[N][N];
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) {
         ar[j][j] = l.rdiag[j];
         ai[j][j] = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = j + 1; i < N; ++i) {
             double tr = 0.0, ti = 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int k = j; k < i; ++k) {
                 tr = d_fma(l.re[i][k], ar[k][j], tr);
                 if (MODEL != MODEL_UPPER) {
@@ -920,10 +927,10 @@ SYMPA_HD bool pack_point(const CMat<N>& z, double (&p)[PointPack<N, MODEL>::LEN]
             ai[i][j] = -ti * l.rdiag[i];
         }
     }
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {
         p[P::OFF_DIAG + i] = ar[i][i];
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < i; ++j) {
             p[P::OFF_LRE + low_index(i, j)] = ar[i][j];
             if constexpr (MODEL != MODEL_UPPER) p[P::OFF_LIM + low_index(i, j)] = ai[i][j];
@@ -940,9 +947,9 @@ SYMPA_HD void e_from_packed(const P1& p1, const P2& p2, CMat<N>& e) {
     constexpr bool CPLX = MODEL != MODEL_UPPER;
     // D = Z2 - Z1 (symmetric: upper triangle)
     double dr[N][N], di[N][N];
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = i; j < N; ++j) {
             dr[i][j] = p2[tri_index(N, i, j)] - p1[tri_index(N, i, j)];
             di[i][j] = p2[P::OFF_IM + tri_index(N, i, j)] - p1[P::OFF_IM + tri_index(N, i, j)];
@@ -951,12 +958,12 @@ SYMPA_HD void e_from_packed(const P1& p1, const P2& p2, CMat<N>& e) {
         }
     // T = A1 D   (A1 lower triangular)
     double tr[N][N], ti[N][N];
-#pragma unroll
+SYMPA_UNROLL
     for (int r = 0; r < N; ++r)
-#pragma unroll
+SYMPA_UNROLL
         for (int c = 0; c < N; ++c) {
             double xr = p1[P::OFF_DIAG + r] * dr[r][c], xi = p1[P::OFF_DIAG + r] * di[r][c];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < r; ++k) {
                 const double lr = p1[P::OFF_LRE + low_index(r, k)];
                 xr = d_fma(lr, dr[k][c], xr);
@@ -971,12 +978,12 @@ SYMPA_HD void e_from_packed(const P1& p1, const P2& p2, CMat<N>& e) {
             ti[r][c] = xi;
         }
     // E = T A2^T (plain transpose):  E[r][c] = sum_{k <= c} T[r][k] A2[c][k]
-#pragma unroll
+SYMPA_UNROLL
     for (int r = 0; r < N; ++r)
-#pragma unroll
+SYMPA_UNROLL
         for (int c = 0; c < N; ++c) {
             double xr = tr[r][c] * p2[P::OFF_DIAG + c], xi = ti[r][c] * p2[P::OFF_DIAG + c];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < c; ++k) {
                 const double lr = p2[P::OFF_LRE + low_index(c, k)];
                 xr = d_fma(tr[r][k], lr, xr);

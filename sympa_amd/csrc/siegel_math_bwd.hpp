@@ -46,7 +46,7 @@ SYMPA_HD void jacobi_rotate_vec(Herm<N>& h, CMat<N>& v, const int p, const int q
     h.d[q] += ua2;
     h.re[p][q] = 0.0;
     h.im[p][q] = 0.0;
-#pragma unroll
+SYMPA_UNROLL
     for (int k = 0; k < N; ++k) {
         if (k == p || k == q) continue;
         double xr, xi, yr, yi;
@@ -59,7 +59,7 @@ SYMPA_HD void jacobi_rotate_vec(Herm<N>& h, CMat<N>& v, const int p, const int q
         if (k < p) { h.re[k][p] = nxr; h.im[k][p] = nxi; } else { h.re[p][k] = nxr; h.im[p][k] = -nxi; }
         if (k < q) { h.re[k][q] = nyr; h.im[k][q] = nyi; } else { h.re[q][k] = nyr; h.im[q][k] = -nyi; }
     }
-#pragma unroll
+SYMPA_UNROLL
     for (int k = 0; k < N; ++k) {   // columns p, q of V
         const double xr = v.re[k][p], xi = v.im[k][p], yr = v.re[k][q], yi = v.im[k][q];
         v.re[k][p] = d_fma(-wi, yi, d_fma(-wr, yr, c * xr));
@@ -73,9 +73,9 @@ constexpr double JACOBI_VEC_TOL2 = 1e-22;
 
 template <int N>
 SYMPA_HD bool herm_eigen_vectors(Herm<N>& h, CMat<N>& v) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) { v.re[i][j] = (i == j) ? 1.0 : 0.0; v.im[i][j] = 0.0; }
     if (N == 1) return true;
     bool conv = false;
@@ -89,9 +89,9 @@ SYMPA_HD bool herm_eigen_vectors(Herm<N>& h, CMat<N>& v) {
             jacobi_rotate_vec<N>(h, v, 0, 2); jacobi_rotate_vec<N>(h, v, 1, 3);
             jacobi_rotate_vec<N>(h, v, 0, 3); jacobi_rotate_vec<N>(h, v, 1, 2);
         } else {
-#pragma unroll
+SYMPA_UNROLL
             for (int p = 0; p < N - 1; ++p) {
-#pragma unroll
+SYMPA_UNROLL
                 for (int q = p + 1; q < N; ++q) jacobi_rotate_vec<N>(h, v, p, q);
             }
         }
@@ -102,12 +102,12 @@ SYMPA_HD bool herm_eigen_vectors(Herm<N>& h, CMat<N>& v) {
 // out_jk = sum_i s_i V_ji conj(V_ki)    (full Hermitian matrix, both triangles)
 template <int N>
 SYMPA_HD void herm_from_eig(const CMat<N>& v, const double (&s)[N], CMat<N>& out) {
-#pragma unroll
+SYMPA_UNROLL
     for (int j = 0; j < N; ++j) {
-#pragma unroll
+SYMPA_UNROLL
         for (int k = j; k < N; ++k) {
             double tr = 0.0, ti = 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i) {
                 const double ar = s[i] * v.re[j][i], ai = s[i] * v.im[j][i];
                 tr = d_fma(ar, v.re[k][i], tr);
@@ -124,12 +124,12 @@ SYMPA_HD void herm_from_eig(const CMat<N>& v, const double (&s)[N], CMat<N>& out
 // c = alpha * a * b
 template <int N>
 SYMPA_HD void cmatmul(const CMat<N>& a, const CMat<N>& b, double alpha, CMat<N>& c) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             double tr = 0.0, ti = 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < N; ++k) {
                 tr = d_fma(a.re[i][k], b.re[k][j], tr);
                 tr = d_fma(-a.im[i][k], b.im[k][j], tr);
@@ -144,12 +144,12 @@ SYMPA_HD void cmatmul(const CMat<N>& a, const CMat<N>& b, double alpha, CMat<N>&
 // c = alpha * a * b^H
 template <int N>
 SYMPA_HD void cmatmul_bh(const CMat<N>& a, const CMat<N>& b, double alpha, CMat<N>& c) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             double tr = 0.0, ti = 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < N; ++k) {   // a_ik conj(b_jk)
                 tr = d_fma(a.re[i][k], b.re[j][k], tr);
                 tr = d_fma(a.im[i][k], b.im[j][k], tr);
@@ -171,12 +171,12 @@ SYMPA_HD void tri_elem(const Tri<N, COMPLEX>& l, const double (&diag)[N], int i,
 // X <- L^-H X   (back substitution, column by column)
 template <int N, bool COMPLEX>
 SYMPA_HD void solve_lh_left(const Tri<N, COMPLEX>& l, CMat<N>& x) {
-#pragma unroll
+SYMPA_UNROLL
     for (int c = 0; c < N; ++c) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = N - 1; i >= 0; --i) {
             double tr = x.re[i][c], ti = x.im[i][c];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = i + 1; k < N; ++k) {   // (L^H)_ik = conj(L_ki)
                 tr = d_fma(-l.re[k][i], x.re[k][c], tr);
                 ti = d_fma(-l.re[k][i], x.im[k][c], ti);
@@ -194,12 +194,12 @@ SYMPA_HD void solve_lh_left(const Tri<N, COMPLEX>& l, CMat<N>& x) {
 // X <- X M^-1 with M = L (CONJ = false) or conj(L) (CONJ = true); row by row, columns from the right
 template <int N, bool COMPLEX, bool CONJ>
 SYMPA_HD void solve_l_right(const Tri<N, COMPLEX>& l, CMat<N>& x) {
-#pragma unroll
+SYMPA_UNROLL
     for (int r = 0; r < N; ++r) {
-#pragma unroll
+SYMPA_UNROLL
         for (int j = N - 1; j >= 0; --j) {
             double tr = x.re[r][j], ti = x.im[r][j];
-#pragma unroll
+SYMPA_UNROLL
             for (int k = j + 1; k < N; ++k) {   // minus x_rk M_kj
                 const double mi = COMPLEX ? (CONJ ? -l.im[k][j] : l.im[k][j]) : 0.0;
                 tr = d_fma(-x.re[r][k], l.re[k][j], tr);
@@ -221,19 +221,19 @@ SYMPA_HD void solve_l_right(const Tri<N, COMPLEX>& l, CMat<N>& x) {
 template <int N, bool COMPLEX>
 SYMPA_HD void chol_adjoint(const Tri<N, COMPLEX>& l, CMat<N>& m, double scale, CMat<N>& abar) {
     double diag[N];
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) diag[i] = d_rcp(l.rdiag[i]);
     solve_lh_left<N, COMPLEX>(l, m);           // m = L^-H M
     // Lbar = scale * tril(m)
     // P = Phi(L^H Lbar):  P_ij = sum_{k >= max(i,j)} conj(L_ki) Lbar_kj,  for i >= j
     CMat<N> p;
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             double tr = 0.0, ti = 0.0;
             if (i >= j) {
-#pragma unroll
+SYMPA_UNROLL
                 for (int k = i; k < N; ++k) {
                     double lr, li;
                     tri_elem<N, COMPLEX>(l, diag, k, i, lr, li);
@@ -254,9 +254,9 @@ SYMPA_HD void chol_adjoint(const Tri<N, COMPLEX>& l, CMat<N>& m, double scale, C
     // S = L^-H P L^-1
     solve_lh_left<N, COMPLEX>(l, p);
     solve_l_right<N, COMPLEX, false>(l, p);
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             abar.re[i][j] = 0.5 * (p.re[i][j] + p.re[j][i]);
             abar.im[i][j] = COMPLEX ? 0.5 * (p.im[i][j] - p.im[j][i]) : 0.0;
@@ -281,9 +281,9 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
         ok = chol_id_minus_wwh<N>(z1, l1);
         ok = chol_id_minus_wwh<N>(z2, l2) && ok;
     }
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             e.re[i][j] = z2.re[i][j] - z1.re[i][j];
             e.im[i][j] = z2.im[i][j] - z1.im[i][j];
@@ -299,7 +299,7 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
     double vv[N], dv[N], lam[N];
     int rank[N];
     bool finite = true;
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {
         finite = finite && d_finite(h.d[i]);     // before the clamp: fmax drops a NaN
         lam[i] = fmax(h.d[i], 0.0);
@@ -319,42 +319,42 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
         vv[i] = d_log1p(u);
         dv[i] = deriv;
     }
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {   // ascending rank, ties broken by index
         int r = 0;
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) r += (vv[j] < vv[i] || (vv[j] == vv[i] && j < i)) ? 1 : 0;
         rank[i] = r;
     }
     double out = 0.0, vbar[N];
     if (metric == METRIC_RIEM) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) out = d_fma(vv[i], vv[i], out);
         out = d_sqrt(out);
         const double inv = (out > 0.0) ? d_rcp(out) : 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) vbar[i] = vv[i] * inv;
     } else if (metric == METRIC_FONE) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) { out += vv[i]; vbar[i] = 1.0; }
     } else if (metric == METRIC_FINF) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) { const bool top = rank[i] == N - 1; vbar[i] = top ? 1.0 : 0.0; out += top ? vv[i] : 0.0; }
     } else if (metric == METRIC_FMIN) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) { vbar[i] = 2.0 * rank[i]; out = d_fma(vbar[i], vv[i], out); }
     } else {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) {
             const double wk = w[rank[i]];
             vbar[i] = fmax(wk, 0.0);
             out = d_fma(vbar[i], vv[i], out);
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < N; ++k) gw[k] += (rank[i] == k && wk > 0.0) ? go * vv[i] : 0.0;
         }
     }
     double phi[N], philam[N];
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) { phi[i] = go * vbar[i] * dv[i]; philam[i] = phi[i] * h.d[i]; }
 
     CMat<N> hbar, ebar, gm, km;
@@ -366,9 +366,9 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
     solve_lh_left<N, CPLX>(l1, ebar);
     solve_l_right<N, CPLX, true>(l2, ebar);
     if (CPLX) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) km.im[i][j] = -km.im[i][j];    // conj(K)
     }
     CMat<N> a1, a2;
@@ -376,9 +376,9 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
     chol_adjoint<N, CPLX>(l2, km, -2.0, a2);
 
     if (MODEL == MODEL_UPPER) {
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) {
                 const double dr = 0.5 * (ebar.re[i][j] + ebar.re[j][i]);
                 const double di = 0.5 * (ebar.im[i][j] + ebar.im[j][i]);
@@ -392,16 +392,16 @@ SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, 
         CMat<N> t1, t2;
         cmatmul<N>(a1, z1, -2.0, t1);
         cmatmul<N>(a2, z2, -2.0, t2);
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) {
                 t1.re[i][j] -= ebar.re[i][j]; t1.im[i][j] -= ebar.im[i][j];
                 t2.re[i][j] += ebar.re[i][j]; t2.im[i][j] += ebar.im[i][j];
             }
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) {
                 g1.re[i][j] = 0.5 * (t1.re[i][j] + t1.re[j][i]);
                 g1.im[i][j] = 0.5 * (t1.im[i][j] + t1.im[j][i]);

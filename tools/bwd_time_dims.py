@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sympa_amd import data, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-for n, nodes, b in ((4, 5041, 65536), (6, 5000, 65536), (7, 5000, 65536), (8, 45500, 262144)):
+for n, nodes, b in ((4, 5041, 65536), (6, 5000, 65536), (7, 5000, 65536), (8, 45500, 262144), (10, 5000, 16384), (16, 5000, 16384)):
     table = data.trained_like_table(nodes, n, seed=1).to(dev)
     pairs = data.sample_pairs(nodes, b, 0, 1).to(dev)
     gd = torch.rand(b, dtype=torch.float64, device=dev) * 5 + 1
