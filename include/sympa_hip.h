@@ -57,7 +57,10 @@ extern "C" {
 #define SYMPA_FLAG_ANY_ORDER 4 /* forward launches only: dispatch without the in-order barrier bit (hipExtAnyOrderLaunch), so
                                   the launch may start while earlier launches of the same stream still run.  Only for
                                   launches that do not depend on earlier work of that stream (independent batches);
-                                  a later ordinary launch or synchronisation still waits for all of them */
+                                  a later ordinary launch or synchronisation still waits for all of them.  MEASURED on
+                                  gfx950 / ROCm 7.2 (profiles/r02_launch_overhead.txt): no overlap is obtained -- the
+                                  runtime documents the flag as unsupported on GFX9 -- so the fused form below
+                                  (SYMPA_FLAG_FUSE) is what overlaps independent batches */
 
 #define SYMPA_FLAG_FUSE 8 /* sympa_model_forward_batches only (dims <= SYMPA_MAX_DIMS): up to SYMPA_MAX_FUSED_BATCHES
                              consecutive batches per kernel launch instead of one launch per batch */
