@@ -128,7 +128,9 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
  * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):
  *   out[(i - row_begin) * num_rows + j] = Model.forward((i, j)),  i in [row_begin, row_begin + row_count),  j in [0, N)
- * The diagonal is exactly 0 (the reference overwrites it with 0, runner.py:152). */
+ * The diagonal is exactly 0 (the reference overwrites it with 0, runner.py:152).  For the FULL matrix (row_begin = 0,
+ * row_count = num_rows) of dims >= 3 the symmetry d(i, j) = d(j, i) is used: the pairs i <= j are evaluated and every
+ * value is stored at (i, j) and (j, i) (SYMPA_FLAG_NO_SYMMETRY evaluates both orders; a row block always does). */
 int sympa_all_pairs_dist(const double* table, int64_t num_rows, int n, int64_t row_begin, int64_t row_count, int model,
                          int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
                          double* out, int32_t* status, int flags, void* stream);

@@ -34,7 +34,37 @@ struct DistArgs {
     int flags;
     int64_t ap_cols;       // > 0: all-pairs mode, pair p = (ap_row0 + p / ap_cols, p % ap_cols), idx1/idx2 unused
     int64_t ap_row0;
+    int ap_sym;            // all-pairs mode over the FULL matrix using d(i, j) = d(j, i): pair p runs over the
+                           // ap_cols (ap_cols + 1) / 2 pairs i <= j in row-major triangular order and is stored twice
 };
+
+#if defined(__HIPCC__)
+// All-pairs mode: rows of pair p and the place(s) its value goes to.
+__device__ __forceinline__ void ap_pair(const DistArgs& a, const int64_t p, int64_t& r1, int64_t& r2) {
+    if (!a.ap_sym) {
+        r1 = a.ap_row0 + p / a.ap_cols;
+        r2 = p % a.ap_cols;
+        return;
+    }
+    // row i of the upper triangle starts at off(i) = i N - i (i - 1) / 2:  i = floor((2N + 1 - sqrt((2N + 1)^2 - 8 p)) / 2)
+    const int64_t n = a.ap_cols;
+    const double t = (double)(2 * n + 1);
+    int64_t i = (int64_t)((t - sympa::d_sqrt(t * t - 8.0 * (double)p)) * 0.5);
+    i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+    if ((i + 1) * n - (i + 1) * i / 2 <= p) ++i;          // the square root is good to an ulp: at most one step off
+    if (i * n - i * (i - 1) / 2 > p) --i;
+    r1 = i;
+    r2 = i + (p - (i * n - i * (i - 1) / 2));
+}
+__device__ __forceinline__ void ap_store(const DistArgs& a, const int64_t p, const int64_t r1, const int64_t r2, const double d) {
+    if (!a.ap_sym) {
+        __builtin_nontemporal_store(d, a.out + p);
+        return;
+    }
+    __builtin_nontemporal_store(d, a.out + r1 * a.ap_cols + r2);
+    if (r1 != r2) __builtin_nontemporal_store(d, a.out + r2 * a.ap_cols + r1);
+}
+#endif
 
 // thread-local message behind sympa_last_error()
 char* last_error_buffer();

@@ -29,8 +29,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
     int st = 0;
     int64_t r1 = ii, r2 = ii;
     if (a.ap_cols > 0) {
-        r1 = a.ap_row0 + ii / a.ap_cols;
-        r2 = ii % a.ap_cols;
+        ap_pair(a, ii, r1, r2);
     } else if (a.idx1 != nullptr) {
         r1 = a.idx1[ii * a.idx1_stride];
         r2 = a.idx2[ii * a.idx2_stride];
@@ -139,7 +138,10 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
     if (!sympa::d_finite(out)) st |= sympa::ST_NONFINITE;
     if (st & sympa::ST_BAD_INDEX) out = __builtin_nan("");
     if (a.scale != nullptr) out *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);
-    if (live) a.out[i] = out;
+    if (live) {
+        if (a.ap_cols > 0) ap_store(a, i, r1, r2, out);
+        else a.out[i] = out;
+    }
     if (a.status != nullptr) {
         const int flagged = (live && st != 0) ? 1 : 0;
         const unsigned long long mk = __ballot(flagged);

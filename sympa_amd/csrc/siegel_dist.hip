@@ -63,8 +63,7 @@ __device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t firs
     int st = 0;
     int64_t r1 = ii, r2 = ii;
     if (a.ap_cols > 0) {          // all-pairs block of the distance matrix (runner.py:142-154)
-        r1 = a.ap_row0 + ii / a.ap_cols;
-        r2 = ii % a.ap_cols;
+        ap_pair(a, ii, r1, r2);
     } else if (a.idx1 != nullptr) {
         // index batches and outputs stream through once: non-temporal, so they do not evict table rows from L2
         r1 = __builtin_nontemporal_load(a.idx1 + ii * a.idx1_stride);
@@ -101,7 +100,10 @@ __device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t firs
     }
     if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
     if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
-    if (live) __builtin_nontemporal_store(d, a.out + i);
+    if (live) {
+        if (a.ap_cols > 0) ap_store(a, i, r1, r2, d);
+        else __builtin_nontemporal_store(d, a.out + i);
+    }
 
     if (a.status != nullptr) {
         const int flagged = (live && st != 0) ? 1 : 0;
@@ -172,8 +174,7 @@ __global__ __launch_bounds__(64) void siegel_dist_generic_kernel(const DistArgs 
     int st = 0;
     int64_t r1 = ii, r2 = ii;
     if (a.ap_cols > 0) {
-        r1 = a.ap_row0 + ii / a.ap_cols;
-        r2 = ii % a.ap_cols;
+        ap_pair(a, ii, r1, r2);
     } else if (a.idx1 != nullptr) {
         r1 = a.idx1[ii * a.idx1_stride];
         r2 = a.idx2[ii * a.idx2_stride];
@@ -186,7 +187,10 @@ __global__ __launch_bounds__(64) void siegel_dist_generic_kernel(const DistArgs 
                                             a.inv_eps, vv, st);
     if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
     if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);
-    if (live) a.out[i] = d;
+    if (live) {
+        if (a.ap_cols > 0) ap_store(a, i, r1, r2, d);
+        else a.out[i] = d;
+    }
     if (a.status != nullptr) {
         const int flagged = (live && st != 0) ? 1 : 0;
         const unsigned long long m = __ballot(flagged);
@@ -442,6 +446,12 @@ int sympa_all_pairs_dist(const double* table, int64_t num_rows, int n, int64_t r
     a.flags = flags;
     a.ap_cols = num_rows;
     a.ap_row0 = row_begin;
+    // the full matrix: d(i, j) = d(j, i), evaluate the pairs i <= j only and store each value twice (dims >= 3: below that
+    // a pair costs less than the scattered mirror store)
+    if (row_begin == 0 && row_count == num_rows && n >= 3 && !(flags & SYMPA_FLAG_NO_SYMMETRY)) {
+        a.ap_sym = 1;
+        a.b = num_rows * (num_rows + 1) / 2;
+    }
     return launch(a, n, model, stream);
 }
 

@@ -544,7 +544,7 @@ def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None
         rc = lib.sympa_all_pairs_dist(tab.data_ptr(), num_rows, n, int(row_begin), row_count, MODEL_IDS[model],
                                       METRIC_IDS[metric], None if w is None else w.data_ptr(), eps,
                                       None if sc is None else sc.data_ptr(), float(scale_coef), out.data_ptr(),
-                                      st.data_ptr(), 0, _stream())
+                                      st.data_ptr(), int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(tab.device)

@@ -348,7 +348,7 @@ def test_low_lds_gather_variants_bit_identical(dev, model, n):
     # all-pairs matrix with N >= 363 rows (deep grid -> low form) against the pairwise kernel in its default form
     N2 = 400
     t2 = table[:N2].contiguous()
-    mat = ops.all_pairs_dist(t2, model, "riem", packed=False)
+    mat = ops.all_pairs_dist(t2, model, "riem", packed=False, flags=ops.FLAG_NO_SYMMETRY)
     ii, jj = torch.meshgrid(torch.arange(N2, device=dev), torch.arange(N2, device=dev), indexing="ij")
     trip = torch.stack((ii.reshape(-1), jj.reshape(-1)), 1)
     chunks = [ops.model_forward(t2, trip[k:k + 60000].contiguous(), model, "riem", flags=0)
@@ -467,7 +467,7 @@ def test_all_pairs_packed_kernel(dev, model, n):
     w = torch.linspace(-0.2, 1.1, n).to(dev)
     for metric in METRICS:
         full = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=True)
-        ref = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=False)
+        ref = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=False, flags=ops.FLAG_NO_SYMMETRY)
         ops.check_status(dev)
         assert torch.all(full.diagonal() == 0)
         if n >= 3:
@@ -492,3 +492,24 @@ def test_all_pairs_packed_kernel(dev, model, n):
     ops.all_pairs_dist(bad, model, "riem", packed=True)
     with pytest.raises(AssertionError):
         ops.check_status(dev)
+
+
+@pytest.mark.parametrize("n", [3, 5, 8, 10])
+@pytest.mark.parametrize("model", MODELS)
+def test_all_pairs_symmetric_mode_of_the_pairwise_kernels(dev, model, n):
+    """Full matrix through the pairwise kernels (dims >= 5; `packed=False` below that): only the pairs i <= j are
+    evaluated (triangular pair index inverted with one square root per lane), every value stored at (i, j) and (j, i).
+    Against the both-orders evaluation; ragged N around the integer-square-root edge cases."""
+    from sympa_amd import data, ops
+    for N in (1, 2, 63, 64, 65, 257, 700):
+        table = data.trained_like_table(max(N, 2), n, model=model, seed=23, scale=0.2)[:N].contiguous().to(dev)
+        sym = ops.all_pairs_dist(table, model, "fone", packed=False)
+        both = ops.all_pairs_dist(table, model, "fone", packed=False, flags=ops.FLAG_NO_SYMMETRY)
+        ops.check_status(dev)
+        assert sym.shape == (N, N) and torch.all(sym.diagonal() == 0) and torch.equal(sym, sym.T)
+        assert rel_err(sym.cpu(), both.cpu()) < 1e-9, (model, n, N)
+        iu = torch.triu_indices(N, N)
+        if n <= 4:       # the i <= j entries are the same evaluation (n >= 5: the lockstep QL makes the last bits depend
+            assert torch.equal(sym[iu[0], iu[1]], both[iu[0], iu[1]])      # on which pairs share a wave)
+        else:
+            assert rel_err(sym[iu[0], iu[1]].cpu(), both[iu[0], iu[1]].cpu()) < 1e-11
