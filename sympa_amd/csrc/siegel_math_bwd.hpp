@@ -99,6 +99,210 @@ SYMPA_UNROLL
     return conv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// n >= 5: eigenvectors through Householder tridiagonalisation (reflectors kept) + implicit QL with the
+// rotations accumulated (EISPACK tql2 / LAPACK dsteqr) + back-transformation.  A cyclic Jacobi iteration with
+// vectors costs ~200 instructions per rotation, 28 rotations per sweep, 7-8 sweeps at n = 8 (~40 k
+// instructions, half of the whole adjoint); this route costs ~9 k.  Per-lane active block [L, m]: the QL sweep
+// of stage L runs over the static index range [L, N-2] and a lane's steps outside its block are identities
+// (c = 1, s = 0) selected by predicates -- with 4 N instructions of eigenvector update per step the bookkeeping
+// (~40 instructions) is a small part, unlike in the eigenvalue-only iteration (siegel_math.hpp, lockstep QL).
+// The eigenvalues that come out are accurate to eps ||H||; the caller refines them to RELATIVE accuracy with the
+// Rayleigh quotients lambda_i = ||E v_i||^2 (H = E^H E), which the adjoint needs for small lambda (d v / d lambda
+// ~ lambda^-1/2).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD void herm_tridiagonalize_keep(Herm<N>& h, double (&a)[N], double (&e)[N], double (&phr)[N], double (&phi)[N],
+                                       CMat<N>& refl, double (&beta)[N]) {
+SYMPA_UNROLL
+    for (int k = 0; k < N - 2; ++k) {
+        double vr[N], vi[N];
+        double sig2 = 0.0;
+SYMPA_UNROLL
+        for (int i = k + 1; i < N; ++i) {
+            herm_get<N>(h, i, k, vr[i], vi[i]);
+            if (i > k + 1) sig2 = d_fma(vr[i], vr[i], d_fma(vi[i], vi[i], sig2));
+        }
+        const double x02 = d_fma(vr[k + 1], vr[k + 1], vi[k + 1] * vi[k + 1]);
+        const double n2 = x02 + sig2;
+        a[k] = h.d[k];
+        const double nx = d_sqrt(n2);
+        const double ix0 = d_rsqrt(x02 + TINY);
+        const double ax0 = x02 * ix0;
+        const bool x0zero = !(x02 > 0.0);
+        const double pr = x0zero ? 1.0 : vr[k + 1] * ix0, pi = x0zero ? 0.0 : vi[k + 1] * ix0;   // phase of x0
+        const bool reflect = sig2 > 0.0;
+        // T[k+1][k] = -phase ||x|| after the reflection, x0 itself when there is nothing to eliminate
+        e[k] = reflect ? nx : ax0;
+        phr[k] = reflect ? -pr : pr;
+        phi[k] = reflect ? -pi : pi;
+        vr[k + 1] = pr * (ax0 + nx);
+        vi[k + 1] = pi * (ax0 + nx);
+        const double bt = reflect ? d_rcp(nx * (nx + ax0)) : 0.0;
+        beta[k] = bt;
+SYMPA_UNROLL
+        for (int i = k + 1; i < N; ++i) { refl.re[i][k] = vr[i]; refl.im[i][k] = vi[i]; }
+        double qr[N], qi[N];
+        double kk = 0.0;
+SYMPA_UNROLL
+        for (int i = k + 1; i < N; ++i) {
+            double tr = h.d[i] * vr[i], ti = h.d[i] * vi[i];
+SYMPA_UNROLL
+            for (int j = k + 1; j < N; ++j) {
+                if (j == i) continue;
+                double ar, ai;
+                herm_get<N>(h, i, j, ar, ai);
+                tr = d_fma(ar, vr[j], tr); tr = d_fma(-ai, vi[j], tr);
+                ti = d_fma(ar, vi[j], ti); ti = d_fma(ai, vr[j], ti);
+            }
+            qr[i] = bt * tr; qi[i] = bt * ti;
+            kk = d_fma(vr[i], qr[i], kk); kk = d_fma(vi[i], qi[i], kk);
+        }
+        kk *= 0.5 * bt;
+SYMPA_UNROLL
+        for (int i = k + 1; i < N; ++i) { qr[i] = d_fma(-kk, vr[i], qr[i]); qi[i] = d_fma(-kk, vi[i], qi[i]); }
+SYMPA_UNROLL
+        for (int i = k + 1; i < N; ++i) {
+            h.d[i] -= 2.0 * d_fma(vr[i], qr[i], vi[i] * qi[i]);
+SYMPA_UNROLL
+            for (int j = i + 1; j < N; ++j) {
+                double tr = d_fma(vr[i], qr[j], vi[i] * qi[j]);
+                double ti = d_fma(vi[i], qr[j], -vr[i] * qi[j]);
+                tr = d_fma(qr[i], vr[j], d_fma(qi[i], vi[j], tr));
+                ti = d_fma(qi[i], vr[j], d_fma(-qr[i], vi[j], ti));
+                h.re[i][j] -= tr;
+                h.im[i][j] -= ti;
+            }
+        }
+    }
+    a[N - 2] = h.d[N - 2];
+    a[N - 1] = h.d[N - 1];
+    // T[N-1][N-2] = conj of the stored upper element (N-2, N-1)
+    const double lr = h.re[N - 2][N - 1], li = -h.im[N - 2][N - 1];
+    const double l2 = d_fma(lr, lr, li * li);
+    const double il = d_rsqrt(l2 + TINY);
+    const bool lz = !(l2 > 0.0);
+    e[N - 2] = l2 * il;
+    phr[N - 2] = lz ? 1.0 : lr * il;
+    phi[N - 2] = lz ? 0.0 : li * il;
+    e[N - 1] = 0.0;
+}
+
+// Implicit QL with accumulated rotations on the real symmetric tridiagonal (d, e): e[i] couples i and i + 1.
+// z must hold the identity on entry; on exit z's columns are the eigenvectors and d the eigenvalues.
+template <int N>
+SYMPA_HD bool tridiag_ql_vectors(double (&d)[N], double (&e)[N], double (&z)[N][N]) {
+    bool all_ok = true;
+SYMPA_UNROLL
+    for (int L = 0; L < N - 1; ++L) {
+        bool conv = false;
+        for (int it = 0; it < 50; ++it) {
+            // m = the first index >= L whose off-diagonal is negligible (e[N-1] = 0): the block is [L, m]
+            int m = N - 1;
+SYMPA_UNROLL
+            for (int i = N - 2; i >= L; --i) {
+                const bool negl = ql_negligible(e[i] * e[i], d[i], d[i + 1]);
+                e[i] = negl ? 0.0 : e[i];
+                m = negl ? i : m;
+            }
+            conv = (m == L);
+            if (wave_all(conv)) break;
+            // Wilkinson shift from the leading 2 x 2 of the block (tql2): g = d[m] - d[L] + e[L] / (g0 + sign(r0, g0))
+            const double el = conv ? 1.0 : e[L];
+            const double g0 = 0.5 * (d[L + 1] - d[L]) * d_rcp(el);
+            const double r0 = d_sqrt(d_fma(g0, g0, 1.0));
+            const double shift = el * d_rcp(g0 + copysign(r0, g0)) - d[L];
+            double c = 1.0, s = 1.0, p = 0.0, g = 0.0;
+SYMPA_UNROLL
+            for (int i = N - 2; i >= L; --i) {
+                const bool active = !conv && (i < m);
+                const bool start = (m == i + 1);
+                g = start ? d[i + 1] + shift : g;
+                s = start ? 1.0 : s;
+                c = start ? 1.0 : c;
+                p = start ? 0.0 : p;
+                const double f = s * e[i];
+                const double b = c * e[i];
+                const double r2 = d_fma(f, f, g * g);
+                const double ir = d_rsqrt(r2 + TINY);
+                const double r = r2 * ir;
+                const bool rzero = !(r2 > 0.0);
+                const double sn = rzero ? 0.0 : f * ir;
+                const double cn = rzero ? 1.0 : g * ir;
+                if (i + 1 <= N - 2) e[i + 1] = (active && !start) ? r : e[i + 1];
+                const double g2 = d[i + 1] - p;
+                const double rr = d_fma(d[i] - g2, sn, 2.0 * cn * b);
+                const double pn = sn * rr;
+                d[i + 1] = active ? g2 + pn : d[i + 1];
+                const double gn = d_fma(cn, rr, -b);
+                const double ce = active ? cn : 1.0, se = active ? sn : 0.0;
+SYMPA_UNROLL
+                for (int k = 0; k < N; ++k) {
+                    const double zf = z[k][i + 1];
+                    z[k][i + 1] = d_fma(se, z[k][i], ce * zf);
+                    z[k][i] = d_fma(ce, z[k][i], -se * zf);
+                }
+                s = active ? sn : s;
+                c = active ? cn : c;
+                p = active ? pn : p;
+                g = active ? gn : g;
+            }
+            d[L] = conv ? d[L] : d[L] - p;
+            e[L] = conv ? e[L] : g;
+        }
+        all_ok = all_ok && conv;
+    }
+    return all_ok;
+}
+
+// Eigen-decomposition of the Hermitian h: eigenvalues into h.d, eigenvectors into the columns of v.
+template <int N>
+SYMPA_HD bool herm_eigen_vectors_ql(Herm<N>& h, CMat<N>& v) {
+    double a[N], e[N], phr[N], phi[N], beta[N];
+    CMat<N> refl;
+    herm_tridiagonalize_keep<N>(h, a, e, phr, phi, refl, beta);
+    double z[N][N];
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) z[i][j] = (i == j) ? 1.0 : 0.0;
+    const bool ok = tridiag_ql_vectors<N>(a, e, z);
+    // W = Phi Z,  Phi_0 = 1,  Phi_{j+1} = Phi_j * phase(T[j+1][j]):  T = Phi T_real Phi^H
+    double fr = 1.0, fi = 0.0;
+SYMPA_UNROLL
+    for (int j = 0; j < N; ++j) {
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i) { v.re[j][i] = fr * z[j][i]; v.im[j][i] = fi * z[j][i]; }
+        if (j < N - 1) {
+            const double nr = fr * phr[j] - fi * phi[j];
+            const double ni = fr * phi[j] + fi * phr[j];
+            fr = nr; fi = ni;
+        }
+    }
+    // V = P_0 P_1 ... P_{N-3} W,  P_k = I - beta_k v_k v_k^H on the rows k+1 .. N-1
+SYMPA_UNROLL
+    for (int k = N - 3; k >= 0; --k) {
+SYMPA_UNROLL
+        for (int c = 0; c < N; ++c) {
+            double tr = 0.0, ti = 0.0;     // tau = beta * v^H w
+SYMPA_UNROLL
+            for (int i = k + 1; i < N; ++i) {
+                tr = d_fma(refl.re[i][k], v.re[i][c], d_fma(refl.im[i][k], v.im[i][c], tr));
+                ti = d_fma(refl.re[i][k], v.im[i][c], d_fma(-refl.im[i][k], v.re[i][c], ti));
+            }
+            tr *= beta[k]; ti *= beta[k];
+SYMPA_UNROLL
+            for (int i = k + 1; i < N; ++i) {
+                v.re[i][c] = d_fma(-tr, refl.re[i][k], d_fma(ti, refl.im[i][k], v.re[i][c]));
+                v.im[i][c] = d_fma(-tr, refl.im[i][k], d_fma(-ti, refl.re[i][k], v.im[i][c]));
+            }
+        }
+    }
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i) h.d[i] = a[i];
+    return ok;
+}
+
 // out_jk = sum_i s_i V_ji conj(V_ki)    (full Hermitian matrix, both triangles)
 template <int N>
 SYMPA_HD void herm_from_eig(const CMat<N>& v, const double (&s)[N], CMat<N>& out) {
@@ -293,7 +497,31 @@ SYMPA_UNROLL
     Herm<N> h;
     gram<N>(e, h);
     CMat<N> v;
-    const bool conv = herm_eigen_vectors<N>(h, v);
+    bool conv;
+#ifndef SYMPA_BWD_EIGEN_JACOBI
+    if constexpr (N >= 5) {
+        conv = herm_eigen_vectors_ql<N>(h, v);
+        // Rayleigh quotients: lambda_i = v_i^H H v_i = ||E v_i||^2, relative accuracy for the small eigenvalues
+SYMPA_UNROLL
+        for (int c = 0; c < N; ++c) {
+            double acc = 0.0;
+SYMPA_UNROLL
+            for (int r = 0; r < N; ++r) {
+                double tr = 0.0, ti = 0.0;
+SYMPA_UNROLL
+                for (int k = 0; k < N; ++k) {
+                    tr = d_fma(e.re[r][k], v.re[k][c], d_fma(-e.im[r][k], v.im[k][c], tr));
+                    ti = d_fma(e.re[r][k], v.im[k][c], d_fma(e.im[r][k], v.re[k][c], ti));
+                }
+                acc = d_fma(tr, tr, d_fma(ti, ti, acc));
+            }
+            h.d[c] = acc;
+        }
+    } else
+#endif
+    {
+        conv = herm_eigen_vectors<N>(h, v);
+    }
 
     const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
     double vv[N], dv[N], lam[N];

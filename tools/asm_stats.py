@@ -18,7 +18,7 @@ with tempfile.TemporaryDirectory() as d:
 i = 0
 while i < len(lines):
     m = re.match(r"^(_Z\S+):", lines[i])
-    if m and flt in m.group(1) and "siegel" in m.group(1):
+    if m and flt in m.group(1) and ("siegel" in m.group(1) or "allpairs" in m.group(1)):
         name = m.group(1)
         blocks = collections.OrderedDict()
         cur = "entry"
