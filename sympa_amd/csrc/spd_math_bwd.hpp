@@ -77,6 +77,120 @@ SYMPA_HD bool spd_eigh_jacobi(double* a, double* v, double* lam, int n) {
     return conv;
 }
 
+// The same decomposition through Householder tridiagonalisation + implicit QL with accumulated transformations
+// (EISPACK tred2 / tql2, restated): ~4/3 n^3 + ~3 n^3 operations instead of ~10 sweeps x 2 n^3 of the Jacobi iteration,
+// 2.5-3x less work at n = 16.  One matrix per lane with its own (divergent) iteration counts.  a is destroyed.
+SYMPA_HD bool spd_eigh_ql(double* a, double* v, double* lam, double* e, int n) {
+    // tred2: v <- a; reduce to tridiagonal form, accumulate the orthogonal transformation in v
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) v[i * n + j] = a[i * n + j];
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0, scale = 0.0;
+        if (l > 0) {
+            for (int k = 0; k <= l; ++k) scale += fabs(v[i * n + k]);
+            if (!(scale > 0.0)) {
+                e[i] = v[i * n + l];
+            } else {
+                const double iscale = d_rcp(scale);
+                for (int k = 0; k <= l; ++k) {
+                    v[i * n + k] *= iscale;
+                    h += v[i * n + k] * v[i * n + k];
+                }
+                double f = v[i * n + l];
+                double g = -copysign(d_sqrt(h), f);
+                e[i] = scale * g;
+                h -= f * g;
+                v[i * n + l] = f - g;
+                f = 0.0;
+                const double ih = d_rcp(h);
+                for (int j = 0; j <= l; ++j) {
+                    v[j * n + i] = v[i * n + j] * ih;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += v[j * n + k] * v[i * n + k];
+                    for (int k = j + 1; k <= l; ++k) g += v[k * n + j] * v[i * n + k];
+                    e[j] = g * ih;
+                    f += e[j] * v[i * n + j];
+                }
+                const double hh = f * d_rcp(h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = v[i * n + j];
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) v[j * n + k] -= f * e[k] + g * v[i * n + k];
+                }
+            }
+        } else {
+            e[i] = v[i * n + l];
+        }
+        lam[i] = h;
+    }
+    lam[0] = 0.0;
+    e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if (lam[i] != 0.0) {
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g += v[i * n + k] * v[k * n + j];
+                for (int k = 0; k <= l; ++k) v[k * n + j] -= g * v[k * n + i];
+            }
+        }
+        lam[i] = v[i * n + i];
+        v[i * n + i] = 1.0;
+        for (int j = 0; j <= l; ++j) { v[j * n + i] = 0.0; v[i * n + j] = 0.0; }
+    }
+    // tql2
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    bool ok = true;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0;
+        int m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                if (ql_negligible(e[m] * e[m], lam[m], lam[m + 1])) break;
+            }
+            if (m != l) {
+                if (iter++ == 60) { ok = false; break; }
+                double g = (lam[l + 1] - lam[l]) * 0.5 * d_rcp(e[l]);
+                double r = d_sqrt(d_fma(g, g, 1.0));
+                g = lam[m] - lam[l] + e[l] * d_rcp(g + copysign(r, g));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    r = d_sqrt(d_fma(f, f, g * g));
+                    e[i + 1] = r;
+                    if (!(r > 0.0)) {
+                        lam[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    const double ir = d_rcp(r);
+                    s = f * ir;
+                    c = g * ir;
+                    g = lam[i + 1] - p;
+                    r = d_fma(lam[i] - g, s, 2.0 * c * b);
+                    p = s * r;
+                    lam[i + 1] = g + p;
+                    g = d_fma(c, r, -b);
+                    for (int k = 0; k < n; ++k) {
+                        f = v[k * n + i + 1];
+                        v[k * n + i + 1] = d_fma(s, v[k * n + i], c * f);
+                        v[k * n + i] = d_fma(c, v[k * n + i], -s * f);
+                    }
+                }
+                if (!(r > 0.0) && i >= l) continue;
+                lam[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return ok;
+}
+
 // Cholesky x = L L^T into w.l / w.rd (lower); returns "x is positive definite".
 SYMPA_HD bool spd_cholesky(const double* __restrict__ px, int n, double* l, double* rd) {
     bool ok = true;
@@ -138,7 +252,23 @@ SYMPA_HD double spd_pair_backward(SpdBwdWork& w, const double* __restrict__ px, 
     spd_congruence_inv(w.a, w.l, w.rd, n);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) { const double t = 0.5 * (w.a[i * n + j] + w.a[j * n + i]); w.a[i * n + j] = t; w.a[j * n + i] = t; }
+#ifdef SYMPA_SPD_EIGEN_JACOBI
     const bool conv = spd_eigh_jacobi(w.a, w.v, w.lam, n);
+#else
+    // tridiagonal QL (eigenvalues to eps ||A||), then Rayleigh quotients lam_i = v_i^T A v_i with the saved matrix for the
+    // eigenvalues near zero (x ~ y in some directions), where the logarithm's relative accuracy matters
+    for (int k = 0; k < n * n; ++k) w.p[k] = w.a[k];
+    const bool conv = spd_eigh_ql(w.a, w.v, w.lam, w.f, n);
+    for (int c = 0; c < n; ++c) {
+        double acc2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double t = 0.0;
+            for (int k = 0; k < n; ++k) t += w.p[i * n + k] * w.v[k * n + c];
+            acc2 += w.v[i * n + c] * t;
+        }
+        w.lam[c] = acc2;
+    }
+#endif
     double acc = 0.0;
     for (int i = 0; i < n; ++i) {
         ok = ok && (w.lam[i] > -1.0);
