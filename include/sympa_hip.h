@@ -65,6 +65,8 @@ extern "C" {
 #define SYMPA_FLAG_FUSE 8 /* sympa_model_forward_batches only (dims <= SYMPA_MAX_DIMS): up to SYMPA_MAX_FUSED_BATCHES
                              consecutive batches per kernel launch instead of one launch per batch */
 #define SYMPA_MAX_FUSED_BATCHES 32
+#define SYMPA_FLAG_COOP 32 /* dims 6 and 8 only: run the sixteen-lanes-per-pair kernel instead of the one-pair-per-lane one
+                              (kept for the A/B of DESIGN.md section 5; it is 2-2.5x slower there) */
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */

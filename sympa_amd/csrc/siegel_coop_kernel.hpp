@@ -163,6 +163,8 @@ int launch_siegel_coop_m(const DistArgs& a, hipStream_t s) {
 template <int MODEL>
 int launch_siegel_coop_model(const DistArgs& a, int n, hipStream_t s) {
     switch (n) {
+        case 6: return launch_siegel_coop_m<MODEL, 6>(a, s);     // A/B against the one-pair-per-lane kernels (SYMPA_FLAG_COOP)
+        case 8: return launch_siegel_coop_m<MODEL, 8>(a, s);
         case 9: return launch_siegel_coop_m<MODEL, 9>(a, s);
         case 10: return launch_siegel_coop_m<MODEL, 10>(a, s);
         case 11: return launch_siegel_coop_m<MODEL, 11>(a, s);

@@ -85,6 +85,7 @@ def _weights(metric, weights, n, device):
 FLAG_LOW_LDS = 1
 FLAG_GENERIC = 2      # spd: force the runtime-n one-lane-per-pair kernel
 FLAG_ANY_ORDER = 4    # forward: dispatch without the in-order barrier bit (independent batches of one stream overlap)
+FLAG_COOP = 32        # dims 6, 8: force the sixteen-lanes-per-pair kernel (A/B)
 FLAG_NO_SYMMETRY = 16  # all_pairs_dist(packed=True): evaluate (i, j) and (j, i) separately
 FLAG_FUSE = 8         # BatchedForward: up to MAX_FUSED_BATCHES consecutive batches per kernel launch
 MAX_FUSED_BATCHES = 32
