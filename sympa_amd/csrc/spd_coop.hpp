@@ -71,8 +71,14 @@ __device__ __forceinline__ void fnmac_bc(double& acc, const double x, const doub
     asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
 }
 
-// sum over the 16 lanes of my group, result in every lane (32-bit DPP rotations: the DP ALU has no row_ror)
+// sum over the 16 lanes of my group, result in every lane (32-bit DPP rotations: the DP ALU has no row_ror).
+// The result is BITWISE the same in the sixteen lanes: rotations by 8, 4, 2, 1 add the same two numbers in both lanes of
+// every exchange.  That only holds if the argument is a rounded value -- with -ffp-contract=fast the compiler would
+// otherwise fuse a product in the caller's argument into the first addition (fma(t, t, other lane's ROUNDED t^2)), and
+// the lanes of a pair would disagree in the last bit, which the redundant per-lane QL of spd_coop_bwd.hpp cannot
+// tolerate (its predicates must agree).  The empty asm makes the argument opaque.
 __device__ __forceinline__ double group_sum(double v) {
+    asm("" : "+v"(v));
 #define SPD_COOP_ROR(CTRL)                                                                          \
     {                                                                                               \
         const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);    \

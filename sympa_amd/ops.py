@@ -605,7 +605,7 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, fla
 
 
 def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale=None, scale_coef=1.0, loss_scale=1.0,
-                      loss=None, grad_scale=None, rows=None, want_out=False):
+                      loss=None, grad_scale=None, rows=None, want_out=False, flags=0):
     """Backward of the spd distance (C-ABI sympa_spd_backward_rows).  triplets None: pair i = (x[i], y[i]); otherwise
     x is y is the [N, n, n] table and pair i = (table[triplets[i, 0]], table[triplets[i, 1]]).  Give grad_out [b] or
     graph_dist [b] (fused AverageDistortionLoss, accumulated into `loss`).  Returns (rows [2b, n, n], out or None):
@@ -648,7 +648,7 @@ def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale
             float(scale_coef), None if go is None else go.data_ptr(), None if gd is None else gd.data_ptr(),
             float(loss_scale), None if loss is None else loss.data_ptr(), rows.data_ptr(),
             rows.data_ptr() + b * n * n * 8, None if grad_scale is None else grad_scale.data_ptr(),
-            None if out is None else out.data_ptr(), st.data_ptr(), 0, _stream())
+            None if out is None else out.data_ptr(), st.data_ptr(), int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(dev)

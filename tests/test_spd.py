@@ -319,3 +319,64 @@ def test_gpu_spd_backward_and_table_ops(n):
     symt = lambda t: 0.5 * (t + t.transpose(-1, -2))
     assert rel_err(m1.embeddings.embeds.grad.cpu(), symt(table.grad), atol=1e-10) < 1e-6
     assert rel_err(m1.scale.grad.cpu(), scale.grad) < 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_spd16_cooperative_backward_against_one_lane_per_pair():
+    """n = 16: the sixteen-lanes-per-pair backward (spd_coop_bwd.hpp) against the one-lane-per-pair kernel
+    (SYMPA_FLAG_GENERIC), the g++ build of the same formulas and the 50-digit directional derivatives; ragged batch,
+    identical points (zero subgradient), fused loss and scale gradient, out-of-range index."""
+    from sympa_amd import ops
+    from tests.helpers import GOLDEN, hostsim_spd_bwd
+    dev = torch.device("cuda:0")
+    n = 16
+    g = torch.Generator().manual_seed(1234)
+    for b, s in ((1, 0.3), (67, 1e-3), (333, 0.4), (1000, 0.8)):
+        x, y = spd_points(b, n, s, g), spd_points(b, n, s, g)
+        if b > 10:
+            y[5] = x[5]
+        go = torch.rand(b, generator=g, dtype=torch.float64) + 0.5
+        rows_c, out_c = ops.spd_backward_rows(x.to(dev), y.to(dev), grad_out=go.to(dev), want_out=True)
+        rows_g, out_g = ops.spd_backward_rows(x.to(dev), y.to(dev), grad_out=go.to(dev), want_out=True, flags=ops.FLAG_GENERIC)
+        ops.check_status(dev)
+        # s = 0.8: generalized eigenvalues 1e-3 .. 1e3; the tridiagonal QL resolves eigenvalues to eps * ||A||, i.e.
+        # ~1e-10 relative on the smallest ones (the forward kernel of the same layout has the same bound)
+        assert rel_err(out_c.cpu(), out_g.cpu()) < (1e-10 if s > 0.5 else 1e-11)
+        scale_ = rows_g.abs().reshape(2 * b, -1).max(1).values.clamp_min(1e-300).cpu()
+        diff = (rows_c - rows_g).abs().reshape(2 * b, -1).max(1).values.cpu()
+        assert (diff / scale_).max() < 1e-8, (b, s, (diff / scale_).max())
+        ho, hgx, hgy, st = hostsim_spd_bwd(x.numpy(), y.numpy())
+        assert rel_err(rows_c[:b].cpu(), hgx * go.numpy()[:, None, None], atol=1e-12) < 1e-7
+        if b > 10:
+            assert float(out_c[5]) == 0.0 and float(rows_c[5].abs().max()) == 0.0
+    gold = np.load(f"{GOLDEN}/spd_n16.npz")
+    x, y, dirs = gold["grad__x"], gold["grad__y"], gold["grad__dirs"]
+    k = x.shape[0]
+    rows, _ = ops.spd_backward_rows(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev),
+                                    grad_out=torch.ones(k, dtype=torch.float64, device=dev))
+    gx, gy = rows[:k].cpu().numpy(), rows[k:].cpu().numpy()
+    ddx = np.einsum("kij,ktij->kt", gx, dirs)
+    ddy = np.einsum("kij,ktij->kt", gy, dirs)
+    assert np.abs(ddx - gold["grad__ddx_exact50"]).max() < 1e-9 * np.abs(gold["grad__ddx_exact50"]).max()
+    assert np.abs(ddy - gold["grad__ddy_exact50"]).max() < 1e-9 * np.abs(gold["grad__ddy_exact50"]).max()
+    # fused loss through a table with an out-of-range index
+    table = spd_points(50, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, 50, (130,), generator=g), torch.randint(0, 50, (130,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (130,), generator=g).to(torch.float64).to(dev)
+    sc = torch.tensor([1.7], device=dev)
+    res = []
+    for fl in (0, ops.FLAG_GENERIC):
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        rows, out = ops.spd_backward_rows(table, table, trip, graph_dist=gd, scale=sc, scale_coef=1.0, loss_scale=0.5,
+                                          loss=loss, grad_scale=gs, want_out=True, flags=fl)
+        res.append((rows.cpu(), out.cpu(), float(loss), float(gs)))
+    ops.check_status(dev)
+    assert rel_err(res[0][1], res[1][1]) < 1e-11 and abs(res[0][2] - res[1][2]) < 1e-10 * abs(res[1][2])
+    assert abs(res[0][3] - res[1][3]) < 1e-9 * abs(res[1][3])
+    assert rel_err(res[0][0], res[1][0], atol=1e-10) < 1e-6
+    trip[3, 1] = 50
+    rows, out = ops.spd_backward_rows(table, table, trip, graph_dist=gd, want_out=True)
+    assert torch.isnan(out[3]) and float(rows[3].abs().max()) == 0.0 and float(rows[130 + 3].abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        ops.check_status(dev)
