@@ -2,32 +2,15 @@
 // distance with the fused AverageDistortionLoss, and the optimiser-side row operations (egrad2rgrad, projx, RSGD step).
 // One pair / one table row per lane, runtime n <= 16, per-lane scratch: functional, not tuned.
 // PARITY UNPINNED with respect to geoopt (absent); pinned by mpmath finite differences and autograd through the oracle.
+#include <cstdlib>
+
 #include "siegel_common.hpp"
 #include "spd_math_bwd.hpp"
-#include "spd_coop_bwd.hpp"
+#include "spd_coop_bwd_kernel.hpp"
 
 namespace {
 using namespace sympa_hip;
 
-struct SpdBwdArgs {
-    const double* x;          // [.., n, n] points or the table
-    const double* y;
-    const int64_t* src;       // nullptr -> pair i = rows i
-    const int64_t* dst;
-    int64_t src_stride, dst_stride;
-    int64_t num_rows, b;
-    const double* scale;
-    double inv_scale_coef;
-    const double* go;         // [b] or nullptr
-    const double* graph_dist; // [b] or nullptr (fused loss)
-    double loss_scale;
-    double* loss;
-    double* gx;               // [b, n, n] rows of the src / x points
-    double* gy;               // [b, n, n] rows of the dst / y points
-    double* gscale;
-    double* out;
-    int32_t* status;
-};
 
 __global__ __launch_bounds__(64) void spd_bwd_kernel(const SpdBwdArgs a, const int n) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -92,137 +75,6 @@ __global__ __launch_bounds__(64) void spd_bwd_kernel(const SpdBwdArgs a, const i
     }
 }
 
-// Sixteen lanes per pair (spd_coop_bwd.hpp): one wave per block, 64 pairs per wave in 16 rounds of 4; group g of the wave
-// handles pair 4 t + g in round t, lane r of the group owns row r of every matrix of that pair.
-template <int M>
-__global__ __launch_bounds__(64) void spd_coop_bwd_kernel(const SpdBwdArgs a) {
-    using namespace spd_coop;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, r = lane & 15;
-    double* const tbuf = tbuf_all + g * N * N;
-    constexpr int nn = M * M;
-    double sc = 1.0;
-    bool sc_active = false;
-    if (a.scale != nullptr) {
-        const double raw = a.scale[0] * a.inv_scale_coef;
-        sc_active = raw > 0.1;
-        sc = sc_active ? raw : 0.1;
-    }
-    int st = 0;
-    double loss_acc = 0.0, gscale_acc = 0.0;
-    for (int t = 0; t < ROUNDS; ++t) {
-        const int64_t i = (int64_t)blockIdx.x * 64 + 4 * t + g;      // my group's pair in this round
-        const bool live = i < a.b;
-        const int64_t ii = live ? i : a.b - 1;
-        int64_t r1 = ii, r2 = ii;
-        bool bad = false;
-        if (a.src != nullptr) {
-            r1 = a.src[ii * a.src_stride];
-            r2 = a.dst[ii * a.dst_stride];
-            if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { bad = true; r1 = 0; r2 = 0; }
-        }
-        const double* px = a.x + r1 * nn;
-        const double* py = a.y + r2 * nn;
-        double x[M], y[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const int lo = r < j ? r : j, hi = r < j ? j : r;
-            const int e = (hi < M) ? lo * M + hi : 0;            // upper triangle; a phantom lane reads element 0
-            x[j] = px[e];
-            y[j] = py[e];
-        }
-#pragma unroll
-        for (int j = 0; j < M; ++j) y[j] -= x[j];                 // D = Y - X
-        double rd[M], m[M];
-        const bool pd = cholesky_rows(x, rd);                     // x <- rows of L
-        solve_right_lt(y, x, rd);                                 // W = D L^-T
-        transpose_rows(y, m, tbuf, r);
-        solve_right_lt(m, x, rd);                                 // A = L^-1 D L^-T
-        double d[M], e[M], vk[M], bk[M];
-        tridiagonalize_keep(m, r, d, e, vk, bk);
-        // The QL below runs redundantly in the sixteen lanes of the pair and its predicates must agree bit for bit:
-        // take (d, e) from lane 0 (they are uniform by construction -- this pins it against compiler reassociation).
-#pragma unroll
-        for (int j = 0; j < M; ++j) { d[j] = bcast<0>(d[j]); e[j] = bcast<0>(e[j]); }
-        double zrow[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) zrow[j] = (r == j) ? 1.0 : 0.0;
-        const bool conv = tridiag_ql_vectors_row(d, e, zrow);
-        double zc[M], vrow[M];
-        transpose_rows(zrow, zc, tbuf, r);                        // lane c holds column c of Z
-        back_transform_columns(zc, vk, bk);                       // ... of V = Q Z
-        transpose_rows(zc, vrow, tbuf, r);                        // lane i holds row i of V
-        // distance and the two spectral weights (group-uniform)
-        bool ok = pd;
-        double acc = 0.0, f[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-            ok = ok && (d[k] > -1.0);
-            f[k] = sympa::d_log1p_signed(d[k]);
-            acc = sympa::d_fma(f[k], f[k], acc);
-        }
-        const double dist = sympa::d_sqrt(acc);
-        const double inv = (dist > 0.0) ? sympa::d_rcp(dist) : 0.0;
-        double go = 0.0, loss_i = 0.0;
-        if (a.graph_dist != nullptr) {
-            const double gd = live ? a.graph_dist[i] : 1.0;
-            const double ratio = dist * sc / gd;
-            const double ee = ratio * ratio - 1.0;
-            loss_i = (live && !bad) ? fabs(ee) * a.loss_scale : 0.0;
-            go = (ee > 0.0 ? 1.0 : (ee < 0.0 ? -1.0 : 0.0)) * 2.0 * ratio / gd * a.loss_scale;
-        } else if (a.go != nullptr) {
-            go = live ? a.go[i] : 0.0;
-        }
-        if (!live || bad) go = 0.0;
-        const double fs = go * sc * inv;
-        double gy[M], gx[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-            gy[k] = fs * f[k] * sympa::d_rcp(1.0 + d[k]);
-            gx[k] = -fs * f[k];
-        }
-        double py_[M], px_[M];
-        vdvt_rows(vrow, gy, py_);
-        vdvt_rows(vrow, gx, px_);
-        congruence_inv_t_rows(py_, x, rd, tbuf, r);
-        congruence_inv_t_rows(px_, x, rd, tbuf, r);
-        if (live && r < M) {
-            double* ox = a.gx + i * nn + r * M;
-            double* oy = a.gy + i * nn + r * M;
-#pragma unroll
-            for (int j = 0; j < M; ++j) { ox[j] = px_[j]; oy[j] = py_[j]; }
-        }
-        if (r == 0) {
-            if (live && a.out != nullptr) a.out[i] = bad ? __builtin_nan("") : dist * sc;
-            loss_acc += loss_i;
-            gscale_acc += (live && sc_active) ? go * dist * a.inv_scale_coef : 0.0;
-            if (live) {
-                if (bad) st |= sympa::ST_BAD_INDEX;
-                if (!ok) st |= sympa::ST_NOT_PD;
-                if (!conv) st |= sympa::ST_NO_CONVERGENCE;
-                if (!sympa::d_finite(dist)) st |= sympa::ST_NONFINITE;
-            }
-        }
-    }
-    // lanes r = 0 of the four groups hold the partial sums
-    double v = (r == 0) ? loss_acc : 0.0;
-    double w = (r == 0) ? gscale_acc : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off); w += __shfl_xor(w, off); }
-    if (lane == 0) {
-        if (a.loss != nullptr && a.graph_dist != nullptr && v != 0.0) atomicAdd(a.loss, v);
-        if (a.gscale != nullptr && a.scale != nullptr && w != 0.0) atomicAdd(a.gscale, w);
-    }
-    if (a.status != nullptr) {
-        const unsigned long long mk = __ballot(st != 0);
-        if (mk != 0ull) {
-            if (st != 0) atomicOr(&a.status[0], st);
-            if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(mk));
-        }
-    }
-}
-
 // OP 0: out = projx(x)   1: table <- RSGD step in place   2: out = egrad2rgrad(x, g)
 __global__ __launch_bounds__(64) void spd_table_kernel(const int op, double* x, const double* g, double* out, const int64_t b,
                                                        const int n, const double lr, const double wd, const double* clip,
@@ -264,8 +116,13 @@ int launch_spd_table(int op, double* x, const double* g, double* out, int64_t b,
     if (b == 0) return 0;
     if (x == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
     if (n < 1 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: dims outside [1, 16]");
-    hipLaunchKernelGGL(spd_table_kernel, dim3((unsigned)((b + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
-                       op, x, g, out, b, n, lr, wd, clip, max_norm, projected, status);
+    // SYMPA_SPD_TABLE_GENERIC=1 keeps the one-row-per-lane kernel for A/B measurements (tools/spd_time.py)
+    static const bool generic = std::getenv("SYMPA_SPD_TABLE_GENERIC") != nullptr;
+    if (op != 0 && n >= SPD_COOP_BWD_MIN_N && !generic)
+        launch_spd_coop_table(op, n, x, g, out, b, lr, wd, clip, max_norm, status, reinterpret_cast<hipStream_t>(stream));
+    else
+        hipLaunchKernelGGL(spd_table_kernel, dim3((unsigned)((b + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                           op, x, g, out, b, n, lr, wd, clip, max_norm, projected, status);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
@@ -297,8 +154,13 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
     a.gx = grad_x_rows; a.gy = grad_y_rows; a.gscale = grad_scale; a.out = out; a.status = status;
     const dim3 grid((unsigned)((b + 63) / 64));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n == 16 && !(flags & SYMPA_FLAG_GENERIC)) hipLaunchKernelGGL(spd_coop_bwd_kernel<16>, grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(spd_bwd_kernel, grid, dim3(64), 0, s, a, n);
+    if (n >= SPD_COOP_BWD_MIN_N && !(flags & SYMPA_FLAG_GENERIC)) {
+        if (n == 16) hipLaunchKernelGGL(spd_coop_bwd_kernel<16>, grid, dim3(64), 0, s, a);
+        else if (n >= 12) launch_spd_coop_bwd_hi(a, n, grid, s);
+        else launch_spd_coop_bwd_lo(a, n, grid, s);
+    } else {
+        hipLaunchKernelGGL(spd_bwd_kernel, grid, dim3(64), 0, s, a, n);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

@@ -1,0 +1,13 @@
+// spd backward, sixteen lanes per pair, M = 12..15 (spd_coop_bwd_kernel.hpp)
+#include "spd_coop_bwd_kernel.hpp"
+
+namespace sympa_hip {
+void launch_spd_coop_bwd_hi(const SpdBwdArgs& a, int n, dim3 grid, hipStream_t s) {
+    switch (n) {
+        case 12: hipLaunchKernelGGL(spd_coop_bwd_kernel<12>, grid, dim3(64), 0, s, a); break;
+        case 13: hipLaunchKernelGGL(spd_coop_bwd_kernel<13>, grid, dim3(64), 0, s, a); break;
+        case 14: hipLaunchKernelGGL(spd_coop_bwd_kernel<14>, grid, dim3(64), 0, s, a); break;
+        default: hipLaunchKernelGGL(spd_coop_bwd_kernel<15>, grid, dim3(64), 0, s, a); break;
+    }
+}
+}  // namespace sympa_hip

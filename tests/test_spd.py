@@ -322,6 +322,54 @@ def test_gpu_spd_backward_and_table_ops(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 8, 9, 11, 12, 13, 15])
+def test_gpu_spd_cooperative_backward_every_size(n):
+    """The sixteen-lanes-per-pair backward is instantiated for every matrix size 3..16 (lanes r >= n are phantoms):
+    each against the one-lane-per-pair kernel and against autograd through the oracle's formula; ragged batch."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + n)
+    b = 203
+    x, y = spd_points(b, n, 0.4, g), spd_points(b, n, 0.4, g)
+    y[7] = x[7]
+    go = torch.rand(b, generator=g, dtype=torch.float64) + 0.5
+    rows_c, out_c = ops.spd_backward_rows(x.to(dev), y.to(dev), grad_out=go.to(dev), want_out=True)
+    rows_g, out_g = ops.spd_backward_rows(x.to(dev), y.to(dev), grad_out=go.to(dev), want_out=True, flags=ops.FLAG_GENERIC)
+    ops.check_status(dev)
+    assert rel_err(out_c.cpu(), out_g.cpu()) < 1e-11
+    scale_ = rows_g.abs().reshape(2 * b, -1).max(1).values.clamp_min(1e-300).cpu()
+    diff = (rows_c - rows_g).abs().reshape(2 * b, -1).max(1).values.cpu()
+    assert (diff / scale_).max() < 1e-8, (n, (diff / scale_).max())
+    assert float(out_c[7]) == 0.0 and float(rows_c[7].abs().max()) == 0.0
+    xs, ys = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    (so.spd_dist(xs, ys) * go).sum().backward()
+    keep = torch.ones(b, dtype=torch.bool); keep[7] = False
+    gx = 0.5 * (xs.grad + xs.grad.transpose(-1, -2))
+    gy = 0.5 * (ys.grad + ys.grad.transpose(-1, -2))
+    assert rel_err(rows_c[:b].cpu()[keep], gx[keep], atol=1e-12) < 1e-7
+    assert rel_err(rows_c[b:].cpu()[keep], gy[keep], atol=1e-12) < 1e-7
+    # the row operations of the optimiser in the same layout (spd_coop_table.hpp): non-symmetric gradient, weight decay,
+    # gradient clipping, ragged row count; a row that is not positive definite raises the status
+    u = torch.randn(b, n, n, generator=g, dtype=torch.float64)
+    assert rel_err(ops.spd_egrad2rgrad(x.to(dev), u.to(dev)).cpu(), so.spd_egrad2rgrad(x, u), atol=1e-13) < 1e-10
+    tab = x.clone().to(dev)
+    ops.spd_rsgd_step_(tab, u.to(dev), 0.05, 0.01)
+    want = so.spd_rsgd_step(x, u, 0.05, 0.01)
+    assert rel_err(tab.cpu(), want, atol=1e-13) < 1e-10
+    assert float((tab - tab.transpose(-1, -2)).abs().max()) == 0.0
+    sq = (u * u).sum().reshape(1).to(dev)
+    tab = x.clone().to(dev)
+    ops.spd_rsgd_step_(tab, u.to(dev), 0.05, 0.0, clip_sqnorm=sq, max_norm=3.0)
+    coef = min(1.0, 3.0 / (float(sq.sqrt()) + 1e-6))
+    assert rel_err(tab.cpu(), so.spd_rsgd_step(x, u * coef, 0.05, 0.0), atol=1e-13) < 1e-10
+    ops.check_status(dev)
+    bad = x.clone(); bad[11] = -bad[11]
+    ops.spd_rsgd_step_(bad.to(dev), u.to(dev), 0.05, 0.0)
+    with pytest.raises(AssertionError, match="1 pairs"):
+        ops.check_status(dev)
+
+
+@pytest.mark.gpu
 def test_gpu_spd16_cooperative_backward_against_one_lane_per_pair():
     """n = 16: the sixteen-lanes-per-pair backward (spd_coop_bwd.hpp) against the one-lane-per-pair kernel
     (SYMPA_FLAG_GENERIC), the g++ build of the same formulas and the 50-digit directional derivatives; ragged batch,
