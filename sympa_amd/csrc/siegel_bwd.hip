@@ -1,5 +1,5 @@
 // gfx950 backward kernels + C-ABI (sympa_siegel_dist_bwd, sympa_model_backward, sympa_model_loss_backward).
-#include "siegel_bwd_kernel.hpp"
+#include "siegel_coop_bwd_kernel.hpp"
 
 namespace {
 using namespace sympa_hip;
@@ -22,7 +22,12 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
         case 8: return model == SYMPA_MODEL_UPPER ? launch_bwd_n8_upper(a, scatter, s) : launch_bwd_n8_bounded(a, scatter, s);
         default: break;
     }
-    if (n > 8 && n <= SYMPA_MAX_DIMS_BACKWARD) return launch_bwd_rolled(a, n, model, scatter, s);
+    if (n > 8 && n <= SYMPA_MAX_DIMS_BACKWARD) {
+        // sixteen lanes per pair (siegel_coop_bwd.hpp); SYMPA_FLAG_GENERIC keeps the one-lane-per-pair kernel over scratch
+        if (model == SYMPA_MODEL_UPPER && !(a.f.flags & SYMPA_FLAG_GENERIC))
+            return launch_bwd_coop_upper(a, n, scatter, s);
+        return launch_bwd_rolled(a, n, model, scatter, s);
+    }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "backward: dims outside [1, SYMPA_MAX_DIMS_BACKWARD]");
 }
 

@@ -13,8 +13,10 @@
 //   Hbar   = V diag(phi) V^H,   K = V diag(phi lambda) V^H = Hbar H
 //   Ebar   = 2 E Hbar,          G = E Hbar E^H
 //   Dbar   = L1^-H Ebar conj(L2)^-1                            (conj only matters for complex factors)
-//   L1bar  = -2 tril(L1^-H G),  L2bar = -2 tril(L2^-H conj(K))
-//   Abar_k = herm( L_k^-H Phi(L_k^H Lbar_k) L_k^-1 )           Phi: lower triangle, diagonal halved
+//   A1bar  = -L1^-H G L1^-1,   A2bar = -L2^-H conj(K) L2^-1
+//     (the lambda_i are the eigenvalues of the pencils (D conj(A2)^-1 D^H, A1) and (D^H A1^-1 D, conj(A2)), so
+//      d lambda_i = -lambda_i u_i^H dA u_i with u_i = L^-H (singular vector): the Cholesky factors only enter through
+//      these congruences and no adjoint of the factorisation itself is needed)
 //   upper  : Ybar_k += Abar_k (real);    X2bar += Re Dbar, Y2bar += Im Dbar, X1bar -= ..., Y1bar -= ...
 //   bounded: Wbar_k  = -/+ Dbar - 2 Abar_k W_k
 // and finally every plane is symmetrised.  Derivation and the numpy prototype that was checked against
@@ -419,7 +421,26 @@ SYMPA_UNROLL
     }
 }
 
-// Cholesky adjoint.  In: L (factor), M (full matrix; only tril(L^-H M) enters), scale.  Computes
+// m <- -herm(L^-H m L^-1) for a Hermitian m (real factor: the two planes stay independent and a caller that only reads
+// the real plane leaves the imaginary one to dead-code elimination)
+template <int N, bool COMPLEX>
+SYMPA_HD void neg_congruence(const Tri<N, COMPLEX>& l, CMat<N>& m) {
+    solve_lh_left<N, COMPLEX>(l, m);
+    solve_l_right<N, COMPLEX, false>(l, m);
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = i; j < N; ++j) {
+            const double re = -0.5 * (m.re[i][j] + m.re[j][i]);
+            const double im = COMPLEX ? -0.5 * (m.im[i][j] - m.im[j][i]) : 0.0;
+            m.re[i][j] = re; m.re[j][i] = re;
+            m.im[i][j] = im; m.im[j][i] = -im;
+        }
+}
+
+// Cholesky adjoint (the route through the adjoint of the factorisation itself; equal to neg_congruence on L^-H M with
+// scale = -2 -- kept for n = 8, where this instruction order happens to spill less, see pair_backward).
+// In: L (factor), M (full matrix; only tril(L^-H M) enters), scale.  Computes
 //   Lbar = scale * tril(L^-H M),  P = Phi(L^H Lbar),  Abar = herm(L^-H P L^-1)
 // and returns Abar as a full Hermitian matrix.
 template <int N, bool COMPLEX>
@@ -468,69 +489,21 @@ SYMPA_UNROLL
 }
 
 // ---------------------------------------------------------------------------------------------
-// One pair: forward value + gradients.  g1, g2: symmetric matrix gradients w.r.t. Z1, Z2 (both planes);
-// gw[k] += d out / d w_k * go for the wsum metric (k = rank of the eigenvalue, ascending).
+// The scalar part of the adjoint: eigenvalues lambda of H -> value of the metric and the spectral weights
+//   phi_i = go * d out / d lambda_i,   philam_i = phi_i lambda_i,   gw[k] += go * d out / d w_k  (wsum)
+// (shared by the one-pair-per-lane adjoint below and the sixteen-lanes-per-pair one, siegel_coop_bwd.hpp)
 // ---------------------------------------------------------------------------------------------
 template <int N, int MODEL>
-SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
-                              double inv_eps, double go, CMat<N>& g1, CMat<N>& g2, double (&gw)[N], int& status) {
-    constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
-    Tri<N, CPLX> l1, l2;
-    CMat<N> e;
-    bool ok;
-    if constexpr (MODEL == MODEL_UPPER) {
-        ok = chol_real<N>(z1.im, l1);
-        ok = chol_real<N>(z2.im, l2) && ok;
-    } else {
-        ok = chol_id_minus_wwh<N>(z1, l1);
-        ok = chol_id_minus_wwh<N>(z2, l2) && ok;
-    }
-SYMPA_UNROLL
-    for (int i = 0; i < N; ++i)
-SYMPA_UNROLL
-        for (int j = 0; j < N; ++j) {
-            e.re[i][j] = z2.re[i][j] - z1.re[i][j];
-            e.im[i][j] = z2.im[i][j] - z1.im[i][j];
-        }
-    solve_left<N, CPLX>(l1, e);
-    solve_right_t<N, CPLX>(l2, e);
-    Herm<N> h;
-    gram<N>(e, h);
-    CMat<N> v;
-    bool conv;
-#ifndef SYMPA_BWD_EIGEN_JACOBI
-    if constexpr (N >= 5) {
-        conv = herm_eigen_vectors_ql<N>(h, v);
-        // Rayleigh quotients: lambda_i = v_i^H H v_i = ||E v_i||^2, relative accuracy for the small eigenvalues
-SYMPA_UNROLL
-        for (int c = 0; c < N; ++c) {
-            double acc = 0.0;
-SYMPA_UNROLL
-            for (int r = 0; r < N; ++r) {
-                double tr = 0.0, ti = 0.0;
-SYMPA_UNROLL
-                for (int k = 0; k < N; ++k) {
-                    tr = d_fma(e.re[r][k], v.re[k][c], d_fma(-e.im[r][k], v.im[k][c], tr));
-                    ti = d_fma(e.re[r][k], v.im[k][c], d_fma(e.im[r][k], v.re[k][c], ti));
-                }
-                acc = d_fma(tr, tr, d_fma(ti, ti, acc));
-            }
-            h.d[c] = acc;
-        }
-    } else
-#endif
-    {
-        conv = herm_eigen_vectors<N>(h, v);
-    }
-
+SYMPA_HD double spectral_adjoint(const double (&lam_in)[N], int metric, const double* __restrict__ w, double inv_eps,
+                                 double go, double (&phi)[N], double (&philam)[N], double (&gw)[N], bool& finite) {
     const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
     double vv[N], dv[N], lam[N];
     int rank[N];
-    bool finite = true;
+    finite = true;
 SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {
-        finite = finite && d_finite(h.d[i]);     // before the clamp: fmax drops a NaN
-        lam[i] = fmax(h.d[i], 0.0);
+        finite = finite && d_finite(lam_in[i]);     // before the clamp: fmax drops a NaN
+        lam[i] = fmax(lam_in[i], 0.0);
         const double lp = lam[i] * scale;
         const double root = d_sqrt(d_fma(lp, lp, lp));       // sqrt(lp (1 + lp))
         double u = 2.0 * (lp + root);
@@ -581,27 +554,104 @@ SYMPA_UNROLL
             for (int k = 0; k < N; ++k) gw[k] += (rank[i] == k && wk > 0.0) ? go * vv[i] : 0.0;
         }
     }
-    double phi[N], philam[N];
 SYMPA_UNROLL
-    for (int i = 0; i < N; ++i) { phi[i] = go * vbar[i] * dv[i]; philam[i] = phi[i] * h.d[i]; }
+    for (int i = 0; i < N; ++i) { phi[i] = go * vbar[i] * dv[i]; philam[i] = phi[i] * lam_in[i]; }
 
-    CMat<N> hbar, ebar, gm, km;
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pair: forward value + gradients.  g1, g2: symmetric matrix gradients w.r.t. Z1, Z2 (both planes);
+// gw[k] += d out / d w_k * go for the wsum metric (k = rank of the eigenvalue, ascending).
+// ---------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
+                              double inv_eps, double go, CMat<N>& g1, CMat<N>& g2, double (&gw)[N], int& status) {
+    constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
+    Tri<N, CPLX> l1, l2;
+    CMat<N> e;
+    bool ok;
+    if constexpr (MODEL == MODEL_UPPER) {
+        ok = chol_real<N>(z1.im, l1);
+        ok = chol_real<N>(z2.im, l2) && ok;
+    } else {
+        ok = chol_id_minus_wwh<N>(z1, l1);
+        ok = chol_id_minus_wwh<N>(z2, l2) && ok;
+    }
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+            e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+        }
+    solve_left<N, CPLX>(l1, e);
+    solve_right_t<N, CPLX>(l2, e);
+    Herm<N> h;
+    gram<N>(e, h);
+    CMat<N> v;
+    bool conv;
+    constexpr bool QL_ROUTE =
+#ifndef SYMPA_BWD_EIGEN_JACOBI
+        N >= 5;
+#else
+        false;
+#endif
+    if constexpr (QL_ROUTE) conv = herm_eigen_vectors_ql<N>(h, v);
+    else conv = herm_eigen_vectors<N>(h, v);
+    if constexpr (QL_ROUTE) {
+        // Rayleigh quotients lambda_i = v_i^H H v_i = ||E v_i||^2: RELATIVE accuracy for the small eigenvalues, which
+        // the QL route needs (column by column: U = E V is never held as a matrix, see below)
+SYMPA_UNROLL
+        for (int c = 0; c < N; ++c) {
+            double acc = 0.0;
+SYMPA_UNROLL
+            for (int r = 0; r < N; ++r) {
+                double tr = 0.0, ti = 0.0;
+SYMPA_UNROLL
+                for (int k = 0; k < N; ++k) {
+                    tr = d_fma(e.re[r][k], v.re[k][c], d_fma(-e.im[r][k], v.im[k][c], tr));
+                    ti = d_fma(e.re[r][k], v.im[k][c], d_fma(e.im[r][k], v.re[k][c], ti));
+                }
+                acc = d_fma(tr, tr, d_fma(ti, ti, acc));
+            }
+            h.d[c] = acc;
+        }
+    }
+
+    double phi[N], philam[N];
+    bool finite;
+    double out = spectral_adjoint<N, MODEL>(h.d, metric, w, inv_eps, go, phi, philam, gw, finite);
+
+    // closed forms (header comment): no Cholesky adjoint -- the factors only enter through congruences.
+    // (Forming U = E V once and Ebar = 2 U diag(phi) V^H, G = U diag(phi) U^H from it saves a product but keeps three
+    //  full matrices alive at once: measured SLOWER for the unrolled kernels, n = 8 1.80 ms against 1.44 ms per 262 144
+    //  pairs, 1342 against 1102 spilled registers.  The order below frees V, then Hbar, then E as early as possible.)
+    CMat<N> hbar, a1, a2;
     herm_from_eig<N>(v, phi, hbar);
-    herm_from_eig<N>(v, philam, km);          // K = Hbar H
+    herm_from_eig<N>(v, philam, a2);          // K = V diag(phi lambda) V^H = Hbar H
+    CMat<N> ebar;
     cmatmul<N>(e, hbar, 2.0, ebar);           // Ebar = 2 E Hbar
-    cmatmul_bh<N>(ebar, e, 0.5, gm);          // G = E Hbar E^H
-    // Dbar = L1^-H Ebar conj(L2)^-1
-    solve_lh_left<N, CPLX>(l1, ebar);
+    cmatmul_bh<N>(ebar, e, 0.5, a1);          // G = E Hbar E^H
+    solve_lh_left<N, CPLX>(l1, ebar);         // Dbar = L1^-H Ebar conj(L2)^-1
     solve_l_right<N, CPLX, true>(l2, ebar);
     if (CPLX) {
 SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
 SYMPA_UNROLL
-            for (int j = 0; j < N; ++j) km.im[i][j] = -km.im[i][j];    // conj(K)
+            for (int j = 0; j < N; ++j) a2.im[i][j] = -a2.im[i][j];    // conj(K)
     }
-    CMat<N> a1, a2;
-    chol_adjoint<N, CPLX>(l1, gm, -2.0, a1);
-    chol_adjoint<N, CPLX>(l2, km, -2.0, a2);
+    if constexpr (N == 8) {
+        // same matrices through the adjoint of the Cholesky factorisation (L_k bar = -2 tril(L_k^-H M), then
+        // herm(L^-H Phi(L^H Lbar) L^-1)): more arithmetic, but at n = 8 the register allocator spills less around it
+        // (1.44 ms against 1.55 ms per 262 144 pairs; n <= 7: the congruences are 0-3 % faster)
+        CMat<N> g = a1, k = a2;
+        chol_adjoint<N, CPLX>(l1, g, -2.0, a1);
+        chol_adjoint<N, CPLX>(l2, k, -2.0, a2);
+    } else {
+        neg_congruence<N, CPLX>(l1, a1);      // A1bar = -L1^-H G L1^-1
+        neg_congruence<N, CPLX>(l2, a2);      // A2bar = -L2^-H conj(K) L2^-1
+    }
 
     if (MODEL == MODEL_UPPER) {
 SYMPA_UNROLL

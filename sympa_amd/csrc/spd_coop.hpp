@@ -30,6 +30,13 @@ namespace spd_coop {
 
 constexpr int N = 16;                            // lanes per pair (a DPP row); matrices are M x M, M <= N
 constexpr int ROUNDS = 16;                       // 4 pairs per round, 64 pairs per wave
+
+// Rounds per wave for the kernels whose waves are independent of each other's pairs (backward, table rows): one wave
+// per SIMD is resident (512 registers), so up to 1024 x 4 pairs run at once -- spread a small batch over all SIMDs.
+inline int coop_rounds(const long long b) {
+    const long long r = (b + 4095) / 4096;
+    return (int)(r < 1 ? 1 : (r > ROUNDS ? ROUNDS : r));
+}
 // The row-per-lane routines below are templates over the matrix size M <= 16: lane r < M of a group of sixteen owns
 // row r, lanes r >= M are phantoms -- they execute the same instructions on values nobody reads (every DPP broadcast
 // takes its source from a lane j < M, the group sums mask them out, the LDS transposes give them columns nobody
@@ -47,6 +54,19 @@ __device__ __forceinline__ void sfor(F&& f) {
     }
 }
 
+// The DPP instructions are `asm volatile`: to the compiler a non-volatile asm is a pure per-thread function of its
+// operands, which a cross-lane read is not, and with plain `asm` one build of the backward kernel (siegel_coop_bwd_kernel
+// <16>, loop bound a kernel argument) came out with every pair wrong while the same source with a constant loop bound was
+// right -- some legal-for-pure-functions motion of the fmac.  Volatile pins every DPP instruction to its place in the
+// control flow and to the order of the other DPP instructions (measured cost in the forward kernels: 1-10 %).
+// settle() stays plain asm: it is a per-lane identity and may move with its value.
+#ifndef SYMPA_COOP_ASM
+#define SYMPA_COOP_ASM asm volatile
+#endif
+#ifndef SYMPA_COOP_ASM_SETTLE
+#define SYMPA_COOP_ASM_SETTLE asm
+#endif
+
 // value of lane J of my group of 16 lanes
 template <int J>
 __device__ __forceinline__ double bcast(const double v) {
@@ -54,21 +74,33 @@ __device__ __forceinline__ double bcast(const double v) {
 }
 
 // acc += x(lane J of my group) * y  /  acc -= ...   in one DP-ALU DPP instruction.
-// Hazard: a DPP source VGPR must not have been written by the two preceding VALU instructions.  The assembler's
-// hazard recogniser inserts the wait states for compiler-generated DPP but sees neither the DPP read nor the VGPR
-// write inside inline asm, so every value that is used as a DPP source is passed through settle() after its last
-// write: an s_nop that the value "depends on", which therefore sits between the write and every DPP read.
+// Hazard: a DPP source VGPR must not have been written by the two preceding VALU instructions.  The compiler's hazard
+// recogniser inserts the wait states for the DPP instructions it generates itself but sees neither the DPP read nor the
+// VGPR write inside inline asm.  Two layers:
+//  1. every value that is used as a DPP source is passed through settle() after its last write: an s_nop that the value
+//     "depends on", which therefore sits between the program's own write and every DPP read;
+//  2. the register allocator may still put a COPY of the source (v_mov_b64, v_accvgpr_read) right in front of the asm
+//     statement -- found once: `v_mov_b64 v[30:31], v[26:27]; v_fmac_f64_dpp .., v[30:31], ..` in siegel_coop_bwd_kernel
+//     <14>, most pairs wrong.  tools/check_dpp_hazards.py scans the generated ISA of every kernel for a VALU write of a
+//     DPP source within two wait states (over all predecessors of a block); __graft_entry__.build() runs it on every
+//     translation unit that includes this header and recompiles a unit that fails with SYMPA_COOP_NOP_IN_ASM, which
+//     carries the two wait states inside every asm statement (always safe; measured 15-60 % slower, so not the default).
+#ifdef SYMPA_COOP_NOP_IN_ASM
+#define SYMPA_COOP_NOP "s_nop 1\n\t"
+#else
+#define SYMPA_COOP_NOP ""
+#endif
 __device__ __forceinline__ double settle(double v) {
-    asm("s_nop 1" : "+v"(v));
+    SYMPA_COOP_ASM_SETTLE("s_nop 1" : "+v"(v));
     return v;
 }
 template <int J>
 __device__ __forceinline__ void fmac_bc(double& acc, const double x, const double y) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+    SYMPA_COOP_ASM(SYMPA_COOP_NOP "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
 }
 template <int J>
 __device__ __forceinline__ void fnmac_bc(double& acc, const double x, const double y) {
-    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+    SYMPA_COOP_ASM(SYMPA_COOP_NOP "v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
 }
 
 // sum over the 16 lanes of my group, result in every lane (32-bit DPP rotations: the DP ALU has no row_ror).

@@ -30,16 +30,22 @@ struct SpdBwdArgs {
     int32_t* status;
 };
 
+inline dim3 spd_coop_bwd_grid(const int64_t b) {
+    const int rounds = spd_coop::coop_rounds(b);
+    return dim3((unsigned)((b + 4 * rounds - 1) / (4 * rounds)));
+}
+
 // egrad2rgrad (op 2) / RSGD step (op 1) with sixteen lanes per table row, n = 3..16 (spd_table_coop.hip)
 void launch_spd_coop_table(int op, int n, double* x, const double* g, double* out, int64_t b, double lr, double wd,
                            const double* clip, double max_norm, int32_t* status, hipStream_t s);
 void launch_spd_coop_bwd_hi(const SpdBwdArgs& a, int n, dim3 grid, hipStream_t s);   // n = 12..15
 void launch_spd_coop_bwd_lo(const SpdBwdArgs& a, int n, dim3 grid, hipStream_t s);   // n = 3..11
 
-// Sixteen lanes per pair (spd_coop_bwd.hpp): one wave per block, 64 pairs per wave in 16 rounds of 4; group g of the wave
-// handles pair 4 t + g in round t, lane r of the group owns row r of every matrix of that pair.
+// Sixteen lanes per pair (spd_coop_bwd.hpp): one wave per block, `rounds` (spd_coop::coop_rounds) rounds of 4 pairs per
+// wave; group g of the wave handles pair 4 (rounds * block + t) + g in round t, lane r of the group owns row r of every
+// matrix of that pair.
 template <int M>
-__global__ __launch_bounds__(64) void spd_coop_bwd_kernel(const SpdBwdArgs a) {
+__global__ __launch_bounds__(64) void spd_coop_bwd_kernel(const SpdBwdArgs a, const int rounds) {
     using namespace spd_coop;
     __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
     const int lane = threadIdx.x;
@@ -55,8 +61,10 @@ __global__ __launch_bounds__(64) void spd_coop_bwd_kernel(const SpdBwdArgs a) {
     }
     int st = 0;
     double loss_acc = 0.0, gscale_acc = 0.0;
-    for (int t = 0; t < ROUNDS; ++t) {
-        const int64_t i = (int64_t)blockIdx.x * 64 + 4 * t + g;      // my group's pair in this round
+    for (int t = 0; t < rounds; ++t) {
+        const int64_t first = ((int64_t)blockIdx.x * rounds + t) * 4;
+        if (first >= a.b) break;                                     // wave-uniform
+        const int64_t i = first + g;                                 // my group's pair in this round
         const bool live = i < a.b;
         const int64_t ii = live ? i : a.b - 1;
         int64_t r1 = ii, r2 = ii;

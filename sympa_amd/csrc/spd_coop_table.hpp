@@ -35,7 +35,7 @@ template <int M, int OP>
 __global__ __launch_bounds__(64) void spd_coop_table_kernel(double* __restrict__ x, const double* __restrict__ g,
                                                             double* __restrict__ out, const int64_t b, const double lr,
                                                             const double wd, const double* __restrict__ clip,
-                                                            const double max_norm, int32_t* __restrict__ status) {
+                                                            const double max_norm, int32_t* __restrict__ status, const int rounds) {
     __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
     const int lane = threadIdx.x;
     const int grp = lane >> 4, r = lane & 15;
@@ -43,9 +43,10 @@ __global__ __launch_bounds__(64) void spd_coop_table_kernel(double* __restrict__
     constexpr int nn = M * M;
     const double coef = (clip != nullptr) ? fmin(1.0, max_norm / (sqrt(clip[0]) + 1e-6)) : 1.0;
     int st = 0, nbad = 0;
-    for (int t = 0; t < ROUNDS; ++t) {
-        const int64_t i = (int64_t)blockIdx.x * 64 + 4 * t + grp;
-        if ((int64_t)blockIdx.x * 64 + 4 * t >= b) break;        // wave-uniform
+    for (int t = 0; t < rounds; ++t) {
+        const int64_t first = ((int64_t)blockIdx.x * rounds + t) * 4;
+        if (first >= b) break;                                   // wave-uniform
+        const int64_t i = first + grp;
         const bool live = i < b;
         const int64_t ii = live ? i : b - 1;
         const double* px = x + ii * nn;

@@ -244,7 +244,7 @@ class BatchedForward:
             check_status(self.dev)
 
 
-def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None):
+def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None, flags=0):
     """Backward of manifold.dist for pre-gathered points (C-ABI sympa_siegel_dist_bwd).
     Returns (grad_z1, grad_z2, grad_weights or None): what torch autograd produces through the
     reference's dist (runner.py:105 over siegel_manifold.py:41-72)."""
@@ -263,7 +263,7 @@ def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights
     if b > 0:
         with torch.cuda.device(z1.device):
             rc = lib.sympa_siegel_dist_bwd(_ptr(z1), _ptr(z2), _ptr(go), b, n, MODEL_IDS[model], METRIC_IDS[metric],
-                                           _ptr(w), eps, _ptr(g1), _ptr(g2), _ptr(gw), _ptr(st), 0, _stream())
+                                           _ptr(w), eps, _ptr(g1), _ptr(g2), _ptr(gw), _ptr(st), int(flags), _stream())
         _lib.check(rc)
     if _debug:
         check_status(z1.device)
@@ -271,7 +271,7 @@ def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights
 
 
 def model_backward(table, triplets, grad_out, model="upper", metric="riem", weights=None, scale=None,
-                   scale_coef=1.0, eps=None, grad_table=None):
+                   scale_coef=1.0, eps=None, grad_table=None, flags=0):
     """Backward of the fused Model.forward (C-ABI sympa_model_backward): scatter-adds the two gradient
     rows of every pair into a dense [N,2,n,n] gradient (created zeroed unless `grad_table` is given, in
     which case it accumulates), returns (grad_table, grad_weights or None, grad_scale or None)."""
@@ -303,7 +303,7 @@ def model_backward(table, triplets, grad_out, model="upper", metric="riem", weig
             rc = lib.sympa_model_backward(_ptr(tab), num_rows, n, src_ptr, stride, dst_ptr, stride, b,
                                           MODEL_IDS[model], METRIC_IDS[metric], _ptr(w), eps, _ptr(sc),
                                           float(scale_coef), _ptr(go), _ptr(grad_table), _ptr(gw), _ptr(gs), None,
-                                          _ptr(st), 0, _stream())
+                                          _ptr(st), int(flags), _stream())
         _lib.check(rc)
     if _debug:
         check_status(tab.device)
@@ -311,7 +311,7 @@ def model_backward(table, triplets, grad_out, model="upper", metric="riem", weig
 
 
 def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="upper", metric="riem", weights=None,
-                        grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None):
+                        grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None, flags=0):
     """Fused training step (C-ABI sympa_model_loss_backward): distances + AverageDistortionLoss + all
     gradients in one kernel.  `grad_table` [N,2,n,n], `loss` [1] (and `grad_weights` [n], `grad_scale` [1]
     when given) are ACCUMULATED into, like autograd's .grad."""
@@ -342,7 +342,7 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
             tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, gd.data_ptr(), b, MODEL_IDS[model],
             METRIC_IDS[metric], None if w is None else w.data_ptr(), eps, sc_ptr, float(scale_coef), float(loss_scale),
             loss.data_ptr(), grad_table.data_ptr(), None if grad_weights is None else grad_weights.data_ptr(),
-            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), 0,
+            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), int(flags),
             torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _lib.check(rc)
@@ -352,7 +352,8 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
 
 
 def model_loss_backward_rows(table, triplets, graph_dist, grad_rows, loss, model="upper", metric="riem", weights=None,
-                             grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None):
+                             grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None,
+                             flags=0):
     """The fused training step with the table gradient left per pair (C-ABI sympa_model_loss_backward_rows):
     `grad_rows` [2b, 2, n, n] is WRITTEN -- rows [0, b) belong to triplets[:, 0], rows [b, 2b) to triplets[:, 1];
     loss / grad_weights / grad_scale are accumulated as in model_loss_backward."""
@@ -386,7 +387,7 @@ def model_loss_backward_rows(table, triplets, graph_dist, grad_rows, loss, model
             METRIC_IDS[metric], None if w is None else w.data_ptr(), eps, sc_ptr, float(scale_coef), float(loss_scale),
             loss.data_ptr(), grad_rows.data_ptr(), grad_rows.data_ptr() + b * rowbytes,
             None if grad_weights is None else grad_weights.data_ptr(),
-            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), 0,
+            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), int(flags),
             torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _lib.check(rc)

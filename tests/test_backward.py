@@ -337,3 +337,59 @@ def test_gpu_backward_dims_9_to_16(dev, model, n):
     assert abs(float(loss2.detach()) - float(loss1.detach())) < 1e-9 * abs(float(loss1.detach()))
     assert relmax(m2.embeddings.embeds.grad.cpu(), m1.embeddings.embeds.grad.cpu()) < 1e-9
     assert relmax(m2.scale.grad.cpu(), m1.scale.grad.cpu()) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", list(range(9, 17)))
+def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, n):
+    """Upper model, dims 9..16: the sixteen-lanes-per-pair backward (siegel_coop_bwd.hpp, the default) against the
+    one-lane-per-pair kernel over scratch (SYMPA_FLAG_GENERIC) -- every metric, a batch that is not a multiple of the
+    four pairs of a round, the regimes of 1, 2 and 16 rounds per wave, per-pair rows and the in-kernel scatter with the
+    fused loss, an out-of-range index."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(1900 + n)
+    for b in ((4099, 8190, 66001) if n == 11 else (4099,)):
+        z1, z2 = points("upper", b, n, 0.3, g), points("upper", b, n, 0.3, g)
+        z1, z2 = z1.to(dev), z2.to(dev)
+        go = (torch.rand(b, generator=g, dtype=torch.float64) + 0.5).to(dev)
+        w = torch.linspace(-0.3, 1.2, n, dtype=torch.float64)
+        for metric in (("riem", "fone", "finf", "fmin", "wsum") if b == 4099 else ("riem",)):
+            ref = ops.siegel_dist_backward(z1, z2, go, metric=metric, weights=w, flags=ops.FLAG_GENERIC)
+            got = ops.siegel_dist_backward(z1, z2, go, metric=metric, weights=w)
+            ops.check_status(dev)
+            for k in (0, 1):
+                scale = ref[k].abs().reshape(b, -1).max(1).values.clamp_min(1e-300)
+                err = (got[k] - ref[k]).abs().reshape(b, -1).max(1).values / scale
+                assert float(err.max()) < 1e-9, (n, b, metric, k, float(err.max()))
+            if metric == "wsum":
+                assert relmax(got[2].cpu(), ref[2].cpu()) < 1e-11
+    # fused loss through the table: rows out and scatter, scale gradient, out-of-range index
+    rows_n = 300
+    table = points("upper", rows_n, n, 0.3, g).to(dev)
+    b = 1203
+    trip = torch.stack((torch.randint(0, rows_n, (b,), generator=g), torch.randint(0, rows_n, (b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    sc = torch.tensor([1.7], dtype=torch.float64, device=dev)
+    res = []
+    for fl in (0, ops.FLAG_GENERIC):
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        gt = torch.zeros_like(table)
+        ops.model_loss_backward(table, trip, gd, gt, loss, scale=sc, grad_scale=gs, loss_scale=0.5, flags=fl)
+        rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+        loss2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward_rows(table, trip, gd, rows, loss2, scale=sc, loss_scale=0.5, flags=fl)
+        gt2 = torch.zeros_like(table)
+        ops.scatter_add_rows_(gt2, rows, torch.cat((trip[:, 0], trip[:, 1])))
+        res.append((gt.cpu(), float(loss), float(gs), gt2.cpu(), float(loss2)))
+    ops.check_status(dev)
+    assert relmax(res[0][0], res[1][0]) < 1e-10 and relmax(res[0][3], res[1][3]) < 1e-10
+    assert relmax(res[0][0], res[0][3]) < 1e-12
+    assert abs(res[0][1] - res[1][1]) < 1e-11 * abs(res[1][1]) and abs(res[0][4] - res[1][4]) < 1e-11 * abs(res[1][4])
+    assert abs(res[0][2] - res[1][2]) < 1e-9 * abs(res[1][2])
+    trip[5, 1] = rows_n
+    rows = torch.full((2 * b, 2, n, n), 7.0, dtype=torch.float64, device=dev)
+    ops.model_loss_backward_rows(table, trip, gd, rows, torch.zeros(1, dtype=torch.float64, device=dev))
+    assert float(rows[5].abs().max()) == 0.0 and float(rows[b + 5].abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        ops.check_status(dev)

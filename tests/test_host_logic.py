@@ -189,3 +189,35 @@ def test_manifold_parameter_survives_deepcopy_and_pickle():
     assert q.data_ptr() != p.data_ptr()
     r = pickle.loads(pickle.dumps(p))
     assert isinstance(r.manifold, UpperHalfManifold)
+
+
+def test_dpp_hazard_checker_flags_a_copy_in_front_of_a_dpp_read():
+    """tools/check_dpp_hazards.py (run by build() on every translation unit): a VALU write of a DPP source within two wait
+    states is flagged -- directly, through a register pair, and across a branch into the block; wait states from s_nop
+    and from unrelated instructions clear it."""
+    import os
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import check_dpp_hazards as chk
+
+    def scan(body):
+        text = "_Z1kv:\n" + "".join("\t" + l + "\n" if not l.endswith(":") else l + "\n" for l in body) + "\ts_endpgm\n"
+        with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+            f.write(text)
+        try:
+            return chk.check_file(f.name)
+        finally:
+            os.unlink(f.name)
+
+    dpp = "v_fmac_f64_dpp v[76:77], v[30:31], v[70:71] row_newbcast:0 row_mask:0xf bank_mask:0xf"
+    assert scan(["v_mov_b64_e32 v[30:31], v[26:27]", dpp]) == (1, [("_Z1kv", "v_mov_b64_e32 v[30:31], v[26:27]", dpp)])
+    assert len(scan(["v_accvgpr_read_b32 v31, a5", "v_add_f64 v[2:3], v[4:5], v[6:7]", dpp])[1]) == 1     # one wait state only
+    assert scan(["v_mov_b64_e32 v[30:31], v[26:27]", "s_nop 1", dpp])[1] == []
+    assert scan(["v_mov_b64_e32 v[30:31], v[26:27]", "v_add_f64 v[2:3], v[4:5], v[6:7]", "v_add_f64 v[8:9], v[4:5], v[6:7]", dpp])[1] == []
+    assert scan(["v_mov_b64_e32 v[32:33], v[26:27]", dpp])[1] == []                                       # another register
+    assert scan(["global_load_dwordx2 v[30:31], v[0:1], off", dpp])[1] == []                              # not a VALU write
+    # the write sits at the end of a block that branches to the DPP instruction's block
+    body = ["v_mov_b64_e32 v[30:31], v[26:27]", "s_cbranch_execz .LBB0_2", ".LBB0_1:", "s_nop 3", ".LBB0_2:", dpp]
+    assert len(scan(body)[1]) == 1
+    assert scan(["v_cmpx_lt_f64_e32 v[0:1], v[2:3]"])[1] != []
