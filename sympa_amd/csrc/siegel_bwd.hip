@@ -24,8 +24,7 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     }
     if (n > 8 && n <= SYMPA_MAX_DIMS_BACKWARD) {
         // sixteen lanes per pair (siegel_coop_bwd.hpp); SYMPA_FLAG_GENERIC keeps the one-lane-per-pair kernel over scratch
-        if (model == SYMPA_MODEL_UPPER && !(a.f.flags & SYMPA_FLAG_GENERIC))
-            return launch_bwd_coop_upper(a, n, scatter, s);
+        if (!(a.f.flags & SYMPA_FLAG_GENERIC)) return launch_bwd_coop(a, n, model, scatter, s);
         return launch_bwd_rolled(a, n, model, scatter, s);
     }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "backward: dims outside [1, SYMPA_MAX_DIMS_BACKWARD]");

@@ -1,0 +1,8 @@
+// Siegel backward, sixteen lanes per pair (siegel_coop_bwd_kernel.hpp): bounded model, M = 10, scatter output.
+// One kernel per translation unit: the build checks each unit's ISA for the DPP copy hazard (tools/check_dpp_hazards.py)
+// and only a unit that fails pays for the safe form.
+#include "siegel_coop_bwd_kernel.hpp"
+
+namespace sympa_hip {
+int launch_bwd_coop_bounded_10_scatter(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<sympa::MODEL_BOUNDED, 10, true>(a, s); }
+}  // namespace sympa_hip

@@ -1,8 +1,8 @@
-// Siegel backward, sixteen lanes per pair, upper-half model (siegel_coop_bwd_kernel.hpp): M = 12, dense output.
+// Siegel backward, sixteen lanes per pair (siegel_coop_bwd_kernel.hpp): bounded model, M = 9, scatter output.
 // One kernel per translation unit: the build checks each unit's ISA for the DPP copy hazard (tools/check_dpp_hazards.py)
 // and only a unit that fails pays for the safe form.
 #include "siegel_coop_bwd_kernel.hpp"
 
 namespace sympa_hip {
-int launch_bwd_coop_upper_12_dense(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<12, false>(a, s); }
+int launch_bwd_coop_bounded_9_scatter(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<sympa::MODEL_BOUNDED, 9, true>(a, s); }
 }  // namespace sympa_hip

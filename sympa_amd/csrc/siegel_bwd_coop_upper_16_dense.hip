@@ -1,8 +1,8 @@
-// Siegel backward, sixteen lanes per pair, upper-half model (siegel_coop_bwd_kernel.hpp): M = 11, dense output.
+// Siegel backward, sixteen lanes per pair (siegel_coop_bwd_kernel.hpp): upper model, M = 16, dense output.
 // One kernel per translation unit: the build checks each unit's ISA for the DPP copy hazard (tools/check_dpp_hazards.py)
 // and only a unit that fails pays for the safe form.
 #include "siegel_coop_bwd_kernel.hpp"
 
 namespace sympa_hip {
-int launch_bwd_coop_upper_11_dense(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<11, false>(a, s); }
+int launch_bwd_coop_upper_16_dense(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<sympa::MODEL_UPPER, 16, false>(a, s); }
 }  // namespace sympa_hip

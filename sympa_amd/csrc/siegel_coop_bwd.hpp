@@ -1,4 +1,4 @@
-// Upper-half model, backward with sixteen lanes per pair (layout and DPP machinery of spd_coop.hpp / siegel_coop.hpp):
+// Upper-half and bounded models, backward with sixteen lanes per pair (layout and DPP machinery of spd_coop.hpp / siegel_coop.hpp):
 // the training path for 9 <= n <= 16.  The one-lane-per-pair adjoint keeps E, H, V and four more n x n complex matrices
 // of a pair in scratch memory (siegel_bwd_rolled.hip: 5 M pairs/s at n = 10, 1 M at n = 16); here lane r of a group of
 // sixteen owns row r (or column r, where noted) of every matrix of its pair and everything stays in registers.
@@ -13,6 +13,10 @@
 //   Ebar = 2 U diag(phi) V^H,  Dbar = L1^-T Ebar L2^-1
 //   A1bar = -L1^-T Re(U diag(phi) U^H) L1^-1,  A2bar = -L2^-T Re(V diag(phi lambda) V^H) L2^-1
 //   X2bar = sym Re Dbar,  Y2bar = sym Im Dbar + A2bar,  X1bar = -sym Re Dbar,  Y1bar = -sym Im Dbar + A1bar
+// Bounded model: E = C1^-1 D C2^-T with the complex factors of I - W_k W_k^H = C_k C_k^H (siegel_coop.hpp), the same
+// eigen part, then  Dbar = C1^-H Ebar conj(C2)^-1,  A1bar = -C1^-H (U diag(phi) U^H) C1^-1,
+// A2bar = -C2^-H conj(V diag(phi lambda) V^H) C2^-1,  W1bar = -Dbar - 2 A1bar W1,  W2bar = Dbar - 2 A2bar W2, each plane
+// symmetrised.
 // Checked on the GPU against the one-lane-per-pair kernel (SYMPA_FLAG_GENERIC), the g++ build of the same adjoint and the
 // reference-autograd goldens.
 #pragma once
@@ -163,6 +167,65 @@ __device__ __forceinline__ void adbh_rows(const double (&ar)[M], const double (&
         outr[j] = a0 + a1;
         if constexpr (!REAL_ONLY) outi[j] = b0 + b1;
     });
+}
+
+// a <- a M^-1 for complex rows held one per lane, M = C (CONJ = false) or conj(C) (CONJ = true), C lower triangular with
+// a real diagonal (rd = 1 / diag):  a'[j] = (a[j] - sum_{k>j} a'[k] M[k][j]) / C[j][j];  C[k][j] is register j of lane k.
+template <int M, bool CONJ>
+__device__ __forceinline__ void csolve_right_l(double (&ar)[M], double (&ai)[M], const double (&cr)[M], const double (&ci)[M],
+                                               const double (&rd)[M]) {
+    sfor<0, M>([&](auto JJ) {
+        constexpr int j = M - 1 - JJ;
+        sfor<j + 1, M>([&](auto K) {
+            constexpr int k = K;
+            // a'[k] (mr + i mi),  mi = -ci for conj(C)
+            fnmac_bc<k>(ar[j], cr[j], ar[k]);
+            fnmac_bc<k>(ai[j], cr[j], ai[k]);
+            if constexpr (CONJ) {
+                fnmac_bc<k>(ar[j], ci[j], ai[k]);
+                fmac_bc<k>(ai[j], ci[j], ar[k]);
+            } else {
+                fmac_bc<k>(ar[j], ci[j], ai[k]);
+                fnmac_bc<k>(ai[j], ci[j], ar[k]);
+            }
+        });
+        ar[j] *= rd[j];
+        ai[j] *= rd[j];
+    });
+}
+
+// rows of T = A W from the rows of A (mine) and of W (broadcast):  T[me][j] = sum_k A[me][k] W[k][j]
+template <int M>
+__device__ __forceinline__ void cmatmul_rows(const double (&ar)[M], const double (&ai)[M], double (&wr)[M], double (&wi)[M],
+                                             double (&tr)[M], double (&ti)[M]) {
+    sfor<0, M>([&](auto J) { wr[J] = settle(wr[J]); wi[J] = settle(wi[J]); });
+    sfor<0, M>([&](auto J) {
+        constexpr int j = J;
+        double t0 = 0.0, t1 = 0.0, u0 = 0.0, u1 = 0.0;
+        sfor<0, M>([&](auto K) {
+            constexpr int k = K;
+            fmac_bc<k>(t0, wr[j], ar[k]);
+            fnmac_bc<k>(t1, wi[j], ai[k]);
+            fmac_bc<k>(u0, wi[j], ar[k]);
+            fmac_bc<k>(u1, wr[j], ai[k]);
+        });
+        tr[j] = t0 + t1;
+        ti[j] = u0 + u1;
+    });
+}
+
+// Hermitian p (rows) <- C^-H p C^-1 (rows), complex factor:  q = p C^-1, transpose, q^T conj(C)^-1 = (C^-H q)^T = conj of the
+// rows of the Hermitian result
+template <int M>
+__device__ __forceinline__ void ccongruence_inv_h_rows(double (&pr)[M], double (&pi)[M], double (&cr)[M], double (&ci)[M],
+                                                       const double (&rd)[M], double* __restrict__ tbuf, const int r) {
+    sfor<0, M>([&](auto J) { cr[J] = settle(cr[J]); ci[J] = settle(ci[J]); });
+    csolve_right_l<M, false>(pr, pi, cr, ci, rd);
+    double tr[M], ti[M];
+    spd_coop::transpose_rows(pr, tr, tbuf, r);
+    spd_coop::transpose_rows(pi, ti, tbuf, r);
+    csolve_right_l<M, true>(tr, ti, cr, ci, rd);
+    sfor<0, M>([&](auto J) { pr[J] = tr[J]; pi[J] = -ti[J]; });
 }
 
 }  // namespace siegel_coop

@@ -1,5 +1,5 @@
-// Kernel of the sixteen-lanes-per-pair Siegel backward (routines: siegel_coop_bwd.hpp), upper-half model, instantiated
-// per matrix size M = n by siegel_bwd_coop_*.hip.  Same argument block, outputs and fused AverageDistortionLoss as the
+// Kernel of the sixteen-lanes-per-pair Siegel backward (routines: siegel_coop_bwd.hpp), both models, instantiated per
+// model, matrix size M = n and output form by siegel_bwd_coop_*.hip.  Same argument block, outputs and fused AverageDistortionLoss as the
 // one-pair-per-lane kernel (siegel_bwd_kernel.hpp); SCATTER: atomic adds of the gradient rows into the table gradient,
 // otherwise per-pair rows [b, 2, n, n].
 #pragma once
@@ -13,8 +13,9 @@ namespace sympa_hip {
 // round t and lane r of the group owns row r of every matrix of that pair.  Lanes r >= M are phantoms (spd_coop.hpp).
 // The host picks rounds = clamp(b / 4096, 1, 16) (spd_coop::coop_rounds): a 512-register wave owns its SIMD, so a batch
 // below 65 536 pairs is spread over all 1024 SIMDs instead of filling a quarter of them with 16-round waves.
-template <int M, bool SCATTER>
+template <int MODEL, int M, bool SCATTER>
 __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, const int rounds) {
+    constexpr bool UPPER = (MODEL == sympa::MODEL_UPPER);
     using namespace siegel_coop;
     using spd_coop::cholesky_rows;
     using spd_coop::solve_right_l;
@@ -55,24 +56,45 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
         }
         const double* pa = f.base1 + r1 * ROW;
         const double* pb = f.base2 + r2 * ROW;
-        double dr[M], di[M], l1[M], l2[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const int lo = r < j ? r : j, hi = r < j ? j : r;
-            const int e = (hi < M) ? lo * M + hi : 0;                 // upper triangle; a phantom lane reads element 0
-            const double xa = pa[e], ya = pa[nn + e], xb = pb[e], yb = pb[nn + e];
-            dr[j] = xb - xa; di[j] = yb - ya; l1[j] = ya; l2[j] = yb;
-        }
-        double rd1[M], rd2[M];
-        const bool pd1 = cholesky_rows(l1, rd1);
-        const bool pd2 = cholesky_rows(l2, rd2);
-        solve_right_lt(dr, l2, rd2);                                  // W = D L2^-T (both planes)
-        solve_right_lt(di, l2, rd2);
+        // upper: l1, l2 = rows of the real factors of Y1, Y2 (c1i, c2i unused);  bounded: c = rows of the complex factors
+        double l1[M], l2[M], c1i[M], c2i[M], rd1[M], rd2[M];
         double etr[M], eti[M];
-        transpose_rows(dr, etr, tbuf, r);
-        transpose_rows(di, eti, tbuf, r);
-        solve_right_lt(etr, l1, rd1);                                 // rows of E^T = W^T L1^-T: my column of E
-        solve_right_lt(eti, l1, rd1);
+        bool pd1, pd2;
+        if constexpr (UPPER) {
+            double dr[M], di[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const int lo = r < j ? r : j, hi = r < j ? j : r;
+                const int e = (hi < M) ? lo * M + hi : 0;             // upper triangle; a phantom lane reads element 0
+                const double xa = pa[e], ya = pa[nn + e], xb = pb[e], yb = pb[nn + e];
+                dr[j] = xb - xa; di[j] = yb - ya; l1[j] = ya; l2[j] = yb;
+            }
+            spd_coop::cholesky_rows2(l1, rd1, l2, rd2, pd1, pd2);
+            spd_coop::solve_right_lt2(dr, di, l2, rd2);               // W = D L2^-T (both planes)
+            transpose_rows(dr, etr, tbuf, r);
+            transpose_rows(di, eti, tbuf, r);
+            spd_coop::solve_right_lt2(etr, eti, l1, rd1);             // rows of E^T = W^T L1^-T: my column of E
+        } else {
+            double dr[M], di[M];
+            {
+                double w1r[M], w1i[M], w2r[M], w2i[M];
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const int lo = r < j ? r : j, hi = r < j ? j : r;
+                    const int e = (hi < M) ? lo * M + hi : 0;
+                    w1r[j] = pa[e]; w1i[j] = pa[nn + e]; w2r[j] = pb[e]; w2i[j] = pb[nn + e];
+                    dr[j] = w2r[j] - w1r[j]; di[j] = w2i[j] - w1i[j];
+                }
+                id_minus_wwh_rows(w2r, w2i, l2, c2i, r);              // A2 = I - W2 W2^H
+                id_minus_wwh_rows(w1r, w1i, l1, c1i, r);
+            }
+            pd2 = ccholesky_rows(l2, c2i, rd2);
+            csolve_right_lt(dr, di, l2, c2i, rd2);                    // W = D C2^-T
+            transpose_rows(dr, etr, tbuf, r);
+            transpose_rows(di, eti, tbuf, r);
+            pd1 = ccholesky_rows(l1, c1i, rd1);
+            csolve_right_lt(etr, eti, l1, c1i, rd1);                  // rows of E^T = W^T C1^-T
+        }
         double d[M], e[M], vr[M], vi[M], bk[M], phr[M], phi_[M];
         {
             double hr[M], hi[M], br[M], bi[M];
@@ -133,7 +155,7 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
 #pragma unroll
         for (int k = 0; k < M; ++k) gwl[k] = 0.0;
         bool finite;
-        double dist = sympa::spectral_adjoint<M, sympa::MODEL_UPPER>(lam, f.metric, f.metric_w, f.inv_eps, 1.0, phi, philam,
+        double dist = sympa::spectral_adjoint<M, MODEL>(lam, f.metric, f.metric_w, f.inv_eps, 1.0, phi, philam,
                                                                      gwl, finite);
         if (!finite) dist = __builtin_nan("");
         double go = 0.0, loss_i = 0.0;
@@ -152,30 +174,76 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
 #pragma unroll
         for (int k = 0; k < M; ++k) { p2[k] = 2.0 * fs * phi[k]; phi[k] *= fs; philam[k] *= fs; }
 
-        double ebr[M], ebi[M], gg[M], kq[M], none[1];
-        adbh_rows<M, false>(urr, uri, p2, vrr, vri, ebr, ebi);         // Ebar = 2 U diag(phi) V^H
+        // (g1r, g1i), (g2r, g2i): my rows of the symmetric gradients with respect to the two points
+        double g1r[M], g1i[M], g2r[M], g2i[M];
         {
-            double dummy[M];
+            double ebr[M], ebi[M];
+            adbh_rows<M, false>(urr, uri, p2, vrr, vri, ebr, ebi);     // Ebar = 2 U diag(phi) V^H
+            double tr[M], ti[M];
+            if constexpr (UPPER) {
+                // Dbar = L1^-T Ebar L2^-1, both planes; its symmetric part
+#pragma unroll
+                for (int j = 0; j < M; ++j) { l1[j] = settle(l1[j]); l2[j] = settle(l2[j]); }
+                spd_coop::solve_right_l2(ebr, ebi, l2, rd2);
+                transpose_rows(ebr, tr, tbuf, r);
+                transpose_rows(ebi, ti, tbuf, r);
+                spd_coop::solve_right_l2(tr, ti, l1, rd1);            // rows of Dbar^T
+            } else {
+                // Dbar = C1^-H Ebar conj(C2)^-1:  (C1^-H X)^T = X^T conj(C1)^-1
+#pragma unroll
+                for (int j = 0; j < M; ++j) { l1[j] = settle(l1[j]); l2[j] = settle(l2[j]); c1i[j] = settle(c1i[j]); c2i[j] = settle(c2i[j]); }
+                csolve_right_l<M, true>(ebr, ebi, l2, c2i, rd2);
+                transpose_rows(ebr, tr, tbuf, r);
+                transpose_rows(ebi, ti, tbuf, r);
+                csolve_right_l<M, true>(tr, ti, l1, c1i, rd1);        // rows of Dbar^T
+            }
+            transpose_rows(tr, ebr, tbuf, r);                         // rows of Dbar
+            transpose_rows(ti, ebi, tbuf, r);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                g2r[j] = 0.5 * (tr[j] + ebr[j]); g2i[j] = 0.5 * (ti[j] + ebi[j]);
+                g1r[j] = -g2r[j]; g1i[j] = -g2i[j];
+            }
+        }
+        if constexpr (UPPER) {
+            double gg[M], kq[M], dummy[M];
             adbh_rows<M, true>(urr, uri, phi, urr, uri, gg, dummy);    // Re G = Re U diag(phi) U^H
             adbh_rows<M, true>(vrr, vri, philam, vrr, vri, kq, dummy); // Re K = Re V diag(phi lambda) V^H
+            spd_coop::congruence_inv_t_rows(gg, l1, rd1, tbuf, r);    // L1^-T Re G L1^-1
+            spd_coop::congruence_inv_t_rows(kq, l2, rd2, tbuf, r);    // L2^-T Re K L2^-1
+#pragma unroll
+            for (int j = 0; j < M; ++j) { g1i[j] -= gg[j]; g2i[j] -= kq[j]; }
+        } else {
+            // Wbar_k = -/+ Dbar - 2 Abar_k W_k with Abar_1 = -C1^-H G C1^-1, Abar_2 = -C2^-H conj(K) C2^-1; symmetrised
+            auto point_term = [&](double (&ar)[M], double (&ai)[M], double (&cr)[M], double (&ci)[M], const double (&rd)[M],
+                                  const double* __restrict__ pw, double (&outr)[M], double (&outi)[M]) {
+                ccongruence_inv_h_rows(ar, ai, cr, ci, rd, tbuf, r);  // C^-H (.) C^-1 = -Abar
+                double wr[M], wi[M], tr[M], ti[M], sr[M], si[M];
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const int lo = r < j ? r : j, hi = r < j ? j : r;
+                    const int e = (hi < M) ? lo * M + hi : 0;
+                    wr[j] = pw[e]; wi[j] = pw[nn + e];
+                }
+                cmatmul_rows(ar, ai, wr, wi, tr, ti);                 // T = (-Abar) W
+                transpose_rows(tr, sr, tbuf, r);
+                transpose_rows(ti, si, tbuf, r);
+#pragma unroll
+                for (int j = 0; j < M; ++j) { outr[j] += tr[j] + sr[j]; outi[j] += ti[j] + si[j]; }   // sym(-2 Abar W) = T + T^T
+            };
+            {
+                double gr[M], gi[M];
+                adbh_rows<M, false>(urr, uri, phi, urr, uri, gr, gi);  // G = U diag(phi) U^H
+                point_term(gr, gi, l1, c1i, rd1, pa, g1r, g1i);
+            }
+            {
+                double kr[M], ki[M];
+                adbh_rows<M, false>(vrr, vri, philam, vrr, vri, kr, ki);
+#pragma unroll
+                for (int j = 0; j < M; ++j) ki[j] = -ki[j];           // conj(K)
+                point_term(kr, ki, l2, c2i, rd2, pb, g2r, g2i);
+            }
         }
-        (void)none;
-        // Dbar = L1^-T Ebar L2^-1, both planes; its symmetric part
-#pragma unroll
-        for (int j = 0; j < M; ++j) { l1[j] = settle(l1[j]); l2[j] = settle(l2[j]); }
-        solve_right_l(ebr, l2, rd2);
-        solve_right_l(ebi, l2, rd2);
-        double tr[M], ti[M];
-        transpose_rows(ebr, tr, tbuf, r);
-        transpose_rows(ebi, ti, tbuf, r);
-        solve_right_l(tr, l1, rd1);                                   // rows of Dbar^T
-        solve_right_l(ti, l1, rd1);
-        transpose_rows(tr, ebr, tbuf, r);                             // rows of Dbar
-        transpose_rows(ti, ebi, tbuf, r);
-#pragma unroll
-        for (int j = 0; j < M; ++j) { tr[j] = 0.5 * (tr[j] + ebr[j]); ti[j] = 0.5 * (ti[j] + ebi[j]); }
-        spd_coop::congruence_inv_t_rows(gg, l1, rd1, tbuf, r);        // L1^-T Re G L1^-1
-        spd_coop::congruence_inv_t_rows(kq, l2, rd2, tbuf, r);        // L2^-T Re K L2^-1
 
         const bool write = live && !bad && r < M;
         if constexpr (SCATTER) {
@@ -184,7 +252,7 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
                 double* o2 = a.g2 + r2 * ROW + r * M;
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
-                    const double x1 = -tr[j], y1 = -ti[j] - gg[j], x2 = tr[j], y2 = ti[j] - kq[j];
+                    const double x1 = g1r[j], y1 = g1i[j], x2 = g2r[j], y2 = g2i[j];
                     if (x1 != 0.0) atomicAdd(o1 + j, x1);
                     if (y1 != 0.0) atomicAdd(o1 + nn + j, y1);
                     if (x2 != 0.0) atomicAdd(o2 + j, x2);
@@ -194,17 +262,12 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
         } else if (live && r < M) {
             double* o1 = a.g1 + i * ROW + r * M;
             double* o2 = a.g2 + i * ROW + r * M;
-#ifdef SYMPA_COOP_DEBUG
-#pragma unroll
-            for (int j = 0; j < M; ++j) { o1[j] = vrr[j]; o1[nn + j] = vri[j]; o2[j] = lam[j]; o2[nn + j] = d[j]; }
-            continue;
-#endif
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                o1[j] = bad ? 0.0 : -tr[j];
-                o1[nn + j] = bad ? 0.0 : -ti[j] - gg[j];
-                o2[j] = bad ? 0.0 : tr[j];
-                o2[nn + j] = bad ? 0.0 : ti[j] - kq[j];
+                o1[j] = bad ? 0.0 : g1r[j];
+                o1[nn + j] = bad ? 0.0 : g1i[j];
+                o2[j] = bad ? 0.0 : g2r[j];
+                o2[nn + j] = bad ? 0.0 : g2i[j];
             }
         }
         if (r == 0) {
@@ -255,18 +318,18 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
     }
 }
 
-template <int M, bool SCATTER>
+template <int MODEL, int M, bool SCATTER>
 int launch_coop_bwd_ms(const BwdArgs& a, hipStream_t s) {
     const int rounds = spd_coop::coop_rounds(a.f.b);
     const dim3 grid((unsigned)((a.f.b + 4 * rounds - 1) / (4 * rounds)));
-    hipLaunchKernelGGL((siegel_coop_bwd_kernel<M, SCATTER>), grid, dim3(64), 0, s, a, rounds);
+    hipLaunchKernelGGL((siegel_coop_bwd_kernel<MODEL, M, SCATTER>), grid, dim3(64), 0, s, a, rounds);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
 }
 
-// upper-half model, n = 9..16 (siegel_bwd_coop_<n>_{dense,scatter}.hip: one kernel per translation unit)
-int launch_bwd_coop_upper(const BwdArgs& a, int n, bool scatter, hipStream_t s);
+// n = 9..16, both models (siegel_bwd_coop_<model>_<n>_{dense,scatter}.hip: one kernel per translation unit; siegel_bwd_coop.hip)
+int launch_bwd_coop(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
 int launch_bwd_coop_upper_9_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_9_scatter(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_10_dense(const BwdArgs& a, hipStream_t s);
@@ -283,5 +346,21 @@ int launch_bwd_coop_upper_15_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_15_scatter(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_16_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_16_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_9_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_9_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_10_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_10_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_11_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_11_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_12_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_12_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_13_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_13_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_14_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_14_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_15_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_15_scatter(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_16_dense(const BwdArgs& a, hipStream_t s);
+int launch_bwd_coop_bounded_16_scatter(const BwdArgs& a, hipStream_t s);
 
 }  // namespace sympa_hip

@@ -140,6 +140,23 @@ __device__ __forceinline__ void solve_right_lt(double (&a)[M], const double (&l)
     });
 }
 
+// The same for two right-hand sides at once (the Re and Im planes of a complex matrix against a real factor).  The DPP
+// statements are `asm volatile` and keep their program order, so independent dependency chains have to be interleaved
+// in the source: a[j] and b[j] are two accumulators instead of one.
+template <int M>
+__device__ __forceinline__ void solve_right_lt2(double (&a)[M], double (&b)[M], const double (&l)[M], const double (&rd)[M]) {
+    sfor<0, M>([&](auto J) {
+        constexpr int j = J;
+        sfor<0, j>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<j>(a[j], l[k], a[k]);
+            fnmac_bc<j>(b[j], l[k], b[k]);
+        });
+        a[j] *= rd[j];
+        b[j] *= rd[j];
+    });
+}
+
 // Cholesky X = L L^T of the matrix held one row per lane, right-looking, in place: after step j, register j of
 // lane i >= j holds L[i][j]; rd[j] = 1 / L[j][j] (group-uniform).  Returns "all pivots positive".
 template <int M>
@@ -158,6 +175,30 @@ __device__ __forceinline__ bool cholesky_rows(double (&x)[M], double (&rd)[M]) {
         });
     });
     return pd;
+}
+
+// Two independent factorisations interleaved (Y1 and Y2 of a pair): the pivot's rsqrt chain of one hides behind the
+// trailing update of the other.
+template <int M>
+__device__ __forceinline__ void cholesky_rows2(double (&x)[M], double (&rdx)[M], double (&y)[M], double (&rdy)[M], bool& pdx,
+                                               bool& pdy) {
+    pdx = true; pdy = true;
+    sfor<0, M>([&](auto J) {
+        constexpr int j = J;
+        const double px = bcast<j>(settle(x[j]));
+        const double py = bcast<j>(settle(y[j]));
+        pdx = pdx && (px > 0.0);
+        pdy = pdy && (py > 0.0);
+        const double rx = sympa::d_rsqrt(px), ry = sympa::d_rsqrt(py);
+        rdx[j] = rx; rdy[j] = ry;
+        x[j] = settle(x[j] * rx);
+        y[j] = settle(y[j] * ry);
+        sfor<j + 1, M>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<k>(x[k], x[j], x[j]);
+            fnmac_bc<k>(y[k], y[j], y[j]);
+        });
+    });
 }
 
 // m <- y^T for the rows held one per lane, through 2 KB of LDS private to my group

@@ -37,6 +37,21 @@ __device__ __forceinline__ void solve_right_l(double (&a)[M], const double (&l)[
     });
 }
 
+// two right-hand sides at once (independent chains interleaved in the source: the DPP statements keep program order)
+template <int M>
+__device__ __forceinline__ void solve_right_l2(double (&a)[M], double (&b)[M], const double (&l)[M], const double (&rd)[M]) {
+    sfor<0, M>([&](auto JJ) {
+        constexpr int j = M - 1 - JJ;
+        sfor<j + 1, M>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<k>(a[j], l[j], a[k]);
+            fnmac_bc<k>(b[j], l[j], b[k]);
+        });
+        a[j] *= rd[j];
+        b[j] *= rd[j];
+    });
+}
+
 // Householder tridiagonalisation of the symmetric matrix held one row per lane, reflectors kept:
 //   d[k], e[k] (signed: e[k] = T[k+1][k]) group-uniform;  vk[k] = my component of reflector k;  bk[k] = beta_k.
 template <int M>

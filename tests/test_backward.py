@@ -341,21 +341,22 @@ def test_gpu_backward_dims_9_to_16(dev, model, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", list(range(9, 17)))
-def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, n):
-    """Upper model, dims 9..16: the sixteen-lanes-per-pair backward (siegel_coop_bwd.hpp, the default) against the
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, model, n):
+    """Both models, dims 9..16: the sixteen-lanes-per-pair backward (siegel_coop_bwd.hpp, the default) against the
     one-lane-per-pair kernel over scratch (SYMPA_FLAG_GENERIC) -- every metric, a batch that is not a multiple of the
     four pairs of a round, the regimes of 1, 2 and 16 rounds per wave, per-pair rows and the in-kernel scatter with the
     fused loss, an out-of-range index."""
     from sympa_amd import ops
-    g = torch.Generator().manual_seed(1900 + n)
-    for b in ((4099, 8190, 66001) if n == 11 else (4099,)):
-        z1, z2 = points("upper", b, n, 0.3, g), points("upper", b, n, 0.3, g)
+    g = torch.Generator().manual_seed(1900 + n + (50 if model == "bounded" else 0))
+    for b in ((4099, 8190, 66001) if (n == 11 and model == "upper") or (n == 10 and model == "bounded") else (4099,)):
+        z1, z2 = points(model, b, n, 0.3, g), points(model, b, n, 0.3, g)
         z1, z2 = z1.to(dev), z2.to(dev)
         go = (torch.rand(b, generator=g, dtype=torch.float64) + 0.5).to(dev)
         w = torch.linspace(-0.3, 1.2, n, dtype=torch.float64)
         for metric in (("riem", "fone", "finf", "fmin", "wsum") if b == 4099 else ("riem",)):
-            ref = ops.siegel_dist_backward(z1, z2, go, metric=metric, weights=w, flags=ops.FLAG_GENERIC)
-            got = ops.siegel_dist_backward(z1, z2, go, metric=metric, weights=w)
+            ref = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w, flags=ops.FLAG_GENERIC)
+            got = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w)
             ops.check_status(dev)
             for k in (0, 1):
                 scale = ref[k].abs().reshape(b, -1).max(1).values.clamp_min(1e-300)
@@ -365,7 +366,7 @@ def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, n):
                 assert relmax(got[2].cpu(), ref[2].cpu()) < 1e-11
     # fused loss through the table: rows out and scatter, scale gradient, out-of-range index
     rows_n = 300
-    table = points("upper", rows_n, n, 0.3, g).to(dev)
+    table = points(model, rows_n, n, 0.3, g).to(dev)
     b = 1203
     trip = torch.stack((torch.randint(0, rows_n, (b,), generator=g), torch.randint(0, rows_n, (b,), generator=g)), 1).to(dev)
     gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
@@ -375,10 +376,10 @@ def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, n):
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
         gs = torch.zeros(1, dtype=torch.float64, device=dev)
         gt = torch.zeros_like(table)
-        ops.model_loss_backward(table, trip, gd, gt, loss, scale=sc, grad_scale=gs, loss_scale=0.5, flags=fl)
+        ops.model_loss_backward(table, trip, gd, gt, loss, model=model, scale=sc, grad_scale=gs, loss_scale=0.5, flags=fl)
         rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=dev)
         loss2 = torch.zeros(1, dtype=torch.float64, device=dev)
-        ops.model_loss_backward_rows(table, trip, gd, rows, loss2, scale=sc, loss_scale=0.5, flags=fl)
+        ops.model_loss_backward_rows(table, trip, gd, rows, loss2, model=model, scale=sc, loss_scale=0.5, flags=fl)
         gt2 = torch.zeros_like(table)
         ops.scatter_add_rows_(gt2, rows, torch.cat((trip[:, 0], trip[:, 1])))
         res.append((gt.cpu(), float(loss), float(gs), gt2.cpu(), float(loss2)))
@@ -389,7 +390,7 @@ def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, n):
     assert abs(res[0][2] - res[1][2]) < 1e-9 * abs(res[1][2])
     trip[5, 1] = rows_n
     rows = torch.full((2 * b, 2, n, n), 7.0, dtype=torch.float64, device=dev)
-    ops.model_loss_backward_rows(table, trip, gd, rows, torch.zeros(1, dtype=torch.float64, device=dev))
+    ops.model_loss_backward_rows(table, trip, gd, rows, torch.zeros(1, dtype=torch.float64, device=dev), model=model)
     assert float(rows[5].abs().max()) == 0.0 and float(rows[b + 5].abs().max()) == 0.0
     with pytest.raises(IndexError):
         ops.check_status(dev)
