@@ -11,6 +11,9 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     if ((a.go == nullptr && a.graph_dist == nullptr) || a.g1 == nullptr || a.g2 == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "null gradient buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // A/B of the sixteen-lanes layout below its range (measured slower: DESIGN.md section 8)
+    if ((a.f.flags & SYMPA_FLAG_COOP) && model == SYMPA_MODEL_UPPER && !scatter && (n == 7 || n == 8))
+        return n == 7 ? launch_bwd_coop_upper_7_dense(a, s) : launch_bwd_coop_upper_8_dense(a, s);
     switch (n) {
         case 1: return launch_bwd_n<1>(a, model, scatter, s);
         case 2: return launch_bwd_n<2>(a, model, scatter, s);

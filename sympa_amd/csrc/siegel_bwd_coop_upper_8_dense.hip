@@ -1,0 +1,7 @@
+// Siegel backward, sixteen lanes per pair (siegel_coop_bwd_kernel.hpp): upper model, M = 8, dense output -- for the A/B
+// against the one-pair-per-lane kernel only (SYMPA_FLAG_COOP; half the lanes of a group are phantoms at this size).
+#include "siegel_coop_bwd_kernel.hpp"
+
+namespace sympa_hip {
+int launch_bwd_coop_upper_8_dense(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<sympa::MODEL_UPPER, 8, false>(a, s); }
+}  // namespace sympa_hip

@@ -13,8 +13,14 @@ namespace sympa_hip {
 // round t and lane r of the group owns row r of every matrix of that pair.  Lanes r >= M are phantoms (spd_coop.hpp).
 // The host picks rounds = clamp(b / 4096, 1, 16) (spd_coop::coop_rounds): a 512-register wave owns its SIMD, so a batch
 // below 65 536 pairs is spread over all 1024 SIMDs instead of filling a quarter of them with 16-round waves.
+// Waves per SIMD (measured per 65 536 pairs, one 512-register wave against two 256-register waves that spill 300-1300
+// registers): upper n = 10 836 / 953 us, n = 16 2489 / 3015 us -> one wave;  bounded n = 10 1469 / 1285 us, n = 16
+// 4558 / 4036 us -> two waves (its tail of complex solves and products has the longer dependent chains to hide).
+template <int MODEL>
+constexpr int coop_bwd_waves() { return MODEL == sympa::MODEL_UPPER ? 1 : 2; }
+
 template <int MODEL, int M, bool SCATTER>
-__global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, const int rounds) {
+__global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_kernel(const BwdArgs a, const int rounds) {
     constexpr bool UPPER = (MODEL == sympa::MODEL_UPPER);
     using namespace siegel_coop;
     using spd_coop::cholesky_rows;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(64) void siegel_coop_bwd_kernel(const BwdArgs a, co
 
 template <int MODEL, int M, bool SCATTER>
 int launch_coop_bwd_ms(const BwdArgs& a, hipStream_t s) {
-    const int rounds = spd_coop::coop_rounds(a.f.b);
+    const int rounds = spd_coop::coop_rounds(a.f.b, coop_bwd_waves<MODEL>());
     const dim3 grid((unsigned)((a.f.b + 4 * rounds - 1) / (4 * rounds)));
     hipLaunchKernelGGL((siegel_coop_bwd_kernel<MODEL, M, SCATTER>), grid, dim3(64), 0, s, a, rounds);
     const hipError_t e = hipGetLastError();
@@ -330,6 +336,8 @@ int launch_coop_bwd_ms(const BwdArgs& a, hipStream_t s) {
 
 // n = 9..16, both models (siegel_bwd_coop_<model>_<n>_{dense,scatter}.hip: one kernel per translation unit; siegel_bwd_coop.hip)
 int launch_bwd_coop(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
+int launch_bwd_coop_upper_7_dense(const BwdArgs& a, hipStream_t s);      // A/B only (SYMPA_FLAG_COOP)
+int launch_bwd_coop_upper_8_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_9_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_9_scatter(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_10_dense(const BwdArgs& a, hipStream_t s);

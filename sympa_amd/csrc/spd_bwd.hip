@@ -155,7 +155,7 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
     const dim3 grid((unsigned)((b + 63) / 64));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n >= SPD_COOP_BWD_MIN_N && !(flags & SYMPA_FLAG_GENERIC)) {
-        if (n == 16) hipLaunchKernelGGL(spd_coop_bwd_kernel<16>, spd_coop_bwd_grid(a.b), dim3(64), 0, s, a, spd_coop::coop_rounds(a.b));
+        if (n == 16) hipLaunchKernelGGL(spd_coop_bwd_kernel<16>, spd_coop_bwd_grid(a.b, 16), dim3(64), 0, s, a, spd_coop::coop_rounds(a.b, spd_coop_bwd_waves<16>()));
         else if (n >= 12) launch_spd_coop_bwd_hi(a, n, grid, s);
         else launch_spd_coop_bwd_lo(a, n, grid, s);
     } else {

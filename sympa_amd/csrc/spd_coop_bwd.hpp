@@ -96,7 +96,13 @@ __device__ __forceinline__ void tridiagonalize_keep(double (&m)[M], const int r,
 }
 
 // Implicit QL with accumulated rotations (tql2) on the group-uniform tridiagonal (d, e); zrow = my row of Z (identity
-// on entry).  The iteration of a stage ends when all pairs of the wave have deflated position L.
+// on entry).  The iteration of a stage ends when all pairs of the wave have deflated position L.  The per-pair active
+// block [L, m] is handled by SELECTS on every state variable (18 of the ~49 instructions of a step).  Real branches --
+// the sixteen lanes of a pair take them together, so the hardware's exec mask would do the predication -- were tried:
+// 6-12 % faster (spd n = 16 1.28 -> 1.21 ms, upper n = 16 2.83 -> 2.49 ms per 65 536 pairs) and correct in every kernel
+// but one (upper, n = 16, scatter output: every gradient wrong with the distances right, identical with and without wait
+// states in the asm statements, i.e. not a hazard; the same source was right in the rows-out kernel).  Not understood,
+// so not used.
 template <int M>
 __device__ __forceinline__ bool tridiag_ql_vectors_row(double (&d)[M], double (&e)[M], double (&zrow)[M]) {
     bool all_ok = true;

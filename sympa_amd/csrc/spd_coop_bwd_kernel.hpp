@@ -8,6 +8,11 @@
 
 namespace sympa_hip {
 
+// Waves per SIMD: two 256-register waves hide each other's dependent chains where the working set fits (M <= 11: no or
+// few spills; n = 8 374 -> 341 us, n = 10 539 -> 511 us per 65 536 pairs); at M = 16 the cap spills and is slower
+// (1.27 -> 1.64 ms), so the large sizes keep one 512-register wave.
+template <int M>
+constexpr int spd_coop_bwd_waves() { return M <= 11 ? 2 : 1; }
 constexpr int SPD_COOP_BWD_MIN_N = 3;      // below: one lane per pair (spd_bwd_kernel), measured faster
 
 struct SpdBwdArgs {
@@ -30,8 +35,8 @@ struct SpdBwdArgs {
     int32_t* status;
 };
 
-inline dim3 spd_coop_bwd_grid(const int64_t b) {
-    const int rounds = spd_coop::coop_rounds(b);
+inline dim3 spd_coop_bwd_grid(const int64_t b, const int n) {
+    const int rounds = spd_coop::coop_rounds(b, n <= 11 ? 2 : 1);
     return dim3((unsigned)((b + 4 * rounds - 1) / (4 * rounds)));
 }
 
@@ -45,7 +50,7 @@ void launch_spd_coop_bwd_lo(const SpdBwdArgs& a, int n, dim3 grid, hipStream_t s
 // wave; group g of the wave handles pair 4 (rounds * block + t) + g in round t, lane r of the group owns row r of every
 // matrix of that pair.
 template <int M>
-__global__ __launch_bounds__(64) void spd_coop_bwd_kernel(const SpdBwdArgs a, const int rounds) {
+__global__ __launch_bounds__(64, spd_coop_bwd_waves<M>()) void spd_coop_bwd_kernel(const SpdBwdArgs a, const int rounds) {
     using namespace spd_coop;
     __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
     const int lane = threadIdx.x;
