@@ -71,10 +71,14 @@ extern "C" {
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 16 /* largest n with a backward kernel in this build (n = 7, 8 spill to scratch; n = 9..16 run
-                                      the same adjoint as rolled loops over per-lane scratch arrays) */
+                                      sixteen lanes per pair, csrc/siegel_coop_bwd.hpp; SYMPA_FLAG_GENERIC selects the same
+                                      adjoint as rolled loops over per-lane scratch arrays; SYMPA_FLAG_COOP at n = 7, 8 runs
+                                      the sixteen-lanes kernel for A/B) */
 #define SYMPA_MAX_DIMS_ALL_PAIRS_PACKED 4 /* sympa_all_pairs_dist_packed: per-point factor reuse, dims 1..4 */
-#define SYMPA_MAX_DIMS_GENERIC 16 /* forward only: n in (SYMPA_MAX_DIMS, 16] run sixteen lanes per pair
-                                     (csrc/siegel_coop.hpp); SYMPA_FLAG_GENERIC selects the runtime-n fallback (scratch) */
+#define SYMPA_MAX_DIMS_GENERIC 16 /* n in (SYMPA_MAX_DIMS, 16]: the forward runs sixteen lanes per pair (csrc/siegel_coop.hpp;
+                                     SYMPA_FLAG_GENERIC selects the runtime-n fallback over scratch); the table operations
+                                     (sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step* / sympa_tangent_sqnorm) run the
+                                     row arithmetic of dims <= 8 with rolled loops over scratch (siegel_table_rolled.hip) */
 
 /* Library / build identification. */
 const char* sympa_version(void);

@@ -19,27 +19,27 @@ namespace sympa {
 // Real symmetric Jacobi with eigenvectors: a = V diag(d) V^T.  a: full symmetric input (upper triangle used).
 template <int N>
 SYMPA_HD bool sym_eigen_vectors(double (&a)[N][N], double (&d)[N], double (&v)[N][N]) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i) {
         d[i] = a[i][i];
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
     }
     if (N == 1) return true;
     bool conv = false;
     for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
         double off2 = 0.0, diag2 = 0.0;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) {
             diag2 = d_fma(d[i], d[i], diag2);
-#pragma unroll
+SYMPA_UNROLL
             for (int j = i + 1; j < N; ++j) off2 = d_fma(a[i][j], a[i][j], off2);
         }
         conv = !(off2 > 1e-30 * diag2);
         if (wave_all(conv)) break;
-#pragma unroll
+SYMPA_UNROLL
         for (int p = 0; p < N - 1; ++p) {
-#pragma unroll
+SYMPA_UNROLL
             for (int q = p + 1; q < N; ++q) {
                 const double b = a[p][q];
                 const double a2 = b * b;
@@ -55,7 +55,7 @@ SYMPA_HD bool sym_eigen_vectors(double (&a)[N][N], double (&d)[N], double (&v)[N
                 d[p] -= ua2;
                 d[q] += ua2;
                 a[p][q] = 0.0;
-#pragma unroll
+SYMPA_UNROLL
                 for (int k = 0; k < N; ++k) {
                     if (k == p || k == q) continue;
                     const double x = (k < p) ? a[k][p] : a[p][k];
@@ -65,7 +65,7 @@ SYMPA_HD bool sym_eigen_vectors(double (&a)[N][N], double (&d)[N], double (&v)[N
                     if (k < p) a[k][p] = nx; else a[p][k] = nx;
                     if (k < q) a[k][q] = ny; else a[q][k] = ny;
                 }
-#pragma unroll
+SYMPA_UNROLL
                 for (int k = 0; k < N; ++k) {
                     const double x = v[k][p], y = v[k][q];
                     v[k][p] = d_fma(-s, y, c * x);
@@ -79,9 +79,9 @@ SYMPA_HD bool sym_eigen_vectors(double (&a)[N][N], double (&d)[N], double (&v)[N
 
 template <int N>
 SYMPA_HD void symmetrise(CMat<N>& z) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = i + 1; j < N; ++j) {
             const double r = 0.5 * (z.re[i][j] + z.re[j][i]);
             const double m = 0.5 * (z.im[i][j] + z.im[j][i]);
@@ -93,12 +93,12 @@ SYMPA_HD void symmetrise(CMat<N>& z) {
 // real n x n products  out = a * b
 template <int N>
 SYMPA_HD void rmatmul(const double (&a)[N][N], const double (&b)[N][N], double (&out)[N][N]) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             double t = 0.0;
-#pragma unroll
+SYMPA_UNROLL
             for (int k = 0; k < N; ++k) t = d_fma(a[i][k], b[k][j], t);
             out[i][j] = t;
         }
@@ -115,12 +115,12 @@ SYMPA_HD void egrad2rgrad(const CMat<N>& z, const CMat<N>& u, CMat<N>& out) {
         rmatmul<N>(t, z.im, out.im);
     } else {
         CMat<N> a, zc, t;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) { zc.re[i][j] = z.re[i][j]; zc.im[i][j] = -z.im[i][j]; }
         cmatmul<N>(zc, z, -1.0, a);              // -conj(Z) Z
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) a.re[i][i] += 1.0;
         cmatmul<N>(a, u, 1.0, t);
         cmatmul<N>(t, a, 1.0, out);
@@ -134,21 +134,21 @@ SYMPA_HD bool projx(CMat<N>& z, double eps, int& status) {
     symmetrise<N>(z);
     if (MODEL == MODEL_UPPER) {
         double a[N][N], d[N], v[N][N];
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) a[i][j] = z.im[i][j];
         if (!sym_eigen_vectors<N>(a, d, v)) status |= ST_NO_CONVERGENCE;
         bool inside = true;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i) inside = inside && (d[i] > eps);
         if (inside) return false;
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) {
                 double t = 0.0;
-#pragma unroll
+SYMPA_UNROLL
                 for (int k = 0; k < N; ++k) t = d_fma(v[i][k] * fmax(d[k], eps), v[j][k], t);
                 z.im[i][j] = t;
             }
@@ -162,17 +162,17 @@ SYMPA_HD bool projx(CMat<N>& z, double eps, int& status) {
         if (!herm_eigen_vectors<N>(h, v)) status |= ST_NO_CONVERGENCE;
         const double lim = 1.0 - eps;
         bool inside = true;
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < N; ++k) inside = inside && (h.d[k] < lim * lim);
         if (inside) return false;
         CMat<N> zu;
         cmatmul<N>(z, v, 1.0, zu);               // columns Z u_k
-#pragma unroll
+SYMPA_UNROLL
         for (int k = 0; k < N; ++k) {
             const double sig = d_sqrt(fmax(h.d[k], 0.0));
             if (!(sig > lim)) continue;
             double pr = 0.0, pi = 0.0;            // u_k^T (Z u_k)
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i) {
                 pr = d_fma(v.re[i][k], zu.re[i][k], pr);
                 pr = d_fma(-v.im[i][k], zu.im[i][k], pr);
@@ -181,9 +181,9 @@ SYMPA_HD bool projx(CMat<N>& z, double eps, int& status) {
             }
             const double f = (sig - lim) * d_rcp(sig);          // (sigma - lim) e^{i theta} = f * p,  p = sigma e^{i theta}
             const double fr = f * pr, fi = f * pi;
-#pragma unroll
+SYMPA_UNROLL
             for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
                 for (int j = 0; j < N; ++j) {
                     // conj(u_ik) conj(u_jk)   (conj(u_k) u_k^H)_ij
                     const double cr = v.re[i][k] * v.re[j][k] - v.im[i][k] * v.im[j][k];
@@ -201,17 +201,17 @@ SYMPA_HD bool projx(CMat<N>& z, double eps, int& status) {
 template <int N, int MODEL>
 SYMPA_HD bool rsgd_row(CMat<N>& z, const CMat<N>& grad, double lr, double weight_decay, double eps, int& status) {
     CMat<N> g, r;
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             g.re[i][j] = d_fma(weight_decay, z.re[i][j], grad.re[i][j]);
             g.im[i][j] = d_fma(weight_decay, z.im[i][j], grad.im[i][j]);
         }
     egrad2rgrad<N, MODEL>(z, g, r);
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             z.re[i][j] = d_fma(-lr, r.re[i][j], z.re[i][j]);
             z.im[i][j] = d_fma(-lr, r.im[i][j], z.im[i][j]);
@@ -234,26 +234,26 @@ SYMPA_HD double tangent_sqnorm(const CMat<N>& z, const CMat<N>& u, int& status) 
     if (MODEL == MODEL_UPPER) {
         Tri<N, false> l;
         ok = chol_real<N>(z.im, l);
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) { e.re[i][j] = u.re[i][j]; e.im[i][j] = u.im[i][j]; }
         solve_left<N, false>(l, e);
         solve_right_t<N, false>(l, e);
     } else {
         Tri<N, true> c;
         ok = chol_id_minus_wwh<N>(z, c);
-#pragma unroll
+SYMPA_UNROLL
         for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
             for (int j = 0; j < N; ++j) { e.re[i][j] = u.re[i][j]; e.im[i][j] = -u.im[i][j]; }
         solve_left<N, true>(c, e);
         solve_right_t<N, true>(c, e);
     }
     double acc = 0.0;
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) acc = d_fma(e.re[i][j], e.re[j][i], d_fma(e.im[i][j], e.im[j][i], acc));
     if (!ok) status |= ST_NOT_PD;
     return acc;
@@ -261,16 +261,16 @@ SYMPA_HD double tangent_sqnorm(const CMat<N>& z, const CMat<N>& u, int& status) 
 
 template <int N>
 SYMPA_HD void load_full(const double* __restrict__ p, CMat<N>& z) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) { z.re[i][j] = p[i * N + j]; z.im[i][j] = p[N * N + i * N + j]; }
 }
 template <int N>
 SYMPA_HD void store_full(double* __restrict__ p, const CMat<N>& z) {
-#pragma unroll
+SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
-#pragma unroll
+SYMPA_UNROLL
         for (int j = 0; j < N; ++j) { p[i * N + j] = z.re[i][j]; p[N * N + i * N + j] = z.im[i][j]; }
 }
 

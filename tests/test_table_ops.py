@@ -203,3 +203,27 @@ def test_gpu_tangent_norm_and_riemannian_adam(dev, model, n):
     ops.check_status(dev)
     ok, _, reason = m.check_all_points()
     assert ok, reason
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [9, 12, 16])
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_table_operations_dims_9_to_16(dev, model, n):
+    """dims 9..16: the same row arithmetic as dims <= 8 compiled with rolled loops (siegel_table_rolled.hip) -- egrad2rgrad,
+    the RSGD step with a small and a large learning rate (projection path), projx of points already inside (bit-identical
+    apart from the symmetrisation) -- against the oracle's restatement of the reference methods."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(40 + n)
+    table, grad = step_inputs(model, n, g)
+    want = (so.upper_egrad2rgrad if model == "upper" else so.bounded_egrad2rgrad)(table, grad)
+    assert relmax(ops.egrad2rgrad(table.to(dev), grad.to(dev), model).cpu(), want) < 1e-12
+    for lr in (1e-2, 0.7):
+        want, keep = so.rsgd_step(model, table, grad, lr, 0.01)
+        tab = table.clone().to(dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.rsgd_step_(tab, grad.to(dev), model, lr, 0.01, counter=cnt)
+        ops.check_status(dev)
+        assert relmax(tab.cpu(), want) < 1e-8, (model, n, lr)
+        assert int(cnt) == int((~keep).sum())
+    out = ops.projx(table.to(dev), model)
+    assert torch.equal(out.cpu(), so.to_symmetric(table))

@@ -89,3 +89,20 @@ def test_riemannian_adam_trains():
     assert hist[-1][2] < 0.75 * hist[0][2] and hist[-1][2] < 0.55, hist       # measured: 0.68 (epoch 5) -> 0.42
     ok, point, reason = model.check_all_points()
     assert ok, reason
+
+
+@pytest.mark.parametrize("manifold,dims", [("upper", 10), ("bounded", 9), ("spd", 16)])
+def test_training_through_the_sixteen_lanes_kernels(manifold, dims):
+    """dims 9..16 (Siegel) and spd n = 16 (configs[4]'s matrix size) end to end: the forward, the fused loss + backward with
+    in-kernel scatter / rows + scatter and the optimiser step all run on the sixteen-lanes-per-pair kernels; the
+    distortion of the 125-node grid drops and every point stays on the manifold."""
+    import train_siegel
+    lr = "0.01" if manifold == "spd" else "0.02"
+    args = train_siegel.parser().parse_args(["--graph", "grid3d-125", "--manifold", manifold, "--metric", "riem",
+                                             "--dims", str(dims), "--epochs", "20", "--batch_size", "512",
+                                             "--val_every", "10", "--learning_rate", lr, "--burnin", "5"])
+    model, hist = train_siegel.train(args, log=lambda *_: None)
+    first, last = hist[0][2], hist[-1][2]
+    assert last < 0.8 * first, hist
+    ok, point, reason = model.check_all_points()
+    assert ok, reason
