@@ -2,10 +2,14 @@
 // (SURVEY 8f-2): egrad2rgrad, projx, and the fused RiemannianSGD step.  One table row per lane; these run
 // once per optimiser step over N rows (N = 5 041 .. 100 000) and are bandwidth-trivial next to the
 // distance kernels, so rows are loaded directly.
+#include <cstdlib>
+
 #include "siegel_table_kernel.hpp"
 
 namespace {
 using namespace sympa_hip;
+
+__device__ int g_rows_outside;      // rows that left the eps-interior in the last sixteen-lanes RSGD step
 
 // OP 0: out = projx(z).   OP 1: table <- retr(table, -lr * egrad2rgrad(table, grad + wd * table)) in place.
 // sum of squares of `count` doubles, accumulated into acc[0] (the total gradient norm of clip_grad_norm_)
@@ -57,8 +61,24 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
         case 8: return launch_table<8>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
         default: break;
     }
-    if (n > 8 && n <= SYMPA_MAX_DIMS_GENERIC)
+    if (n > 8 && n <= SYMPA_MAX_DIMS_GENERIC) {
+        // SYMPA_TABLE_GENERIC=1 keeps the one-row-per-lane kernels for A/B measurements (tools/table_time.py)
+        static const bool generic = std::getenv("SYMPA_TABLE_GENERIC") != nullptr;
+        if ((op == 1 || op == 2) && !generic) {
+            // sixteen lanes per row; the step counts the rows that left the eps-interior in a device word and the exact
+            // one-row-per-lane projx runs gated on it (siegel_coop_table.hpp)
+            static int* outside = nullptr;
+            if (outside == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&outside), HIP_SYMBOL(g_rows_outside)) != hipSuccess)
+                return fail(SYMPA_ERR_BAD_ARG, "no device symbol for the interior test");
+            if (op == 1 && hipMemsetAsync(outside, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "memset failed");
+            const int rc = model == SYMPA_MODEL_UPPER
+                               ? launch_table_coop_upper(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s)
+                               : launch_table_coop_bounded(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
+            if (rc != 0 || op == 2) return rc;
+            return launch_table_rolled(0, n, model, z, nullptr, z, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside);
+        }
         return launch_table_rolled(op, n, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
+    }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS_GENERIC]");
 }
 

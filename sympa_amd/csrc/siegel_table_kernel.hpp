@@ -39,7 +39,11 @@ __global__ __launch_bounds__(BLOCK) void tangent_sqnorm_kernel(const double* z, 
 template <int N, int MODEL, int OP>
 __global__ __launch_bounds__(BLOCK) void table_update_kernel(double* z, const double* grad, double* out, int64_t b,
                                                              double lr, double wd, double eps, int32_t* projected,
-                                                             int32_t* status, const double* clip, double max_norm) {
+                                                             int32_t* status, const double* clip, double max_norm,
+                                                             const int* gate) {
+    // gate: device word written by the sixteen-lanes step kernel (siegel_coop_table.hpp) = rows that left the interior;
+    // zero (the usual case) -> nothing to project
+    if (gate != nullptr && *gate == 0) return;
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < b;
     const int64_t ii = live ? i : b - 1;      // tail lanes recompute the last row (the Jacobi loops ballot)
@@ -76,7 +80,8 @@ SYMPA_UNROLL
 
 template <int N>
 int launch_table(int op, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
-                 double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm) {
+                 double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm,
+                 const int* gate = nullptr) {
     const unsigned grid = (unsigned)((b + BLOCK - 1) / BLOCK);
     const bool up = model == SYMPA_MODEL_UPPER;
     if (op == 3) {
@@ -86,11 +91,11 @@ int launch_table(int op, int model, double* z, const double* g, double* out, int
         if (up) hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
         else hipLaunchKernelGGL((egrad2rgrad_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b);
     } else if (op == 0) {
-        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
-        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
+        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm, gate);
+        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 0>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm, gate);
     } else {
-        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
-        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm);
+        if (up) hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_UPPER, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm, gate);
+        else hipLaunchKernelGGL((table_update_kernel<N, sympa::MODEL_BOUNDED, 1>), dim3(grid), dim3(BLOCK), 0, s, z, g, out, b, lr, wd, eps, projected, status, clip, max_norm, gate);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -99,6 +104,13 @@ int launch_table(int op, int model, double* z, const double* g, double* out, int
 
 // n = 9..16 (siegel_table_rolled.hip)
 int launch_table_rolled(int op, int n, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
-                        double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm);
+                        double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm,
+                        const int* gate = nullptr);
+// n = 9..16, op 1 (RSGD step) and 2 (egrad2rgrad) with sixteen lanes per row (siegel_table_coop_{upper,bounded}.hip);
+// `outside`: device word that receives the number of rows that left the eps-interior (op 1)
+int launch_table_coop_upper(int op, int n, double* z, const double* g, double* out, int64_t b, double lr, double wd, double eps,
+                            const double* clip, double max_norm, int* outside, hipStream_t s);
+int launch_table_coop_bounded(int op, int n, double* z, const double* g, double* out, int64_t b, double lr, double wd, double eps,
+                              const double* clip, double max_norm, int* outside, hipStream_t s);
 
 }  // namespace sympa_hip
