@@ -10,11 +10,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("manifold,metric", [("upper", "riem"), ("bounded", "fone")])
-def test_embedding_a_grid_reduces_distortion(manifold, metric):
+@pytest.mark.parametrize("manifold,metric,dims", [("upper", "riem", 2), ("bounded", "fone", 2), ("bounded", "finf", 4)])
+def test_embedding_a_grid_reduces_distortion(manifold, metric, dims):
+    """configs[0] (grid, n = 2), and configs[2]'s model (bounded, F-infinity metric, n = 4) on the same small graph."""
     import train_siegel
     args = train_siegel.parser().parse_args(["--graph", "grid3d-125", "--manifold", manifold, "--metric", metric,
-                                             "--dims", "2", "--epochs", "40", "--batch_size", "512",
+                                             "--dims", str(dims), "--epochs", "40", "--batch_size", "512",
                                              "--val_every", "10", "--learning_rate", "0.02", "--burnin", "5"])
     model, hist = train_siegel.train(args, log=lambda *_: None)
     first, last = hist[0][2], hist[-1][2]
