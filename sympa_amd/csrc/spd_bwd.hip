@@ -1,6 +1,7 @@
 // gfx950 kernels + C-ABI of the SPD model's training path (spd_math_bwd.hpp): backward of the affine-invariant
 // distance with the fused AverageDistortionLoss, and the optimiser-side row operations (egrad2rgrad, projx, RSGD step).
-// One pair / one table row per lane, runtime n <= 16, per-lane scratch: functional, not tuned.
+// Sixteen lanes per pair / per row for n >= 3 (spd_coop_bwd_kernel.hpp, spd_coop_table.hpp); the one-pair-per-lane kernels
+// below (runtime n <= 16, per-lane scratch) serve n <= 2, projx, and SYMPA_FLAG_GENERIC / SYMPA_SPD_TABLE_GENERIC=1 (A/B).
 // PARITY UNPINNED with respect to geoopt (absent); pinned by mpmath finite differences and autograd through the oracle.
 #include <cstdlib>
 
