@@ -37,11 +37,13 @@ def test_embedding_at_dims_8_trains(tmp_path):
     assert ok, reason
 
 
-def test_graphed_step_equals_eager_step():
-    """One hipGraph replay per batch (sympa_amd/train_step.py) trains exactly like the kernel-by-kernel step: same
+@pytest.mark.parametrize("dims", [3, 10])
+def test_graphed_step_equals_eager_step(dims):
+    """dims 10: the sixteen-lanes kernels, including the memset + gated projection of the RSGD step, inside the graph.
+    One hipGraph replay per batch (sympa_amd/train_step.py) trains exactly like the kernel-by-kernel step: same
     distortion history (fp64 atomics make the last bits of a gradient order-dependent, hence a tolerance)."""
     import train_siegel
-    common = ["--graph", "grid3d-125", "--manifold", "upper", "--metric", "riem", "--dims", "3", "--epochs", "12",
+    common = ["--graph", "grid3d-125", "--manifold", "upper", "--metric", "riem", "--dims", str(dims), "--epochs", "12",
               "--batch_size", "512", "--val_every", "3", "--learning_rate", "0.02", "--burnin", "4"]
     _, h_graph = train_siegel.train(train_siegel.parser().parse_args(common), log=lambda *_: None)
     _, h_eager = train_siegel.train(train_siegel.parser().parse_args(common + ["--no_graph_step"]), log=lambda *_: None)
