@@ -155,7 +155,11 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
     a.gx = grad_x_rows; a.gy = grad_y_rows; a.gscale = grad_scale; a.out = out; a.status = status;
     const dim3 grid((unsigned)((b + 63) / 64));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n >= SPD_COOP_BWD_MIN_N && !(flags & SYMPA_FLAG_GENERIC)) {
+    // default: the QL of two rounds run together (8 pairs per wave and step) once the batch fills the chip that way;
+    // SYMPA_FLAG_COOP forces the single-round kernel (A/B), SYMPA_FLAG_GENERIC the one-lane-per-pair kernel
+    if (!(flags & (SYMPA_FLAG_COOP | SYMPA_FLAG_GENERIC)) && n >= 4 && b >= 8192 &&
+        (n <= 10 ? launch_spd_bwd_coop2_lo(a, n, s) : launch_spd_bwd_coop2_hi(a, n, s))) {
+    } else if (n >= SPD_COOP_BWD_MIN_N && !(flags & SYMPA_FLAG_GENERIC)) {
         if (n == 16) hipLaunchKernelGGL(spd_coop_bwd_kernel<16>, spd_coop_bwd_grid(a.b, 16), dim3(64), 0, s, a, spd_coop::coop_rounds(a.b, spd_coop_bwd_waves<16>()));
         else if (n >= 12) launch_spd_coop_bwd_hi(a, n, grid, s);
         else launch_spd_coop_bwd_lo(a, n, grid, s);

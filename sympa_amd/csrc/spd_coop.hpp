@@ -33,8 +33,8 @@ constexpr int ROUNDS = 16;                       // 4 pairs per round, 64 pairs 
 
 // Rounds per wave for the kernels whose waves are independent of each other's pairs (backward, table rows): one wave
 // per SIMD is resident (512 registers), so up to 1024 x 4 pairs run at once -- spread a small batch over all SIMDs.
-inline int coop_rounds(const long long b, const int waves_per_simd = 1) {
-    const long long slots = 4096ll * waves_per_simd;      // pairs in flight: 1024 SIMDs x waves x 4 pairs
+inline int coop_rounds(const long long b, const int waves_per_simd = 1, const int pairs_per_round = 4) {
+    const long long slots = 1024ll * pairs_per_round * waves_per_simd;      // pairs in flight: 1024 SIMDs x waves x pairs
     const long long r = (b + slots - 1) / slots;
     return (int)(r < 1 ? 1 : (r > ROUNDS ? ROUNDS : r));
 }

@@ -163,6 +163,71 @@ __device__ __forceinline__ bool tridiag_ql_vectors_row(double (&d)[M], double (&
     return all_ok;
 }
 
+// The same iteration with TWO rows of Z per lane: eight lanes then carry the sixteen rows of a pair, so the two halves of
+// a group of sixteen run the QL of two different pairs and every instruction of the scalar recurrence (two thirds of the
+// whole backward kernel) serves eight pairs per wave instead of four.  (d, e) must be uniform over the eight lanes.
+template <int M>
+__device__ __forceinline__ bool tridiag_ql_vectors_2rows(double (&d)[M], double (&e)[M], double (&zrow)[M], double (&zrw2)[M]) {
+    bool all_ok = true;
+    sfor<0, M - 1>([&](auto LL) {
+        constexpr int L = LL;
+        bool conv = false;
+        for (int it = 0; it < 50; ++it) {
+            int mm = M - 1;
+            sfor<0, M - 1 - L>([&](auto II) {
+                constexpr int i = M - 2 - II;
+                const bool negl = sympa::ql_negligible(e[i] * e[i], d[i], d[i + 1]);
+                e[i] = negl ? 0.0 : e[i];
+                mm = negl ? i : mm;
+            });
+            conv = (mm == L);
+            if (sympa::wave_all(conv)) break;
+            const double el = conv ? 1.0 : e[L];
+            const double g0 = 0.5 * (d[L + 1] - d[L]) * sympa::d_rcp(el);
+            const double r0 = sympa::d_sqrt(sympa::d_fma(g0, g0, 1.0));
+            const double shift = el * sympa::d_rcp(g0 + copysign(r0, g0)) - d[L];
+            double c = 1.0, s = 1.0, p = 0.0, g = 0.0;
+            sfor<0, M - 1 - L>([&](auto II) {
+                constexpr int i = M - 2 - II;
+                const bool active = !conv && (i < mm);
+                const bool start = (mm == i + 1);
+                g = start ? d[i + 1] + shift : g;
+                s = start ? 1.0 : s;
+                c = start ? 1.0 : c;
+                p = start ? 0.0 : p;
+                const double f = s * e[i];
+                const double b = c * e[i];
+                const double r2 = sympa::d_fma(f, f, g * g);
+                const double ir = sympa::d_rsqrt(r2 + sympa::TINY);
+                const double rr0 = r2 * ir;
+                const bool rzero = !(r2 > 0.0);
+                const double sn = rzero ? 0.0 : f * ir;
+                const double cn = rzero ? 1.0 : g * ir;
+                if constexpr (i + 1 <= M - 2) e[i + 1] = (active && !start) ? rr0 : e[i + 1];
+                const double g2 = d[i + 1] - p;
+                const double rr = sympa::d_fma(d[i] - g2, sn, 2.0 * cn * b);
+                const double pn = sn * rr;
+                d[i + 1] = active ? g2 + pn : d[i + 1];
+                const double gn = sympa::d_fma(cn, rr, -b);
+                const double ce = active ? cn : 1.0, se = active ? sn : 0.0;
+                const double zf = zrow[i + 1], zg = zrw2[i + 1];
+                zrow[i + 1] = sympa::d_fma(se, zrow[i], ce * zf);
+                zrow[i] = sympa::d_fma(ce, zrow[i], -se * zf);
+                zrw2[i + 1] = sympa::d_fma(se, zrw2[i], ce * zg);
+                zrw2[i] = sympa::d_fma(ce, zrw2[i], -se * zg);
+                s = active ? sn : s;
+                c = active ? cn : c;
+                p = active ? pn : p;
+                g = active ? gn : g;
+            });
+            d[L] = conv ? d[L] : d[L] - p;
+            e[L] = conv ? e[L] : g;
+        }
+        all_ok = all_ok && conv;
+    });
+    return all_ok;
+}
+
 // zc = my COLUMN of Z (lane c holds Z[:, c]);  zc <- P_0 ... P_{M-3} zc  with P_k = I - beta_k v_k v_k^T, component
 // r of v_k living in lane r's vk[k].
 template <int M>

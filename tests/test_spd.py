@@ -341,6 +341,18 @@ def test_gpu_spd_cooperative_backward_every_size(n):
     diff = (rows_c - rows_g).abs().reshape(2 * b, -1).max(1).values.cpu()
     assert (diff / scale_).max() < 1e-8, (n, (diff / scale_).max())
     assert float(out_c[7]) == 0.0 and float(rows_c[7].abs().max()) == 0.0
+    # batches of 8192 pairs and more take the kernel that runs the QL of two rounds together (8 pairs per wave and step):
+    # ragged count, against the single-round kernel (SYMPA_FLAG_COOP) on the same pairs repeated
+    reps = 8197 // b + 1
+    xb, yb = x.repeat(reps, 1, 1)[:8197].to(dev), y.repeat(reps, 1, 1)[:8197].to(dev)
+    gob = go.repeat(reps)[:8197].to(dev)
+    rows_p, out_p = ops.spd_backward_rows(xb, yb, grad_out=gob, want_out=True)
+    rows_s, out_s = ops.spd_backward_rows(xb, yb, grad_out=gob, want_out=True, flags=ops.FLAG_COOP)
+    ops.check_status(dev)
+    assert rel_err(out_p.cpu(), out_s.cpu()) < 1e-12
+    sc2 = rows_s.abs().reshape(2 * 8197, -1).max(1).values.clamp_min(1e-300)
+    assert float(((rows_p - rows_s).abs().reshape(2 * 8197, -1).max(1).values / sc2).max()) < 1e-9
+    assert rel_err(rows_p[:b].cpu(), rows_c[:b].cpu(), atol=1e-14) < 1e-9
     xs, ys = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
     (so.spd_dist(xs, ys) * go).sum().backward()
     keep = torch.ones(b, dtype=torch.bool); keep[7] = False

@@ -21,7 +21,7 @@ for n in dims:
     go = (torch.rand(b, generator=g, dtype=torch.float64) + 0.5).to(dev)
     rows = torch.empty(2 * b, n, n, dtype=torch.float64, device=dev)
     res = {}
-    for name, fl in (("one lane per pair", ops.FLAG_GENERIC), ("sixteen lanes per pair", 0)):
+    for name, fl in (("one lane per pair", ops.FLAG_GENERIC), ("sixteen lanes per pair", ops.FLAG_COOP), ("sixteen lanes, paired QL", 0)):
         for _ in range(2):
             ops.spd_backward_rows(table, table, trip, grad_out=go, rows=rows, flags=fl)
         torch.cuda.synchronize()
@@ -33,6 +33,6 @@ for n in dims:
         res[name] = (dt, rows.clone())
     ops.check_status(dev)
     ref = res["one lane per pair"][1]
-    diff = float((res["sixteen lanes per pair"][1] - ref).abs().max() / ref.abs().max())
-    for name, (dt, _) in res.items():
+    for name, (dt, rows_) in res.items():
+        diff = float((rows_ - ref).abs().max() / ref.abs().max())
         print(f"spd backward rows n={n:2d} b={b} {name:24s}: {dt * 1e6:9.1f} us  {b / dt / 1e6:8.2f} M pairs/s   max rel diff {diff:.1e}")
