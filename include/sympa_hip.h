@@ -65,8 +65,11 @@ extern "C" {
 #define SYMPA_FLAG_FUSE 8 /* sympa_model_forward_batches only (dims <= SYMPA_MAX_DIMS): up to SYMPA_MAX_FUSED_BATCHES
                              consecutive batches per kernel launch instead of one launch per batch */
 #define SYMPA_MAX_FUSED_BATCHES 32
-#define SYMPA_FLAG_COOP 32 /* dims 6 and 8 only: run the sixteen-lanes-per-pair kernel instead of the one-pair-per-lane one
-                              (kept for the A/B of DESIGN.md section 5; it is 2-2.5x slower there) */
+#define SYMPA_FLAG_COOP 32 /* A/B switch of the sixteen-lanes-per-pair layout (DESIGN.md sections 5, 8, 12):
+                              forward, dims 6 and 8: run it instead of the one-pair-per-lane kernel (2-2.5x slower there);
+                              backward (sympa_siegel_dist_bwd, upper, dims 7 and 8, dense rows): likewise (1.3-2x slower);
+                              sympa_spd_backward_rows: the single-round kernel instead of the one that runs the QL of two
+                              rounds together */
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
@@ -263,7 +266,10 @@ int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const 
  * Either grad_out [b] (dLoss/d out) or graph_dist [b] is given; with graph_dist the AverageDistortionLoss of
  * sympa/losses.py:10-19 is fused in: loss[0] += loss_scale * sum |(out / graph_dist)^2 - 1|.
  * grad_x_rows / grad_y_rows [b, n, n] are WRITTEN with the (symmetric) gradient rows of the two points of each pair;
- * accumulate them into a table gradient with sympa_scatter_add_flat_rows.  grad_scale [1] accumulated, out [b] optional. */
+ * accumulate them into a table gradient with sympa_scatter_add_flat_rows.  grad_scale [1] accumulated, out [b] optional.
+ * n >= 3 runs sixteen lanes per pair (csrc/spd_coop_bwd.hpp); flags: 0, SYMPA_FLAG_GENERIC (one lane per pair over scratch)
+ * or SYMPA_FLAG_COOP (see above).  The row operations below run sixteen lanes per row for n >= 3 (csrc/spd_coop_table.hpp;
+ * environment SYMPA_SPD_TABLE_GENERIC=1 keeps the one-row-per-lane kernel for measurements; projx always uses it). */
 int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, int n, const int64_t* src,
                             int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
                             double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
