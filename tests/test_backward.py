@@ -394,3 +394,44 @@ def test_gpu_cooperative_backward_against_one_lane_per_pair(dev, model, n):
     assert float(rows[5].abs().max()) == 0.0 and float(rows[b + 5].abs().max()) == 0.0
     with pytest.raises(IndexError):
         ops.check_status(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_cooperative_backward_nonfinite_and_degenerate_inputs(dev, model):
+    """dims 9..16 backward: a NaN / Inf entry in a point gives a NaN distance for that pair (not 0) and raises the status
+    without disturbing its neighbours in the wave; identical points give distance 0 and a zero subgradient."""
+    from sympa_amd import ops
+    n, b = 11, 37
+    g = torch.Generator().manual_seed(77)
+    z1, z2 = points(model, b, n, 0.3, g), points(model, b, n, 0.3, g)
+    z2[4] = z1[4]
+    z1[9, 0, 2, 3] = float("nan"); z1[9, 0, 3, 2] = float("nan")
+    z2[20, 1, 1, 1] = float("inf")
+    rows_n = b
+    table = torch.cat((z1, z2)).to(dev)
+    trip = torch.stack((torch.arange(b), torch.arange(b) + b), 1).to(dev)
+    gd = torch.full((b,), 2.0, dtype=torch.float64, device=dev)
+    rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    lib_out = torch.empty(b, dtype=torch.float64, device=dev)
+    # forward values through the backward entry (out) come from the same kernel
+    go = torch.ones(b, dtype=torch.float64, device=dev)
+    g1, g2, _ = ops.siegel_dist_backward(table[:b], table[b:], go, model=model)
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+    ref1, ref2, _ = ops.siegel_dist_backward(table[:b], table[b:], go, model=model, flags=ops.FLAG_GENERIC)
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+    good = torch.ones(b, dtype=torch.bool); good[9] = False; good[20] = False
+    assert torch.isfinite(g1.cpu()[good]).all() and torch.isfinite(g2.cpu()[good]).all()
+    assert relmax(g1.cpu()[good], ref1.cpu()[good]) < 1e-10 and relmax(g2.cpu()[good], ref2.cpu()[good]) < 1e-10
+    assert float(g1[4].abs().max()) == 0.0 and float(g2[4].abs().max()) == 0.0
+    d = ops.siegel_dist_forward(table[:b], table[b:], model)
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+    assert torch.isnan(d[9]) and torch.isnan(d[20]) and float(d[4]) == 0.0
+    ops.model_loss_backward_rows(table, trip, gd, rows, loss, model=model)
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+    assert torch.isnan(loss).all()                                   # a NaN pair poisons the loss, as in the reference
