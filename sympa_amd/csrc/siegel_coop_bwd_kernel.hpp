@@ -253,18 +253,17 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
 
         const bool write = live && !bad && r < M;
         if constexpr (SCATTER) {
-            if (write) {
-                double* o1 = a.g1 + r1 * ROW + r * M;
-                double* o2 = a.g2 + r2 * ROW + r * M;
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    const double x1 = g1r[j], y1 = g1i[j], x2 = g2r[j], y2 = g2i[j];
-                    if (x1 != 0.0) atomicAdd(o1 + j, x1);
-                    if (y1 != 0.0) atomicAdd(o1 + nn + j, y1);
-                    if (x2 != 0.0) atomicAdd(o2 + j, x2);
-                    if (y2 != 0.0) atomicAdd(o2 + nn + j, y2);
-                }
-            }
+            // One plane at a time through the group's LDS tile, so that consecutive lanes add to consecutive doubles: the
+            // cost of an fp64 atomic wave-instruction is per 128-byte line it touches (profiles/r01_atomic_scope.txt), and
+            // a lane-per-row instruction touches 64 lines where this one touches 4 (n = 16 fused step 1.13 -> see DESIGN 8).
+            const bool on = live && !bad;
+            double* o1 = a.g1 + r1 * ROW;
+            double* o2 = a.g2 + r2 * ROW;
+            spd_coop::scatter_plane<M>(g1r, tbuf, o1, r, on);
+            spd_coop::scatter_plane<M>(g1i, tbuf, o1 + nn, r, on);
+            spd_coop::scatter_plane<M>(g2r, tbuf, o2, r, on);
+            spd_coop::scatter_plane<M>(g2i, tbuf, o2 + nn, r, on);
+            (void)write;
         } else if (live && r < M) {
             double* o1 = a.g1 + i * ROW + r * M;
             double* o2 = a.g2 + i * ROW + r * M;

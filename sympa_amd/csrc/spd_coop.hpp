@@ -211,6 +211,23 @@ __device__ __forceinline__ void transpose_rows(const double (&y)[M], double (&m)
     sfor<0, M>([&](auto J) { m[J] = tbuf[J * N + r]; });
 }
 
+// dst[0 .. M*M) += the M x M block whose row r is `v` in lane r (fp64 atomics), through the group's LDS tile so that
+// consecutive lanes add to consecutive doubles (one 128-byte line per group and instruction instead of one per lane)
+template <int M>
+__device__ __forceinline__ void scatter_plane(const double (&v)[M], double* __restrict__ tile, double* __restrict__ dst,
+                                              const int r, const bool on) {
+    wave_lds_fence();
+    if (r < M) sfor<0, M>([&](auto J) { tile[r * M + J] = v[J]; });
+    wave_lds_fence();
+    constexpr int CHUNKS = (M * M + 15) / 16;
+    sfor<0, CHUNKS>([&](auto K) {
+        constexpr int k = K;
+        const int idx = k * 16 + r;
+        const double val = (idx < M * M) ? tile[idx] : 0.0;
+        if (on && val != 0.0) atomicAdd(dst + idx, val);
+    });
+}
+
 // First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
 // W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
 template <int M>
