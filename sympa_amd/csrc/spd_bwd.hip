@@ -133,15 +133,17 @@ int launch_spd_table(int op, double* x, const double* g, double* out, int64_t b,
 
 extern "C" {
 
-int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, int n, const int64_t* src,
+static int spd_backward_impl(const double* x, const double* y, int64_t num_rows, int n, const int64_t* src,
                             int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
                             double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
                             double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
-                            int32_t* status, int flags, void* stream) {
+                            int32_t* status, int flags, void* stream, double* grad_table) {
     if (b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (b == 0) return 0;
-    if (x == nullptr || y == nullptr || grad_x_rows == nullptr || grad_y_rows == nullptr)
+    if (x == nullptr || y == nullptr || (grad_table == nullptr && (grad_x_rows == nullptr || grad_y_rows == nullptr)))
         return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (grad_table != nullptr && (n < SPD_COOP_BWD_MIN_N || src == nullptr || (flags & SYMPA_FLAG_GENERIC)))
+        return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: the in-kernel scatter needs n >= 3 and index lists");
     if ((src == nullptr) != (dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "give both index lists or neither");
     if (src != nullptr && num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
     if (grad_out == nullptr && graph_dist == nullptr) return fail(SYMPA_ERR_BAD_ARG, "need grad_out or graph_dist");
@@ -152,7 +154,7 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
     a.x = x; a.y = y; a.src = src; a.dst = dst; a.src_stride = src_stride; a.dst_stride = dst_stride;
     a.num_rows = num_rows; a.b = b; a.scale = scale; a.inv_scale_coef = 1.0 / scale_coef;
     a.go = grad_out; a.graph_dist = graph_dist; a.loss_scale = loss_scale; a.loss = loss;
-    a.gx = grad_x_rows; a.gy = grad_y_rows; a.gscale = grad_scale; a.out = out; a.status = status;
+    a.gtab = grad_table; a.gx = grad_x_rows; a.gy = grad_y_rows; a.gscale = grad_scale; a.out = out; a.status = status;
     const dim3 grid((unsigned)((b + 63) / 64));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // default: the QL of two rounds run together (8 pairs per wave and step) once the batch fills the chip that way;
@@ -169,6 +171,25 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
+}
+
+
+int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, int n, const int64_t* src,
+                            int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
+                            double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
+                            double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
+                            int32_t* status, int flags, void* stream) {
+    return spd_backward_impl(x, y, num_rows, n, src, src_stride, dst, dst_stride, b, scale, scale_coef, grad_out, graph_dist,
+                             loss_scale, loss, grad_x_rows, grad_y_rows, grad_scale, out, status, flags, stream, nullptr);
+}
+
+int sympa_spd_loss_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                            const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
+                            const double* grad_out, const double* graph_dist, double loss_scale, double* loss,
+                            double* grad_table, double* grad_scale, double* out, int32_t* status, int flags, void* stream) {
+    if (b > 0 && grad_table == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null gradient table");
+    return spd_backward_impl(table, table, num_rows, n, src, src_stride, dst, dst_stride, b, scale, scale_coef, grad_out,
+                             graph_dist, loss_scale, loss, nullptr, nullptr, grad_scale, out, status, flags, stream, grad_table);
 }
 
 int sympa_spd_egrad2rgrad(const double* x, const double* u, int64_t b, int n, double* out, void* stream) {

@@ -28,6 +28,7 @@ struct SpdBwdArgs {
     const double* graph_dist; // [b] or nullptr (fused loss)
     double loss_scale;
     double* loss;
+    double* gtab;             // scatter form: [num_rows, n, n] table gradient, accumulated with atomics (gx, gy unused); or null
     double* gx;               // [b, n, n] rows of the src / x points
     double* gy;               // [b, n, n] rows of the dst / y points
     double* gscale;
@@ -146,7 +147,10 @@ __global__ __launch_bounds__(64, spd_coop_bwd_waves<M>()) void spd_coop_bwd_kern
         vdvt_rows(vrow, gx, px_);
         congruence_inv_t_rows(py_, x, rd, tbuf, r);
         congruence_inv_t_rows(px_, x, rd, tbuf, r);
-        if (live && r < M) {
+        if (a.gtab != nullptr) {            // in-kernel scatter, consecutive lanes on consecutive doubles (spd_coop.hpp)
+            scatter_plane<M>(px_, tbuf, a.gtab + r1 * nn, r, live && !bad);
+            scatter_plane<M>(py_, tbuf, a.gtab + r2 * nn, r, live && !bad);
+        } else if (live && r < M) {
             double* ox = a.gx + i * nn + r * M;
             double* oy = a.gy + i * nn + r * M;
 #pragma unroll
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(64) void spd_coop_bwd2_kernel(const SpdBwdArgs a, c
     // beta array) and 1 / diag(L) recomputed when the congruences need it -- n = 16 1124 -> 1076 us per 65 536 pairs; for
     // smaller M the extra square roots and reciprocals cost more than the registers (n = 12 500 -> 521 us).
     constexpr bool SLIM = M >= 14;
-    struct PairState { double l[M], rd[M], vk[M], bk[M], d[M], e[M]; bool pd, live, bad; int64_t i; };
+    struct PairState { double l[M], rd[M], vk[M], bk[M], d[M], e[M]; bool pd, live, bad; int64_t i, r1, r2; };
     // rows in, Cholesky factor + tridiagonal form + reflectors out
     auto front = [&](const int64_t i, PairState& p) {
         p.i = i;
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(64) void spd_coop_bwd2_kernel(const SpdBwdArgs a, c
             r2 = a.dst[ii * a.dst_stride];
             if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { p.bad = true; r1 = 0; r2 = 0; }
         }
+        p.r1 = r1; p.r2 = r2;
         const double* px = a.x + r1 * nn;
         const double* py = a.y + r2 * nn;
         double y[M], m[M];
@@ -299,7 +304,10 @@ __global__ __launch_bounds__(64) void spd_coop_bwd2_kernel(const SpdBwdArgs a, c
         vdvt_rows(vrow, gx, px_);
         congruence_inv_t_rows(py_, p.l, rd, tbuf, r);
         congruence_inv_t_rows(px_, p.l, rd, tbuf, r);
-        if (p.live && r < M) {
+        if (a.gtab != nullptr) {
+            scatter_plane<M>(px_, tbuf, a.gtab + p.r1 * nn, r, p.live && !p.bad);
+            scatter_plane<M>(py_, tbuf, a.gtab + p.r2 * nn, r, p.live && !p.bad);
+        } else if (p.live && r < M) {
             double* ox = a.gx + p.i * nn + r * M;
             double* oy = a.gy + p.i * nn + r * M;
 #pragma unroll

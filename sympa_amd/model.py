@@ -44,7 +44,7 @@ class Model(nn.Module):
         if table.grad is None:
             table.grad = torch.zeros_like(table.data)
         if man.model_name == "spd":
-            # two launches: per-pair gradient rows (backward + loss fused), then the coalesced scatter-add
+            # n <= 2: two launches, per-pair gradient rows (backward + loss fused), then the coalesced scatter-add
             gs = None
             if self.scale.requires_grad:
                 if self.scale.grad is None:
@@ -53,6 +53,11 @@ class Model(nn.Module):
             loss = torch.zeros(1, dtype=torch.float64, device=dev)
             b = input_triplet.shape[0]
             n = table.shape[-1]
+            if n >= 3 and table.grad.is_contiguous():
+                # one launch: loss, backward and the scatter into .grad (sympa_spd_loss_backward)
+                ops.spd_loss_backward(table.data, input_triplet, table.grad, graph_dist=graph_distances, scale=self.scale.data,
+                                      scale_coef=self.scale_coef, loss_scale=loss_scale, loss=loss, grad_scale=gs)
+                return loss
             ws = getattr(self, "_spd_rows", None)
             if ws is None or ws.shape[0] < 2 * b or ws.device != dev:
                 ws = torch.empty(2 * b, n, n, dtype=torch.float64, device=dev)

@@ -656,6 +656,48 @@ def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale
     return rows, out
 
 
+def spd_loss_backward(table, triplets, grad_table, grad_out=None, graph_dist=None, scale=None, scale_coef=1.0,
+                      loss_scale=1.0, loss=None, grad_scale=None, want_out=False, flags=0):
+    """spd backward with the scatter inside the kernel (C-ABI sympa_spd_loss_backward, n >= 3): the gradient rows of pair
+    i = (table[triplets[i, 0]], table[triplets[i, 1]]) are ACCUMULATED into grad_table [N, n, n]; grad_out [b] or
+    graph_dist [b] (fused AverageDistortionLoss into `loss`) as in spd_backward_rows.  Returns out [b] or None."""
+    lib = _lib.load()
+    _need_gpu(table, "table"); _need_gpu(triplets, "triplets"); _need_gpu(grad_table, "grad_table")
+    if table.dtype != torch.float64 or table.dim() != 3 or table.shape[1] != table.shape[2]:
+        raise ValueError(f"spd table must be float64 [N, n, n], got {tuple(table.shape)}")
+    if grad_table.dtype != torch.float64 or not grad_table.is_contiguous() or grad_table.shape != table.shape:
+        raise ValueError("grad_table must be a contiguous float64 tensor of the table's shape")
+    if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
+        raise TypeError("triplets must be an int64 [b, >=2] tensor")
+    tab = table.detach()
+    tab = tab if tab.is_contiguous() else tab.contiguous()
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    b, n, dev = triplets.shape[0], tab.shape[1], tab.device
+    out = torch.empty(b, dtype=torch.float64, device=dev) if want_out else None
+    if b == 0:
+        return out
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    go = None if grad_out is None else grad_out.detach().to(torch.float64).contiguous()
+    gd = None if graph_dist is None else graph_dist.detach().to(torch.float64).contiguous()
+    sc = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=dev, dtype=torch.float64).contiguous()
+    st = _status_buf(dev)
+    tp = triplets.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.sympa_spd_loss_backward(
+            tab.data_ptr(), tab.shape[0], n, tp, stride, tp + 8, stride, b, None if sc is None else sc.data_ptr(),
+            float(scale_coef), None if go is None else go.data_ptr(), None if gd is None else gd.data_ptr(),
+            float(loss_scale), None if loss is None else loss.data_ptr(), grad_table.data_ptr(),
+            None if grad_scale is None else grad_scale.data_ptr(), None if out is None else out.data_ptr(),
+            st.data_ptr(), int(flags), _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(dev)
+    return out
+
+
 def scatter_add_flat_rows_(grad_table, rows, idx, alpha=1.0):
     """grad_table[idx[r]] += alpha * rows[r] for rows of any length (C-ABI sympa_scatter_add_flat_rows)."""
     lib = _lib.load()

@@ -440,3 +440,41 @@ def test_gpu_spd16_cooperative_backward_against_one_lane_per_pair():
     assert torch.isnan(out[3]) and float(rows[3].abs().max()) == 0.0 and float(rows[130 + 3].abs().max()) == 0.0
     with pytest.raises(IndexError):
         ops.check_status(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 6, 11, 16])
+def test_gpu_spd_loss_backward_in_kernel_scatter(n):
+    """sympa_spd_loss_backward (loss + backward + scatter in one launch) == sympa_spd_backward_rows followed by
+    sympa_scatter_add_flat_rows: small batch (single-round kernel) and a ragged batch above 8192 pairs (two-rounds kernel),
+    repeated rows (atomic accumulation), scale gradient, loss, out; an out-of-range index is skipped and flagged."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(600 + n)
+    rows_n = 70
+    table = spd_points(rows_n, n, 0.3, g).to(dev)
+    sc = torch.tensor([1.7], dtype=torch.float64, device=dev)
+    for b in (333, 8203):
+        trip = torch.stack((torch.randint(0, rows_n, (b,), generator=g), torch.randint(0, rows_n, (b,), generator=g)), 1).to(dev)
+        gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+        loss1 = torch.zeros(1, dtype=torch.float64, device=dev); gs1 = torch.zeros(1, dtype=torch.float64, device=dev)
+        gt1 = torch.zeros_like(table)
+        out1 = ops.spd_loss_backward(table, trip, gt1, graph_dist=gd, scale=sc, loss_scale=0.5, loss=loss1, grad_scale=gs1, want_out=True)
+        loss2 = torch.zeros(1, dtype=torch.float64, device=dev); gs2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        rows, out2 = ops.spd_backward_rows(table, table, trip, graph_dist=gd, scale=sc, loss_scale=0.5, loss=loss2, grad_scale=gs2,
+                                           want_out=True)
+        gt2 = torch.zeros_like(table)
+        ops.scatter_add_flat_rows_(gt2, rows.reshape(2 * b, -1), torch.cat((trip[:, 0], trip[:, 1])))
+        ops.check_status(dev)
+        assert rel_err(gt1.cpu(), gt2.cpu(), atol=1e-13) < 1e-10
+        assert rel_err(out1.cpu(), out2.cpu()) < 1e-13
+        assert abs(float(loss1) - float(loss2)) < 1e-11 * abs(float(loss2)) and abs(float(gs1) - float(gs2)) < 1e-10 * abs(float(gs2))
+    trip[4, 0] = rows_n
+    gt3 = torch.zeros_like(table)
+    out3 = ops.spd_loss_backward(table, trip, gt3, graph_dist=gd, want_out=True)
+    assert torch.isnan(out3[4])
+    with pytest.raises(IndexError):
+        ops.check_status(dev)
+    with pytest.raises(Exception):
+        ops.spd_loss_backward(spd_points(5, 2, 0.3, g).to(dev), trip[:3] % 5, torch.zeros(5, 2, 2, dtype=torch.float64, device=dev),
+                              graph_dist=gd[:3])                       # n = 2: rows + scatter is the path

@@ -57,7 +57,7 @@ if "--train" in sys.argv:
         m.fused_loss_backward(trip[:bt], gd)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print(f"spd n={n} fused loss+backward (rows + scatter) b={bt}: {dt * 1e3:.2f} ms  {bt / dt / 1e6:.2f} M pairs/s")
+    print(f"spd n={n} fused loss+backward+scatter (Model.fused_loss_backward) b={bt}: {dt * 1e3:.2f} ms  {bt / dt / 1e6:.2f} M pairs/s")
     grad = m.embeddings.embeds.grad
     for _ in range(2):
         ops.spd_rsgd_step_(m.embeddings.embeds.data, grad * 1e-6, 1e-3)
