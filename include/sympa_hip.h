@@ -67,7 +67,9 @@ extern "C" {
 #define SYMPA_MAX_FUSED_BATCHES 32
 #define SYMPA_FLAG_COOP 32 /* A/B switch of the sixteen-lanes-per-pair layout (DESIGN.md sections 5, 8, 12):
                               forward, dims 6 and 8: run it instead of the one-pair-per-lane kernel (2-2.5x slower there);
-                              backward (sympa_siegel_dist_bwd, upper, dims 7 and 8, dense rows): likewise (1.3-2x slower);
+                              backward entries, dims 5..8: the eight-lanes-per-pair kernels (two pairs per DPP row; the default
+                              where measured faster: the fused step at n = 8, bounded n = 8 rows, bounded n = 7 fused);
+                              SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels there;
                               sympa_spd_backward_rows: the single-round kernel instead of the one that runs the QL of two
                               rounds together */
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */

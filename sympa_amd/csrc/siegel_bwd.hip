@@ -11,9 +11,15 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     if ((a.go == nullptr && a.graph_dist == nullptr) || a.g1 == nullptr || a.g2 == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "null gradient buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // A/B of the sixteen-lanes layout below its range (measured slower: DESIGN.md section 8)
-    if ((a.f.flags & SYMPA_FLAG_COOP) && model == SYMPA_MODEL_UPPER && !scatter && (n == 7 || n == 8))
-        return n == 7 ? launch_bwd_coop_upper_7_dense(a, s) : launch_bwd_coop_upper_8_dense(a, s);
+    // Eight lanes per pair (two pairs per DPP row, no scratch) where measured faster than one pair per lane
+    // (tools/bwd_coop_ab_small.py, per 262 144 pairs): the fused step at n = 8 (upper 1.78 -> 1.49 ms, bounded 2.59 -> 1.99 ms),
+    // bounded n = 8 dense rows (2.51 -> 2.15 ms), bounded n = 7 fused (1.70 -> 1.56 ms).  SYMPA_FLAG_COOP forces it for
+    // dims 5..8, SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels.
+    if (n >= 5 && n <= 8 && !(a.f.flags & SYMPA_FLAG_GENERIC)) {
+        const bool bounded = model == SYMPA_MODEL_BOUNDED;
+        const bool faster = (n == 8 && (scatter || bounded)) || (n == 7 && bounded && scatter);
+        if (faster || (a.f.flags & SYMPA_FLAG_COOP)) return launch_bwd_half(a, n, model, scatter, s);
+    }
     switch (n) {
         case 1: return launch_bwd_n<1>(a, model, scatter, s);
         case 2: return launch_bwd_n<2>(a, model, scatter, s);

@@ -1,0 +1,8 @@
+// Siegel backward, EIGHT lanes per pair (two pairs per DPP row: SYMPA_COOP_HALF, spd_coop.hpp): bounded model, M = 6,
+// dense output.  One kernel per translation unit (the build's DPP hazard check works per unit).
+#define SYMPA_COOP_HALF
+#include "siegel_coop_bwd_kernel.hpp"
+
+namespace sympa_hip {
+int launch_bwd_half_bounded_6_dense(const BwdArgs& a, hipStream_t s) { return launch_coop_bwd_ms<sympa::MODEL_BOUNDED, 6, false>(a, s); }
+}  // namespace sympa_hip

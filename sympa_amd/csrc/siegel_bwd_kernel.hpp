@@ -254,6 +254,9 @@ SYMPA_BWD_LARGE(8, upper)
 SYMPA_BWD_LARGE(8, bounded)
 #undef SYMPA_BWD_LARGE
 
+// dims 5..8 with eight lanes per pair (siegel_bwd_half*.hip; A/B and, where faster, the default)
+int launch_bwd_half(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
+
 // dims 9..16: siegel_bwd_rolled.hip (the same adjoint with rolled loops over scratch arrays)
 int launch_bwd_rolled(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
 

@@ -16,8 +16,11 @@ namespace sympa_hip {
 // Waves per SIMD (measured per 65 536 pairs, one 512-register wave against two 256-register waves that spill 300-1300
 // registers): upper n = 10 836 / 953 us, n = 16 2489 / 3015 us -> one wave;  bounded n = 10 1469 / 1285 us, n = 16
 // 4558 / 4036 us -> two waves (its tail of complex solves and products has the longer dependent chains to hide).
+#ifndef SYMPA_COOP_BWD_WAVES_UPPER
+#define SYMPA_COOP_BWD_WAVES_UPPER 1
+#endif
 template <int MODEL>
-constexpr int coop_bwd_waves() { return MODEL == sympa::MODEL_UPPER ? 1 : 2; }
+constexpr int coop_bwd_waves() { return MODEL == sympa::MODEL_UPPER ? SYMPA_COOP_BWD_WAVES_UPPER : 2; }
 
 template <int MODEL, int M, bool SCATTER>
 __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_kernel(const BwdArgs a, const int rounds) {
@@ -27,10 +30,10 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
     using spd_coop::solve_right_l;
     using spd_coop::solve_right_lt;
     using spd_coop::transpose_rows;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[spd_coop::GROUPS_PER_WAVE * N * N];
     const DistArgs& f = a.f;
     const int lane = threadIdx.x;
-    const int g = lane >> 4, r = lane & 15;
+    const int g = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
     double* const tbuf = tbuf_all + g * N * N;
     constexpr int nn = M * M;
     constexpr int64_t ROW = 2 * nn;
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
     for (int k = 0; k < M; ++k) gw_acc[k] = 0.0;
 
     for (int t = 0; t < rounds; ++t) {
-        const int64_t first = ((int64_t)blockIdx.x * rounds + t) * 4;
+        const int64_t first = ((int64_t)blockIdx.x * rounds + t) * spd_coop::GROUPS_PER_WAVE;
         if (first >= f.b) break;                                      // wave-uniform
         const int64_t i = first + g;                                  // my group's pair in this round
         const bool live = i < f.b;
@@ -325,8 +328,9 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
 
 template <int MODEL, int M, bool SCATTER>
 int launch_coop_bwd_ms(const BwdArgs& a, hipStream_t s) {
-    const int rounds = spd_coop::coop_rounds(a.f.b, coop_bwd_waves<MODEL>());
-    const dim3 grid((unsigned)((a.f.b + 4 * rounds - 1) / (4 * rounds)));
+    constexpr int PPR = spd_coop::GROUPS_PER_WAVE;               // pairs per wave and round
+    const int rounds = spd_coop::coop_rounds(a.f.b, coop_bwd_waves<MODEL>(), PPR);
+    const dim3 grid((unsigned)((a.f.b + PPR * rounds - 1) / (PPR * rounds)));
     hipLaunchKernelGGL((siegel_coop_bwd_kernel<MODEL, M, SCATTER>), grid, dim3(64), 0, s, a, rounds);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -335,8 +339,6 @@ int launch_coop_bwd_ms(const BwdArgs& a, hipStream_t s) {
 
 // n = 9..16, both models (siegel_bwd_coop_<model>_<n>_{dense,scatter}.hip: one kernel per translation unit; siegel_bwd_coop.hip)
 int launch_bwd_coop(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
-int launch_bwd_coop_upper_7_dense(const BwdArgs& a, hipStream_t s);      // A/B only (SYMPA_FLAG_COOP)
-int launch_bwd_coop_upper_8_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_9_dense(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_9_scatter(const BwdArgs& a, hipStream_t s);
 int launch_bwd_coop_upper_10_dense(const BwdArgs& a, hipStream_t s);

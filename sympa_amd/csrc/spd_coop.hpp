@@ -31,6 +31,18 @@ namespace spd_coop {
 constexpr int N = 16;                            // lanes per pair (a DPP row); matrices are M x M, M <= N
 constexpr int ROUNDS = 16;                       // 4 pairs per round, 64 pairs per wave
 
+// Lanes per pair.  Default: a whole DPP row of sixteen.  A translation unit that defines SYMPA_COOP_HALF before including
+// this header gets GROUPS OF EIGHT -- two pairs per DPP row, eight per wave and step, for matrices with M <= 8: every
+// per-lane instruction (the scalar recurrences, the square roots, the reductions' arithmetic) then serves eight pairs
+// instead of four with four of them phantoms, and only the DPP instructions are issued twice, once per half of the row
+// with the other half masked off (bank_mask) and the broadcast lane offset by eight.
+#ifdef SYMPA_COOP_HALF
+constexpr int GROUP = 8;
+#else
+constexpr int GROUP = 16;
+#endif
+constexpr int GROUPS_PER_WAVE = 64 / GROUP;
+
 // Rounds per wave for the kernels whose waves are independent of each other's pairs (backward, table rows): one wave
 // per SIMD is resident (512 registers), so up to 1024 x 4 pairs run at once -- spread a small batch over all SIMDs.
 inline int coop_rounds(const long long b, const int waves_per_simd = 1, const int pairs_per_round = 4) {
@@ -71,7 +83,18 @@ __device__ __forceinline__ void sfor(F&& f) {
 // value of lane J of my group of 16 lanes
 template <int J>
 __device__ __forceinline__ double bcast(const double v) {
+#ifdef SYMPA_COOP_HALF
+    static_assert(J < 8, "half groups: lanes 0..7");
+    // Two bank-masked movs, written as asm: the pair of 64-bit __builtin_amdgcn_update_dpp calls with bank masks compiled to
+    // movs that read the WRONG source register after an inline-asm producer (tools/microbench/half_group_check.hip: the
+    // Cholesky pivots came from a stale register).  The wait states for the source travel inside the statement.
+    double res;
+    SYMPA_COOP_ASM("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\ts_nop 1\n\t"
+                   "v_mov_b64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xc bound_ctrl:1" : "=&v"(res) : "v"(v), "n"(J), "n"(J + 8));
+    return res;
+#else
     return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, true));
+#endif
 }
 
 // acc += x(lane J of my group) * y  /  acc -= ...   in one DP-ALU DPP instruction.
@@ -86,7 +109,7 @@ __device__ __forceinline__ double bcast(const double v) {
 //     DPP source within two wait states (over all predecessors of a block); __graft_entry__.build() runs it on every
 //     translation unit that includes this header and recompiles a unit that fails with SYMPA_COOP_NOP_IN_ASM, which
 //     carries the two wait states inside every asm statement (always safe; measured 15-60 % slower, so not the default).
-#ifdef SYMPA_COOP_NOP_IN_ASM
+#if defined(SYMPA_COOP_NOP_IN_ASM) || defined(SYMPA_COOP_HALF)      // half groups: accumulators are read as "old" values too
 #define SYMPA_COOP_NOP "s_nop 1\n\t"
 #else
 #define SYMPA_COOP_NOP ""
@@ -95,6 +118,22 @@ __device__ __forceinline__ double settle(double v) {
     SYMPA_COOP_ASM_SETTLE("s_nop 1" : "+v"(v));
     return v;
 }
+#ifdef SYMPA_COOP_HALF
+template <int J>
+__device__ __forceinline__ void fmac_bc(double& acc, const double x, const double y) {
+    // The two instructions write the same register under complementary bank masks.  They must NOT be back to back: the
+    // second one re-writes the lanes it has masked off with the value the register had BEFORE the first one (measured,
+    // tools/microbench/dpp_bank_mask.hip: lanes 0-7 lose their update) -- the "old" value of a masked lane is read like a
+    // DPP source, two wait states after a VALU write.
+    SYMPA_COOP_ASM(SYMPA_COOP_NOP "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\ts_nop 1\n\t"
+                   "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xc" : "+v"(acc) : "v"(x), "v"(y), "n"(J), "n"(J + 8));
+}
+template <int J>
+__device__ __forceinline__ void fnmac_bc(double& acc, const double x, const double y) {
+    SYMPA_COOP_ASM(SYMPA_COOP_NOP "v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\ts_nop 1\n\t"
+                   "v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xc" : "+v"(acc) : "v"(x), "v"(y), "n"(J), "n"(J + 8));
+}
+#else
 template <int J>
 __device__ __forceinline__ void fmac_bc(double& acc, const double x, const double y) {
     SYMPA_COOP_ASM(SYMPA_COOP_NOP "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
@@ -103,6 +142,7 @@ template <int J>
 __device__ __forceinline__ void fnmac_bc(double& acc, const double x, const double y) {
     SYMPA_COOP_ASM(SYMPA_COOP_NOP "v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
 }
+#endif
 
 // sum over the 16 lanes of my group, result in every lane (32-bit DPP rotations: the DP ALU has no row_ror).
 // The result is BITWISE the same in the sixteen lanes: rotations by 8, 4, 2, 1 add the same two numbers in both lanes of
@@ -118,7 +158,13 @@ __device__ __forceinline__ double group_sum(double v) {
         const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);    \
         v += __hiloint2double(hi, lo);                                                              \
     }
+#ifdef SYMPA_COOP_HALF
+    // eight lanes: exchange inside the quads (quad_perm [1,0,3,2], then [2,3,0,1]), then with the other quad of my half
+    // (row_half_mirror: lane i <-> 7 - i; every lane of a quad holds the quad's sum by then) -- bitwise uniform as above
+    SPD_COOP_ROR(0xB1) SPD_COOP_ROR(0x4E) SPD_COOP_ROR(0x141)
+#else
     SPD_COOP_ROR(0x128) SPD_COOP_ROR(0x124) SPD_COOP_ROR(0x122) SPD_COOP_ROR(0x121)
+#endif
 #undef SPD_COOP_ROR
     return v;
 }
@@ -219,10 +265,10 @@ __device__ __forceinline__ void scatter_plane(const double (&v)[M], double* __re
     wave_lds_fence();
     if (r < M) sfor<0, M>([&](auto J) { tile[r * M + J] = v[J]; });
     wave_lds_fence();
-    constexpr int CHUNKS = (M * M + 15) / 16;
+    constexpr int CHUNKS = (M * M + GROUP - 1) / GROUP;
     sfor<0, CHUNKS>([&](auto K) {
         constexpr int k = K;
-        const int idx = k * 16 + r;
+        const int idx = k * GROUP + r;
         const double val = (idx < M * M) ? tile[idx] : 0.0;
         if (on && val != 0.0) atomicAdd(dst + idx, val);
     });

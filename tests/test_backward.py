@@ -435,3 +435,58 @@ def test_gpu_cooperative_backward_nonfinite_and_degenerate_inputs(dev, model):
     with pytest.raises(AssertionError):
         ops.check_status(dev)
     assert torch.isnan(loss).all()                                   # a NaN pair poisons the loss, as in the reference
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_eight_lanes_backward_against_one_pair_per_lane(dev, model, n):
+    """dims 5..8: the eight-lanes-per-pair backward (two pairs per DPP row, SYMPA_FLAG_COOP; the default for the n = 8 fused
+    step) against the one-pair-per-lane kernels (SYMPA_FLAG_GENERIC): every metric, ragged batch, dense rows, rows with
+    the fused loss, in-kernel scatter with scale gradient, out-of-range index, the reference-autograd goldens."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(2900 + n + (50 if model == "bounded" else 0))
+    for b in ((4099, 70001) if n == 8 else (4099,)):
+        z1, z2 = points(model, b, n, 0.3, g).to(dev), points(model, b, n, 0.3, g).to(dev)
+        go = (torch.rand(b, generator=g, dtype=torch.float64) + 0.5).to(dev)
+        w = torch.linspace(-0.3, 1.2, n, dtype=torch.float64)
+        for metric in (("riem", "fone", "finf", "fmin", "wsum") if b == 4099 else ("riem",)):
+            ref = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w, flags=ops.FLAG_GENERIC)
+            got = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w, flags=ops.FLAG_COOP)
+            ops.check_status(dev)
+            for k in (0, 1):
+                scale = ref[k].abs().reshape(b, -1).max(1).values.clamp_min(1e-300)
+                err = (got[k] - ref[k]).abs().reshape(b, -1).max(1).values / scale
+                # the two kernels take their eigenvectors by different routes; near-degenerate pairs differ by their conditioning
+                assert float(err.quantile(0.99)) < 1e-9 and float(err.max()) < 1e-5, (n, b, metric, k, float(err.max()))
+            if metric == "wsum":
+                assert relmax(got[2].cpu(), ref[2].cpu()) < 1e-10
+    rows_n = 300
+    table = points(model, rows_n, n, 0.3, g).to(dev)
+    b = 1203
+    trip = torch.stack((torch.randint(0, rows_n, (b,), generator=g), torch.randint(0, rows_n, (b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    sc = torch.tensor([1.7], dtype=torch.float64, device=dev)
+    res = []
+    for fl in (ops.FLAG_COOP, ops.FLAG_GENERIC):
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        gt = torch.zeros_like(table)
+        ops.model_loss_backward(table, trip, gd, gt, loss, model=model, scale=sc, grad_scale=gs, loss_scale=0.5, flags=fl)
+        rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+        loss2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward_rows(table, trip, gd, rows, loss2, model=model, scale=sc, loss_scale=0.5, flags=fl)
+        gt2 = torch.zeros_like(table)
+        ops.scatter_add_rows_(gt2, rows, torch.cat((trip[:, 0], trip[:, 1])))
+        res.append((gt.cpu(), float(loss), float(gs), gt2.cpu(), float(loss2)))
+    ops.check_status(dev)
+    assert relmax(res[0][0], res[1][0]) < 1e-9 and relmax(res[0][3], res[1][3]) < 1e-9
+    assert relmax(res[0][0], res[0][3]) < 1e-12
+    assert abs(res[0][1] - res[1][1]) < 1e-11 * abs(res[1][1]) and abs(res[0][4] - res[1][4]) < 1e-11 * abs(res[1][4])
+    assert abs(res[0][2] - res[1][2]) < 1e-9 * abs(res[1][2])
+    trip[5, 1] = rows_n
+    rows = torch.full((2 * b, 2, n, n), 7.0, dtype=torch.float64, device=dev)
+    ops.model_loss_backward_rows(table, trip, gd, rows, torch.zeros(1, dtype=torch.float64, device=dev), model=model, flags=ops.FLAG_COOP)
+    assert float(rows[5].abs().max()) == 0.0 and float(rows[b + 5].abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        ops.check_status(dev)

@@ -221,3 +221,8 @@ def test_dpp_hazard_checker_flags_a_copy_in_front_of_a_dpp_read():
     body = ["v_mov_b64_e32 v[30:31], v[26:27]", "s_cbranch_execz .LBB0_2", ".LBB0_1:", "s_nop 3", ".LBB0_2:", dpp]
     assert len(scan(body)[1]) == 1
     assert scan(["v_cmpx_lt_f64_e32 v[0:1], v[2:3]"])[1] != []
+    # partial bank mask: the destination's old value is a DPP read too (two complementary masked writes back to back)
+    half_a = "v_fmac_f64_dpp v[8:9], -v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0x3"
+    half_b = "v_fmac_f64_dpp v[8:9], -v[2:3], v[4:5] row_newbcast:11 row_mask:0xf bank_mask:0xc"
+    assert len(scan(["s_nop 1", half_a, half_b])[1]) == 1
+    assert scan(["s_nop 1", half_a, "s_nop 1", half_b])[1] == []

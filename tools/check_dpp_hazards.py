@@ -2,7 +2,8 @@
 """Static check of the gfx950 ISA for the hazard the compiler cannot see in inline asm (sympa_amd/csrc/spd_coop.hpp):
 a VGPR that a DPP instruction reads as its DPP source (src0) must not be written by a VALU instruction in the two
 preceding wait states.  Walks every kernel of an assembly file (hipcc -S --cuda-device-only, or the .s that
---save-temps leaves), over ALL predecessors of a basic block.  Also flags v_cmpx (a VALU write of EXEC needs five wait
+--save-temps leaves), over ALL predecessors of a basic block.  A DPP instruction with a partial row_mask / bank_mask also reads its DESTINATION (the lanes it masks off keep the old value)
+under the same rule.  Also flags v_cmpx (a VALU write of EXEC needs five wait
 states before a DPP instruction; gfx950 code normally has none).
 
     python tools/check_dpp_hazards.py file.s [...]        exit code 1 when a hazard is found
@@ -100,6 +101,11 @@ def check_kernel(name, text):
                 ndpp += 1
                 ops = l.split(None, 1)[1].split(",")
                 src = vregs(ops[1].split()[0])
+                # a lane masked off by row_mask / bank_mask keeps the OLD value of the destination, and that value is read
+                # like a DPP source (measured: tools/microbench/dpp_bank_mask.hip) -- the destination counts as a source then
+                m = re.search(r"row_mask:(0x[0-9a-fA-F]+)\s+bank_mask:(0x[0-9a-fA-F]+)", l)
+                if m and (int(m.group(1), 16) != 0xf or int(m.group(2), 16) != 0xf):
+                    src = src | vregs(ops[0])
                 walk(b, i, src, 0, set(), l)
     return ndpp, found
 
