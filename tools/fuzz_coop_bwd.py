@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the sixteen-lanes-per-pair TRAINING kernels (backward of both Siegel models at dims 9..16, spd backward at
+"""Soak test of the sixteen-lanes-per-pair TRAINING kernels (backward of both Siegel models at dims 5..16 -- eight lanes per pair up to 8, sixteen above --, spd backward at
 n = 3..16, the row operations of the optimisers): random dims, batch sizes, scales and metrics, some pairs made identical
 or diagonal, every result compared with the one-lane-per-pair kernels (FLAG_GENERIC / SYMPA_*_GENERIC are the same
 arithmetic over scratch).   python tools/fuzz_coop_bwd.py [seconds]"""
@@ -47,7 +47,7 @@ while time.time() - t0 < budget:
         lim_out = 1e-9
     else:
         kind = "siegel"
-        n = int(torch.randint(9, 17, (1,), generator=g))
+        n = int(torch.randint(5, 17, (1,), generator=g))       # 5..8: eight lanes per pair (SYMPA_FLAG_COOP), 9..16: sixteen
         model = "upper" if torch.rand(1, generator=g) < 0.5 else "bounded"
         metric = ("riem", "fone", "finf", "fmin", "wsum")[int(torch.randint(0, 5, (1,), generator=g))]
         s = min(s, 0.4)
@@ -56,7 +56,7 @@ while time.time() - t0 < budget:
         if b > 3:
             z2[1] = z1[1]
         z1, z2 = z1.to(dev), z2.to(dev)
-        a = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w)
+        a = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w, flags=ops.FLAG_COOP if n <= 8 else 0)
         c = ops.siegel_dist_backward(z1, z2, go, model=model, metric=metric, weights=w, flags=ops.FLAG_GENERIC)
         err = torch.cat((rowerr(a[0], c[0], b), rowerr(a[1], c[1], b)))
         oerr = 0.0
