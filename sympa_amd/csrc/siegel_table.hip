@@ -50,6 +50,20 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
     if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
     if (b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "too many rows for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool generic = std::getenv("SYMPA_TABLE_GENERIC") != nullptr;      // one-row-per-lane kernels for A/B
+    if ((n == 7 || n == 8) && (op == 1 || op == 2) && !generic) {
+        // eight lanes per row; same scheme as dims 9..16 below (interior test by Cholesky, exact projx gated on the count)
+        static int* outside8 = nullptr;
+        if (outside8 == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&outside8), HIP_SYMBOL(g_rows_outside)) != hipSuccess)
+            return fail(SYMPA_ERR_BAD_ARG, "no device symbol for the interior test");
+        if (op == 1 && hipMemsetAsync(outside8, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "memset failed");
+        const int rc = model == SYMPA_MODEL_UPPER
+                           ? launch_table_half_upper(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside8, s)
+                           : launch_table_half_bounded(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside8, s);
+        if (rc != 0 || op == 2) return rc;
+        return n == 7 ? launch_table<7>(0, model, z, nullptr, z, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside8)
+                      : launch_table<8>(0, model, z, nullptr, z, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside8);
+    }
     switch (n) {
         case 1: return launch_table<1>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
         case 2: return launch_table<2>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
@@ -63,7 +77,6 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
     }
     if (n > 8 && n <= SYMPA_MAX_DIMS_GENERIC) {
         // SYMPA_TABLE_GENERIC=1 keeps the one-row-per-lane kernels for A/B measurements (tools/table_time.py)
-        static const bool generic = std::getenv("SYMPA_TABLE_GENERIC") != nullptr;
         if ((op == 1 || op == 2) && !generic) {
             // sixteen lanes per row; the step counts the rows that left the eps-interior in a device word and the exact
             // one-row-per-lane projx runs gated on it (siegel_coop_table.hpp)

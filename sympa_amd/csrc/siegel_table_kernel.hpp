@@ -112,5 +112,10 @@ int launch_table_coop_upper(int op, int n, double* z, const double* g, double* o
                             const double* clip, double max_norm, int* outside, hipStream_t s);
 int launch_table_coop_bounded(int op, int n, double* z, const double* g, double* out, int64_t b, double lr, double wd, double eps,
                               const double* clip, double max_norm, int* outside, hipStream_t s);
+// n = 7, 8 with eight lanes per row (siegel_table_half_{upper,bounded}.hip)
+int launch_table_half_upper(int op, int n, double* z, const double* g, double* out, int64_t b, double lr, double wd, double eps,
+                            const double* clip, double max_norm, int* outside, hipStream_t s);
+int launch_table_half_bounded(int op, int n, double* z, const double* g, double* out, int64_t b, double lr, double wd, double eps,
+                              const double* clip, double max_norm, int* outside, hipStream_t s);
 
 }  // namespace sympa_hip

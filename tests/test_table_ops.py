@@ -206,7 +206,7 @@ def test_gpu_tangent_norm_and_riemannian_adam(dev, model, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", list(range(9, 17)))      # every instance of the sixteen-lanes row kernels
+@pytest.mark.parametrize("n", list(range(7, 17)))      # every instance of the eight- (7, 8) and sixteen-lanes (9..16) row kernels
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_table_operations_dims_9_to_16(dev, model, n):
     """dims 9..16: the same row arithmetic as dims <= 8 compiled with rolled loops (siegel_table_rolled.hip) -- egrad2rgrad,
