@@ -199,6 +199,9 @@ int sympa_all_pairs_dist_packed(const double* table, int64_t num_rows, int n, in
         case 2: return launch_allpairs_n<2>(table, num_rows, a, pack, model, s);
         case 3: return launch_allpairs_n<3>(table, num_rows, a, pack, model, s);
         case 4: return launch_allpairs_n<4>(table, num_rows, a, pack, model, s);
+        case 5: return launch_allpairs_n<5>(table, num_rows, a, pack, model, s);
+        case 6: return launch_allpairs_n<6>(table, num_rows, a, pack, model, s);
+        case 7: return launch_allpairs_n<7>(table, num_rows, a, pack, model, s);
         default: break;
     }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed all-pairs kernel: unsupported dims");

@@ -455,7 +455,7 @@ def test_integration_md_stub_runs_on_the_gpu(dev):
             assert torch.equal(z1.grad, y1.grad) and torch.equal(z2.grad, y2.grad)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("model", MODELS)
 def test_all_pairs_packed_kernel(dev, model, n):
     """sympa_all_pairs_dist_packed (every point factored once, inverted factor, wave-uniform row point, symmetric full
@@ -473,14 +473,15 @@ def test_all_pairs_packed_kernel(dev, model, n):
         if n >= 3:
             assert torch.equal(full, full.T)                 # symmetric mode: d(i, j) evaluated once, stored twice
             both = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, packed=True, flags=ops.FLAG_NO_SYMMETRY)
-            assert rel_err(both.cpu(), ref.cpu()) < 1e-11 and torch.all(both.diagonal() == 0)
+            assert rel_err(both.cpu(), ref.cpu()) < (1e-11 if n <= 4 else 1e-10) and torch.all(both.diagonal() == 0)
         # symmetric mode stores d(i, j) also at (j, i), where the pairwise kernel evaluates d(j, i): two runs of the
         # Jacobi iteration on different matrices with the same spectrum (measured agreement ~3e-11 at n = 4)
         assert rel_err(full.cpu(), ref.cpu()) < (2e-10 if n >= 3 else 1e-11), (model, n, metric)
+        blk_tol = 1e-11 if n <= 4 else 1e-10          # n >= 5: the lockstep QL makes the last bits depend on which pairs share a wave
         for rb, rc in ((0, 1), (5, 64), (63, 66), (100, 233), (332, 1)):
             blk = ops.all_pairs_dist(table, model, metric, w, scale, 2.0, row_begin=rb, row_count=rc, packed=True)
             assert blk.shape == (rc, N)
-            assert rel_err(blk.cpu(), ref[rb:rb + rc].cpu()) < 1e-11, (model, n, metric, rb, rc)
+            assert rel_err(blk.cpu(), ref[rb:rb + rc].cpu()) < blk_tol, (model, n, metric, rb, rc)
     ii, jj = torch.meshgrid(torch.arange(40), torch.arange(N), indexing="ij")
     want = so.model_forward(table.cpu(), torch.stack((ii.reshape(-1), jj.reshape(-1)), 1), model, "riem",
                             scale=scale.cpu(), scale_coef=2.0).reshape(40, N)

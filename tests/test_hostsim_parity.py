@@ -114,7 +114,7 @@ def test_nonfinite_input_generic_large_n(n):
             assert np.isnan(out[0]) and (st & 2)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("model", MODELS)
 def test_packed_point_path_of_the_all_pairs_kernel(model, n):
     """All-pairs matrix (runner.py:142-154): points are packed once with their INVERTED Cholesky factor and a pair costs
