@@ -1,5 +1,5 @@
 // Upper-half / bounded models, optimiser-side row operations for 9 <= n <= 16 with sixteen lanes per table row (layout and
-// DPP machinery of spd_coop.hpp): egrad2rgrad and the RiemannianSGD step.  The one-row-per-lane kernels of these dims
+// DPP machinery of spd_coop.hpp): egrad2rgrad, the RiemannianSGD step, projx and the squared tangent norm (inner).  The one-row-per-lane kernels of these dims
 // (siegel_table_rolled.hip, per-lane scratch) take 2.4 ms (n = 10) to 10-19 ms (n = 16) per step over 5 041 rows --
 // more than the backward of a 65 536-pair batch.
 //   upper  : egrad2rgrad = Y G Y on both planes (four real row-broadcast products)          upper_half.py:25-40
@@ -45,17 +45,59 @@ __global__ __launch_bounds__(64) void siegel_coop_table_kernel(double* __restric
         const int64_t ii = live ? i : b - 1;
         const int rr = r < M ? r : 0;                            // a phantom lane reads row 0
         const double* pz = z + ii * ROW + rr * M;
-        const double* pg = grad + ii * ROW + rr * M;
         double zr[M], zi[M], gr[M], gi[M];
 #pragma unroll
-        for (int j = 0; j < M; ++j) { zr[j] = pz[j]; zi[j] = pz[nn + j]; gr[j] = pg[j]; gi[j] = pg[nn + j]; }
+        for (int j = 0; j < M; ++j) { zr[j] = pz[j]; zi[j] = pz[nn + j]; }
+        if constexpr (OP != spd_coop::OP_PROJX) {
+            const double* pg = grad + ii * ROW + rr * M;
+#pragma unroll
+            for (int j = 0; j < M; ++j) { gr[j] = pg[j]; gi[j] = pg[nn + j]; }
+        }
+        if constexpr (OP == spd_coop::OP_SQNORM) {
+            // inner(z, u, u) = Re tr[Q conj(Q)] = sum_ij (Re q_ij Re q_ji + Im q_ij Im q_ji)   (siegel_table_math.hpp)
+            //   upper: Q = L^-1 u L^-T, Y = L L^T;   bounded: Q = C^-1 conj(u) C^-T, I - Z Z^H = C C^H
+            double qr[M], qi[M], tr[M], ti[M];
+            bool pd;
+            if constexpr (UPPER) {
+                double l[M], rd[M];
+#pragma unroll
+                for (int j = 0; j < M; ++j) l[j] = zi[j];
+                pd = spd_coop::cholesky_rows(l, rd);
+                spd_coop::solve_right_lt2(gr, gi, l, rd);                 // u L^-T
+                transpose_rows(gr, qr, tbuf, r);
+                transpose_rows(gi, qi, tbuf, r);
+                spd_coop::solve_right_lt2(qr, qi, l, rd);                 // rows of (L^-1 u L^-T)^T
+            } else {
+                double cr[M], ci[M], rd[M];
+                id_minus_wwh_rows(zr, zi, cr, ci, r);
+                pd = ccholesky_rows(cr, ci, rd);
+#pragma unroll
+                for (int j = 0; j < M; ++j) gi[j] = -gi[j];               // conj(u)
+                csolve_right_lt(gr, gi, cr, ci, rd);
+                transpose_rows(gr, qr, tbuf, r);
+                transpose_rows(gi, qi, tbuf, r);
+                csolve_right_lt(qr, qi, cr, ci, rd);                      // rows of Q^T
+            }
+            transpose_rows(qr, tr, tbuf, r);
+            transpose_rows(qi, ti, tbuf, r);
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc = sympa::d_fma(qr[j], tr[j], sympa::d_fma(qi[j], ti[j], acc));
+            acc = group_sum((r < M) ? acc : 0.0);
+            if (live && r == 0) out[i] = acc;
+            if (live && !pd && r == 0) ++nout;                            // reported as "not positive definite" by the host side
+            continue;
+        }
+
         if constexpr (OP == spd_coop::OP_RSGD) {
 #pragma unroll
             for (int j = 0; j < M; ++j) { gr[j] = sympa::d_fma(wd, zr[j], coef * gr[j]); gi[j] = sympa::d_fma(wd, zi[j], coef * gi[j]); }
         }
         // (rr, ri) = my row of egrad2rgrad(z, g)
         double rgr[M], rgi[M];
-        if constexpr (UPPER) {
+        if constexpr (OP == spd_coop::OP_PROJX) {
+            // nothing to add: projx(z) alone
+        } else if constexpr (UPPER) {
             double y[M], tt[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) y[j] = zi[j];
@@ -85,8 +127,10 @@ __global__ __launch_bounds__(64) void siegel_coop_table_kernel(double* __restric
         } else {
             // x + u, symmetrised through the transpose
             double tr[M], ti[M];
+            if constexpr (OP == spd_coop::OP_RSGD) {
 #pragma unroll
-            for (int j = 0; j < M; ++j) { zr[j] = sympa::d_fma(-lr, rgr[j], zr[j]); zi[j] = sympa::d_fma(-lr, rgi[j], zi[j]); }
+                for (int j = 0; j < M; ++j) { zr[j] = sympa::d_fma(-lr, rgr[j], zr[j]); zi[j] = sympa::d_fma(-lr, rgi[j], zi[j]); }
+            }
             transpose_rows(zr, tr, tbuf, r);
             transpose_rows(zi, ti, tbuf, r);
 #pragma unroll
@@ -96,7 +140,7 @@ __global__ __launch_bounds__(64) void siegel_coop_table_kernel(double* __restric
                 zi[j] = (r == j) ? zi[j] : si;
             }
             if (live && r < M) {
-                double* po = z + i * ROW + r * M;
+                double* po = (OP == spd_coop::OP_PROJX ? out : z) + i * ROW + r * M;
 #pragma unroll
                 for (int j = 0; j < M; ++j) { po[j] = zr[j]; po[nn + j] = zi[j]; }
             }
@@ -118,11 +162,18 @@ __global__ __launch_bounds__(64) void siegel_coop_table_kernel(double* __restric
             if (live && !pd && r == 0) ++nout;
         }
     }
-    if constexpr (OP == spd_coop::OP_RSGD) {
-        if (__ballot(nout != 0) != 0ull) {
+    if constexpr (OP != spd_coop::OP_EGRAD2RGRAD) {
+        if (outside != nullptr && __ballot(nout != 0) != 0ull) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) nout += __shfl_xor(nout, off);
-            if (lane == 0) atomicAdd(outside, nout);
+            if (lane == 0) {
+                if constexpr (OP == spd_coop::OP_SQNORM) {       // `outside` is the status pair here: a point off the manifold
+                    atomicOr(&outside[0], sympa::ST_NOT_PD);
+                    atomicAdd(&outside[1], nout);
+                } else {
+                    atomicAdd(outside, nout);                    // rows that left the eps-interior
+                }
+            }
         }
     }
 }

@@ -51,18 +51,29 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
     if (b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "too many rows for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const bool generic = std::getenv("SYMPA_TABLE_GENERIC") != nullptr;      // one-row-per-lane kernels for A/B
-    if ((n == 7 || n == 8) && (op == 1 || op == 2) && !generic) {
-        // eight lanes per row; same scheme as dims 9..16 below (interior test by Cholesky, exact projx gated on the count)
-        static int* outside8 = nullptr;
-        if (outside8 == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&outside8), HIP_SYMBOL(g_rows_outside)) != hipSuccess)
+    if (n >= 7 && n <= SYMPA_MAX_DIMS_GENERIC && !generic) {
+        // Eight (n = 7, 8) or sixteen (n = 9..16) lanes per row (siegel_coop_table.hpp).  egrad2rgrad and the tangent norm
+        // are complete there.  The RSGD step and projx symmetrise, test "inside the eps-interior" by a Cholesky
+        // factorisation and count the rows that fail in a device word; the exact one-row-per-lane projx (the reference's
+        // eigenvalue clamp, which leaves inside rows untouched) then runs gated on that word -- it returns at once in the
+        // usual case of zero.  No host synchronisation, no allocation, capturable in the training hipGraph.
+        static int* outside = nullptr;
+        if (outside == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&outside), HIP_SYMBOL(g_rows_outside)) != hipSuccess)
             return fail(SYMPA_ERR_BAD_ARG, "no device symbol for the interior test");
-        if (op == 1 && hipMemsetAsync(outside8, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "memset failed");
-        const int rc = model == SYMPA_MODEL_UPPER
-                           ? launch_table_half_upper(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside8, s)
-                           : launch_table_half_bounded(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside8, s);
-        if (rc != 0 || op == 2) return rc;
-        return n == 7 ? launch_table<7>(0, model, z, nullptr, z, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside8)
-                      : launch_table<8>(0, model, z, nullptr, z, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside8);
+        const bool gated = (op == 0 || op == 1);
+        if (gated && hipMemsetAsync(outside, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "memset failed");
+        int* word = gated ? outside : (op == 3 ? reinterpret_cast<int*>(status) : nullptr);
+        const bool up = model == SYMPA_MODEL_UPPER;
+        int rc;
+        if (n <= 8) rc = up ? launch_table_half_upper(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, word, s)
+                            : launch_table_half_bounded(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, word, s);
+        else rc = up ? launch_table_coop_upper(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, word, s)
+                     : launch_table_coop_bounded(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, word, s);
+        if (rc != 0 || !gated) return rc;
+        double* target = (op == 0) ? out : z;        // projx wrote sym(z) to out; the step updated z in place
+        if (n == 7) return launch_table<7>(0, model, target, nullptr, target, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside);
+        if (n == 8) return launch_table<8>(0, model, target, nullptr, target, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside);
+        return launch_table_rolled(0, n, model, target, nullptr, target, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside);
     }
     switch (n) {
         case 1: return launch_table<1>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
@@ -75,23 +86,8 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
         case 8: return launch_table<8>(op, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
         default: break;
     }
-    if (n > 8 && n <= SYMPA_MAX_DIMS_GENERIC) {
-        // SYMPA_TABLE_GENERIC=1 keeps the one-row-per-lane kernels for A/B measurements (tools/table_time.py)
-        if ((op == 1 || op == 2) && !generic) {
-            // sixteen lanes per row; the step counts the rows that left the eps-interior in a device word and the exact
-            // one-row-per-lane projx runs gated on it (siegel_coop_table.hpp)
-            static int* outside = nullptr;
-            if (outside == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&outside), HIP_SYMBOL(g_rows_outside)) != hipSuccess)
-                return fail(SYMPA_ERR_BAD_ARG, "no device symbol for the interior test");
-            if (op == 1 && hipMemsetAsync(outside, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "memset failed");
-            const int rc = model == SYMPA_MODEL_UPPER
-                               ? launch_table_coop_upper(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s)
-                               : launch_table_coop_bounded(op, n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
-            if (rc != 0 || op == 2) return rc;
-            return launch_table_rolled(0, n, model, z, nullptr, z, b, 0.0, 0.0, eps, projected, status, s, nullptr, 0.0, outside);
-        }
+    if (n > 8 && n <= SYMPA_MAX_DIMS_GENERIC)
         return launch_table_rolled(op, n, model, z, g, out, b, lr, wd, eps, projected, status, s, clip, max_norm);
-    }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS_GENERIC]");
 }
 

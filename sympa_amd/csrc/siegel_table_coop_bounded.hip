@@ -28,7 +28,11 @@ int launch_op(int n, double* z, const double* g, double* out, int64_t b, double 
 
 int launch_table_coop_bounded(int op, int n, double* z, const double* g, double* out, int64_t b, double lr, double wd, double eps,
                             const double* clip, double max_norm, int* outside, hipStream_t s) {
-    return op == spd_coop::OP_RSGD ? launch_op<spd_coop::OP_RSGD>(n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s)
-                                   : launch_op<spd_coop::OP_EGRAD2RGRAD>(n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
+    switch (op) {
+        case spd_coop::OP_PROJX: return launch_op<spd_coop::OP_PROJX>(n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
+        case spd_coop::OP_RSGD: return launch_op<spd_coop::OP_RSGD>(n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
+        case spd_coop::OP_SQNORM: return launch_op<spd_coop::OP_SQNORM>(n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
+        default: return launch_op<spd_coop::OP_EGRAD2RGRAD>(n, z, g, out, b, lr, wd, eps, clip, max_norm, outside, s);
+    }
 }
 }  // namespace sympa_hip

@@ -13,7 +13,7 @@
 
 namespace spd_coop {
 
-constexpr int OP_RSGD = 1, OP_EGRAD2RGRAD = 2;
+constexpr int OP_PROJX = 0, OP_RSGD = 1, OP_EGRAD2RGRAD = 2, OP_SQNORM = 3;      // the op numbers of siegel_table.hip
 
 // t = a b for the rows held one per lane (b's rows are broadcast)
 template <int M>

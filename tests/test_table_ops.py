@@ -155,7 +155,7 @@ def test_gpu_clip_folded_into_the_step_equals_torch_clip(dev, model, max_norm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 4, 7])
+@pytest.mark.parametrize("n", [2, 4, 7, 8, 11, 16])      # 7, 8: eight lanes per row; 11, 16: sixteen
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_tangent_norm_and_riemannian_adam(dev, model, n):
     """manifold.inner(z, u, u) kernel == the restated upper_half.py:68-91 / bounded_domain.py:86-116, and three steps of
@@ -227,3 +227,23 @@ def test_gpu_table_operations_dims_9_to_16(dev, model, n):
         assert int(cnt) == int((~keep).sum())
     out = ops.projx(table.to(dev), model)
     assert torch.equal(out.cpu(), so.to_symmetric(table))
+    # projx on its own with rows outside the manifold (the gated exact projection) and a non-symmetric input
+    bad = table.clone()
+    bad[3] = table[3] + 0.01 * torch.randn(2, n, n, generator=g, dtype=torch.float64)
+    if model == "upper":
+        bad[7, 1] = -bad[7, 1]
+        bad[20, 1] = bad[20, 1] - 1.5 * torch.eye(n, dtype=torch.float64)
+    else:
+        bad[7] = 3.0 * bad[7]
+        bad[20] = 1.4 * bad[20] / torch.linalg.matrix_norm(torch.complex(bad[20, 0], bad[20, 1]), ord=2)
+    want = (so.upper_projx if model == "upper" else so.bounded_projx)(bad)
+    want = want[0] if isinstance(want, tuple) else want
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    got = ops.projx(bad.to(dev), model, counter=cnt)
+    ops.check_status(dev)
+    assert relmax(got.cpu(), want) < 1e-8 and int(cnt) == 2
+    # squared tangent norm (inner) against the restated reference formula
+    u = torch.randn(50, 2, n, n, generator=g, dtype=torch.float64)
+    inner = so.upper_inner if model == "upper" else so.bounded_inner
+    assert relmax(ops.tangent_sqnorm(table.to(dev), u.to(dev), model).cpu(), inner(table, u)) < 1e-10
+    ops.check_status(dev)
