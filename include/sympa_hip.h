@@ -246,6 +246,10 @@ int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, 
  *     min(1, max_norm / (sqrt(total_sqnorm[0]) + 1e-6))
  * as it is loaded (the gradient buffer itself is left unscaled). */
 int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream);
+/* The plain SGD step of the parameters that live on no manifold (the model's scale: RiemannianSGD on a Euclidean
+ * parameter, geoopt/optim/rsgd.py) with the same folded clip: p <- p - lr * (coef * grad + weight_decay * p). */
+int sympa_sgd_step_clipped(double* p, const double* grad, int64_t count, double lr, double weight_decay,
+                           const double* total_sqnorm, double max_norm, void* stream);
 int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
                             double weight_decay, double eps, const double* total_sqnorm, double max_norm,
                             int32_t* projected_count, int32_t* status, void* stream);

@@ -30,6 +30,7 @@ SYMBOLS = (
     "sympa_projx",
     "sympa_rsgd_step",
     "sympa_sqnorm_accum",
+    "sympa_sgd_step_clipped",
     "sympa_rsgd_step_clipped",
     "sympa_spd_dist_fwd",
     "sympa_spd_model_forward",
@@ -141,6 +142,9 @@ def load():
                                     ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_sqnorm_accum.restype = ctypes.c_int
     lib.sympa_sqnorm_accum.argtypes = [_c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_void_p]
+    lib.sympa_sgd_step_clipped.restype = ctypes.c_int
+    lib.sympa_sgd_step_clipped.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                           _c_double_p, ctypes.c_double, ctypes.c_void_p]
     lib.sympa_rsgd_step_clipped.restype = ctypes.c_int
     lib.sympa_rsgd_step_clipped.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_double_p,

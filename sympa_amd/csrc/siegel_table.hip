@@ -21,6 +21,15 @@ __global__ __launch_bounds__(BLOCK) void sqnorm_kernel(const double* __restrict_
     if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(acc, s);
 }
 
+// p <- p - lr * (coef * grad + wd * p), coef = min(1, max_norm / (sqrt(total_sqnorm) + 1e-6)): the plain SGD step of the
+// parameters that live on no manifold (the model's scale), with the same folded gradient clip as the table step
+__global__ __launch_bounds__(BLOCK) void sgd_step_kernel(double* __restrict__ p, const double* __restrict__ g, int64_t count, double lr,
+                                                         double wd, const double* __restrict__ clip, double max_norm) {
+    const double coef = (clip != nullptr) ? fmin(1.0, max_norm / (sqrt(clip[0]) + 1e-6)) : 1.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * BLOCK)
+        p[i] = fma(-lr, fma(wd, p[i], coef * g[i]), p[i]);
+}
+
 // grad[idx[r]] += alpha * rows[r] for `count` rows of `rowd` doubles: consecutive lanes take consecutive doubles of a
 // row, so one atomic wave-instruction covers 512 contiguous bytes of ONE gradient row (the shape the fp64 atomics run
 // at rate with, profiles/r01_atomic_scope.txt); rows with an index outside [0, num_rows) are skipped and flagged.
@@ -129,6 +138,21 @@ int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream
     const int64_t want = (count + BLOCK - 1) / BLOCK;
     const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
     hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x, count, acc);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int sympa_sgd_step_clipped(double* p, const double* grad, int64_t count, double lr, double weight_decay,
+                           const double* total_sqnorm, double max_norm, void* stream) {
+    if (count < 0) return fail(SYMPA_ERR_BAD_ARG, "negative count");
+    if (count == 0) return 0;
+    if (p == nullptr || grad == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (total_sqnorm != nullptr && !(max_norm > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "max_norm must be > 0");
+    const int64_t want = (count + BLOCK - 1) / BLOCK;
+    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), p, grad, count, lr,
+                       weight_decay, total_sqnorm, max_norm);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

@@ -464,6 +464,21 @@ def projx(z, model, eps=None, counter=None):
     return out
 
 
+def sgd_step_clipped_(param, grad, lr, weight_decay=0.0, clip_sqnorm=None, max_norm=None):
+    """param <- param - lr * (coef * grad + wd * param) in one kernel (C-ABI sympa_sgd_step_clipped): the step of a
+    parameter without a manifold, with the gradient clip folded in like the table step."""
+    lib = _lib.load()
+    _need_gpu(param, "param"); _need_gpu(grad, "grad")
+    if param.dtype != torch.float64 or grad.dtype != torch.float64 or not param.is_contiguous() or not grad.is_contiguous():
+        raise ValueError("param and grad must be contiguous float64 tensors")
+    with torch.cuda.device(param.device):
+        rc = lib.sympa_sgd_step_clipped(param.data_ptr(), grad.data_ptr(), param.numel(), float(lr), float(weight_decay),
+                                        None if clip_sqnorm is None else clip_sqnorm.data_ptr(),
+                                        float(max_norm) if max_norm is not None else 0.0, _stream())
+    _lib.check(rc)
+    return param
+
+
 def sqnorm_accum_(x, acc):
     """acc[0] += sum(x^2)  (C-ABI sympa_sqnorm_accum): the squared total norm of clip_grad_norm_, on the device."""
     lib = _lib.load()

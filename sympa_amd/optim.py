@@ -62,6 +62,11 @@ class RiemannianSGD(torch.optim.Optimizer):
                     # the kernel adds the number of projected rows to a persistent device counter (read lazily by
                     # manifold.projected_points): no allocation, no synchronisation, graph-capturable
                     ops.rsgd_step_(p.data, p.grad, manifold.model_name, lr, wd, counter=manifold.projected_counter(p.device))
+                elif (p.is_cuda and p.dtype == torch.float64 and p.grad.dtype == torch.float64 and p.is_contiguous()
+                      and p.grad.is_contiguous()):
+                    # a parameter without a manifold (the scale): one kernel, clip folded in
+                    ops.sgd_step_clipped_(p.data, p.grad, lr, wd, clip_sqnorm=sq,
+                                          max_norm=self.clip_max_norm if sq is not None else None)
                 else:
                     g = p.grad
                     if sq is not None:

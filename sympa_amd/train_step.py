@@ -25,9 +25,8 @@ class GraphedTrainStep:
 
     def _body(self):
         self.opt.zero_grad(set_to_none=False)
-        loss = self.model.fused_loss_backward(self.ids, self.gd)
+        self.model.fused_loss_backward(self.ids, self.gd, loss_out=self.loss)      # accumulated straight into self.loss
         self._clip_and_step()
-        self.loss.copy_(loss)
 
     def _clip_and_step(self):
         if hasattr(self.opt, "clip_max_norm"):       # sympa_amd.optim.RiemannianSGD: the clip rides inside the step

@@ -247,3 +247,20 @@ def test_gpu_table_operations_dims_9_to_16(dev, model, n):
     inner = so.upper_inner if model == "upper" else so.bounded_inner
     assert relmax(ops.tangent_sqnorm(table.to(dev), u.to(dev), model).cpu(), inner(table, u)) < 1e-10
     ops.check_status(dev)
+
+
+@pytest.mark.gpu
+def test_gpu_sgd_step_of_a_parameter_without_manifold(dev):
+    """sympa_sgd_step_clipped (the scale's step inside RiemannianSGD): p <- p - lr (coef g + wd p), coef from the device-side
+    squared total norm like clip_grad_norm_."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(1000, generator=g, dtype=torch.float64)
+    gr = torch.randn(1000, generator=g, dtype=torch.float64)
+    for max_norm in (None, 0.5, 1e6):
+        p = p0.clone().to(dev)
+        sq = (gr * gr).sum().reshape(1).to(dev) if max_norm is not None else None
+        ops.sgd_step_clipped_(p, gr.to(dev), 0.03, 0.01, clip_sqnorm=sq, max_norm=max_norm)
+        coef = 1.0 if max_norm is None else min(1.0, max_norm / (float((gr * gr).sum().sqrt()) + 1e-6))
+        want = p0 - 0.03 * (coef * gr + 0.01 * p0)
+        assert relmax(p.cpu(), want) < 1e-14
