@@ -29,3 +29,18 @@ for W in margulis-bounded-finf-n4-b65536 cartesian-upper-riem-n8-b262144 custom-
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --steps 64 --warmup 8 --launch graph --streams 1 > $OUT/prof_$W.log 2>&1
   find $OUT/prof_$W -name "*kernel_stats.csv" | head -1 | xargs -r head -2
 done
+echo "== training-path kernels (times, A/B against the one-lane kernels, whole graphed step, soak)"
+{
+  timeout 300 python3 tools/bwd_time_dims.py 2>&1 | grep "fused"
+  timeout 300 python3 tools/bwd_coop_ab_small.py 262144 upper 2>&1 | grep "n="
+  timeout 300 python3 tools/bwd_coop_ab_small.py 262144 bounded 2>&1 | grep "n="
+  timeout 300 python3 tools/bwd_coop_ab.py upper 65536 9 10 12 16 2>&1 | grep backward
+  timeout 300 python3 tools/bwd_coop_ab.py bounded 65536 9 10 12 16 2>&1 | grep backward
+  timeout 300 python3 tools/spd_bwd_ab.py 65536 4 8 12 16 2>&1 | grep "spd backward"
+  timeout 300 python3 tools/spd_time.py 16 1048576 100000 --train 2>&1 | grep "spd n="
+  timeout 300 python3 tools/table_time.py upper 45500 8 2>&1 | grep rows=
+  timeout 300 python3 tools/table_time.py upper 5041 10 16 2>&1 | grep rows=
+  timeout 300 python3 tools/train_step_time.py 20 2>&1 | grep "training step"
+  timeout 300 python3 tools/fuzz_coop_bwd.py 120 2>&1 | tail -1
+  timeout 200 python3 tools/fuzz_coop.py 60 2>&1 | tail -1
+} | tee $OUT/training_path.txt
