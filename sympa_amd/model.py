@@ -32,12 +32,12 @@ class Model(nn.Module):
         return sa.model_forward(self.embeddings.embeds, input_triplet, man.model_name, man.metric.kind.value,
                                 weights, self.scale, self.scale_coef)
 
-    def fused_loss_backward(self, input_triplet, graph_distances, loss_scale=1.0, loss_out=None):
+    def fused_loss_backward(self, input_triplet, graph_distances, loss_scale=1.0, loss_out=None, zero_loss_out=True):
         """Extension (not in the reference API): the body of Runner.train_epoch's inner loop
         (runner.py:101-105: forward, AverageDistortionLoss / grad_accum_steps, loss.backward()) as ONE
         HIP kernel.  Accumulates into the parameters' .grad exactly like loss.backward() and returns the
-        loss as a 1-element device tensor (no host sync); `loss_out` (1-element fp64 device tensor) is zeroed and
-        used for it when given (a persistent buffer: one graph node less per step)."""
+        loss as a 1-element device tensor (no host sync); `loss_out` (1-element fp64 device tensor) is zeroed
+        (unless zero_loss_out=False: the caller has) and used for it when given (a persistent buffer: fewer graph nodes per step)."""
         from sympa_amd import ops
         man = self.manifold
         table = self.embeddings.embeds
@@ -51,7 +51,7 @@ class Model(nn.Module):
                 if self.scale.grad is None:
                     self.scale.grad = torch.zeros_like(self.scale.data)
                 gs = self.scale.grad
-            loss = torch.zeros(1, dtype=torch.float64, device=dev) if loss_out is None else loss_out.zero_()
+            loss = torch.zeros(1, dtype=torch.float64, device=dev) if loss_out is None else (loss_out.zero_() if zero_loss_out else loss_out)
             b = input_triplet.shape[0]
             n = table.shape[-1]
             if n >= 3 and table.grad.is_contiguous():
@@ -80,7 +80,7 @@ class Model(nn.Module):
             if self.scale.grad is None:
                 self.scale.grad = torch.zeros_like(self.scale.data)
             gs = self.scale.grad
-        loss = torch.zeros(1, dtype=torch.float64, device=dev) if loss_out is None else loss_out.zero_()
+        loss = torch.zeros(1, dtype=torch.float64, device=dev) if loss_out is None else (loss_out.zero_() if zero_loss_out else loss_out)
         ops.model_loss_backward(table.data, input_triplet, graph_distances, table.grad, loss, man.model_name,
                                 man.metric.kind.value, None if weights is None else weights.data, gw, self.scale.data,
                                 gs, self.scale_coef, loss_scale)

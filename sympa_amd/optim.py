@@ -25,6 +25,7 @@ class RiemannianSGD(torch.optim.Optimizer):
         # gradients as the update kernels read them; .grad itself is left unscaled.
         self.clip_max_norm = None
         self._sqnorm = {}
+        self._sqnorm_zeroed_by_caller = False      # GraphedTrainStep zeroes it together with the gradients (one launch)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -40,7 +41,8 @@ class RiemannianSGD(torch.optim.Optimizer):
                 if key not in self._sqnorm:
                     self._sqnorm[key] = torch.zeros(1, dtype=torch.float64, device=grads[0].device)
                 sq = self._sqnorm[key]
-                sq.zero_()
+                if not self._sqnorm_zeroed_by_caller:
+                    sq.zero_()
                 for t in grads:
                     ops.sqnorm_accum_(t if t.is_contiguous() else t.contiguous(), sq)
             else:

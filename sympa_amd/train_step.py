@@ -22,11 +22,22 @@ class GraphedTrainStep:
         self.key = None
         self.grad_ptrs = []
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self._zero_list = None
 
     def _body(self):
-        self.opt.zero_grad(set_to_none=False)
-        self.model.fused_loss_backward(self.ids, self.gd, loss_out=self.loss)      # accumulated straight into self.loss
-        self._clip_and_step()
+        if self._zero_list is None:
+            self.opt.zero_grad(set_to_none=False)
+            self.model.fused_loss_backward(self.ids, self.gd, loss_out=self.loss)      # accumulated straight into self.loss
+            self._clip_and_step()
+            return
+        # gradients, the loss word and the optimiser's squared-norm word zeroed by ONE multi-tensor launch
+        torch._foreach_zero_(self._zero_list)
+        self.model.fused_loss_backward(self.ids, self.gd, loss_out=self.loss, zero_loss_out=False)
+        self.opt._sqnorm_zeroed_by_caller = True
+        try:
+            self._clip_and_step()
+        finally:
+            self.opt._sqnorm_zeroed_by_caller = False
 
     def _clip_and_step(self):
         if hasattr(self.opt, "clip_max_norm"):       # sympa_amd.optim.RiemannianSGD: the clip rides inside the step
@@ -67,6 +78,13 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         for g, lr in zip(self.opt.param_groups, saved):
             g["lr"] = lr
+        # after the warm-up every buffer exists: from here on one foreach launch zeroes them all
+        self._zero_list = None
+        if hasattr(self.opt, "_sqnorm_zeroed_by_caller") and hasattr(self.opt, "clip_max_norm"):
+            grads = [p.grad for p in self.params if p.grad is not None]
+            words = [self.loss] + [t for t in getattr(self.opt, "_sqnorm", {}).values() if t.device == self.loss.device]
+            if grads and all(g.is_cuda for g in grads):
+                self._zero_list = grads + words
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._body()
