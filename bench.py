@@ -4,10 +4,23 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one pass of the hot path (fused Model.forward: gather + distance + metric + scale,
-C-ABI `sympa_model_forward`, ONE kernel launch) over one batch of synthetic pairs, inputs already
-resident in HBM.  Default workload: upper / riem / n=4, batch 65 536 pairs per GPU, table of 5 041
-nodes (the configuration the headline target is quoted on).
+A *step* is one pass of the hot path (fused Model.forward: gather + distance + metric + scale) over one
+batch of synthetic pairs, inputs already resident in HBM.  Default workload: upper / riem / n=4, batch
+65 536 pairs per GPU, table of 5 041 nodes (the configuration the headline target is quoted on).
+
+How the K steps reach the GPU (`launch_mode` in the record):
+  fused (default, Siegel dims <= 8)  the K batches are handed to `Model.forward_batches` as one list (the
+        loop of Runner.evaluate, runner.py:124-135): ONE C call (`sympa_model_forward_batches`), which
+        evaluates up to 32 consecutive steps per kernel launch (`siegel_dist_multi_kernel`).  The headline
+        pairs/s is therefore that of launches of up to 32 x 65 536 pairs; `roofline` describes that kernel,
+        `roofline_default_kernel` the one-launch-per-step kernel a single `Model.forward` call runs.
+  graph   one kernel launch per step (C-ABI `sympa_model_forward`), replayed from hipGraphs
+  direct  one Python -> C-ABI call and one launch per step
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...` as a CHILD process before it
+touches the GPU (train.py:133-136 / README.md:104: the reference is one command too), relays the child's one
+JSON line and exits with its return code.
 
 Scaling modes (the pair list shards by triplet, the table is replicated, NO data-path collective):
   weak   (default)  every rank processes its own B-pair shard of a (B x N)-pair global batch
@@ -20,6 +33,8 @@ Prints ONE JSON line on rank 0 (DESIGN.md section 7 explains every field).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +50,11 @@ WORKLOADS = {
     "margulis-bounded-finf-n4-b65536": ("bounded", "finf", 4, 5041, 65536),  # configs[2]
     "cartesian-upper-riem-n8-b262144": ("upper", "riem", 8, 45500, 262144),  # configs[3]
     "custom-spd-n16-b1048576": ("spd", "riem", 16, 100000, 1048576),         # configs[4] (parity unpinned: geoopt absent)
+}
+
+GRAPH_OF = {   # --pairs graph: the graph whose (i < j, d) triplets the workload trains / evaluates on (BASELINE.json configs)
+    "grid-upper-riem-n2-b512": "grid3d-125", "tree-upper-riem-n4-b8192": "tree-b3-h6",
+    "margulis-bounded-finf-n4-b65536": "margulis-71", "upper-riem-n4-b65536": "margulis-71",
 }
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -68,7 +88,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
+def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0, pairs=None):
     """Oracle (op-for-op torch-CPU fp64 restatement of the reference) timed on the host cores."""
     import torch
     from oracle import siegel_oracle as so
@@ -83,12 +103,17 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
     else:
         table = data.trained_like_table(nodes, n, model=model, seed=seed)
         oracle_forward = so.model_forward
-    pairs = data.sample_pairs(nodes, batch, 0, seed)
+    if pairs is None:
+        pairs = data.sample_pairs(nodes, batch, 0, seed)
+    else:
+        batch = min(batch, pairs.shape[0])
+        pairs = pairs[:batch]
     # batched LAPACK eigh on tiny matrices does not scale with threads and collapses
     # when oversubscribed: pick the fastest of a few thread counts on a small probe, report that one
     ncpu = os.cpu_count() or 1
     probe = pairs[: min(batch, 8192)]
     best = (None, 0.0)
+    by_threads = {}
     with torch.no_grad():
         for threads in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
             torch.set_num_threads(threads)
@@ -96,6 +121,7 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
             t0 = time.perf_counter()
             oracle_forward(table, probe, model, metric)
             rate = len(probe) / (time.perf_counter() - t0)
+            by_threads[threads] = rate
             if rate > best[1]:
                 best = (threads, rate)
     torch.set_num_threads(best[0])
@@ -111,9 +137,45 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0):
                 break
     return {"value": done / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": cpu_model_name(), "host_logical_cpus": ncpu,
+            # the 1-thread figure beside the best-of (batched eigh barely scales); probe of len(probe) pairs
+            "value_1_thread": by_threads.get(1), "probe_pairs_per_s_by_threads": by_threads,
             "sample": f"{iters} x batch {batch} of the same workload, oracle/siegel_oracle.py "
                       f"{'spd_model_forward' if model == 'spd' else 'model_forward'}, "
                       f"{el:.1f} s"}
+
+
+def self_launch(nproc, argv, worker=None):
+    """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child `torch.distributed.run` (never an
+    exec: this is called before anything touches the GPU, and the parent never does), relay the ONE JSON line rank 0
+    printed and return the child's exit code.  `worker` (default: this file; SYMPA_BENCH_WORKER overrides it for the CPU
+    test, which runs a gloo stub) is the script every rank executes."""
+    worker = worker or os.environ.get("SYMPA_BENCH_WORKER") or os.path.abspath(__file__)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker] + list(argv)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    rc = proc.returncode
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited 0 but printed no JSON record\n")
+        rc = 1
+    return rc if rc >= 0 else 128 - rc
 
 
 def main():
@@ -145,7 +207,15 @@ def main():
                          "replayed from captured hipGraphs over --streams parallel streams; direct: one "
                          "Python->C-ABI call and one launch per step")
     ap.add_argument("--steps-per-launch", type=int, default=32, help="fused launch only (<= 32)")
+    ap.add_argument("--pairs", default="sampled", choices=["sampled", "graph", "graph-shuffled"],
+                    help="sampled: keyed-RNG pairs (i, j != i) of the workload's table; graph / graph-shuffled (configs[0..2] "
+                         "only): the workload's real (i < j, d_graph) triplets (preprocess.py:101-126), step j takes the "
+                         "j-th batch of them in lexicographic order (the evaluation split, runner.py:124-135) or in "
+                         "DistributedSampler order (the training split, train.py:105-110)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 -- RCCL prints its version
@@ -155,13 +225,13 @@ def main():
     os.dup2(2, 1)
     import torch.distributed as dist
     from sympa_amd import _lib, data, ops
+    from sympa_amd.model import Model
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     _lib.load()
     torch.cuda.set_device(local_rank)
@@ -190,9 +260,23 @@ def main():
     # global batch j has `global_pairs` pairs; this rank takes the interleave rank::world of it
     nb = max(1, min(args.distinct_batches, args.steps))
     batches = []
-    for j in range(nb):
-        glob = data.sample_pairs(nodes, global_pairs, j, args.seed)
-        batches.append(glob[rank::world].contiguous().to(dev))
+    if args.pairs == "sampled":
+        for j in range(nb):
+            glob = data.sample_pairs(nodes, global_pairs, j, args.seed)
+            batches.append(glob[rank::world].contiguous().to(dev))
+    else:
+        if args.workload not in GRAPH_OF:
+            raise SystemExit(f"--pairs {args.pairs}: no graph for workload {args.workload} (configs[3], [4] sample their pairs, "
+                             "SURVEY 8d)")
+        trip_all, id2node = data.graph_triplets(data.named_graph(GRAPH_OF[args.workload]))
+        assert len(id2node) == nodes
+        if args.pairs == "graph-shuffled":    # the order DistributedSampler(world 1, epoch 0) feeds the training loop
+            order = torch.tensor(data.distributed_sampler_indices(trip_all.shape[0], 1, 0, epoch=0, seed=args.seed))
+            trip_all = trip_all[order]
+        total = trip_all.shape[0]
+        for j in range(nb):                   # global batch j = triplets [j G, (j+1) G), wrapping around the split
+            rows = (torch.arange(global_pairs) + j * global_pairs) % total
+            batches.append(trip_all[rows][rank::world].contiguous().to(dev))
     my_pairs = batches[0].shape[0]
     outs = [torch.empty(my_pairs, dtype=torch.float64, device=dev) for _ in range(nb)]
     if args.launch == "fused" and (model == "spd" or n > 8):
@@ -261,32 +345,47 @@ def main():
             step(i)            # warm (allocates the status word)
         torch.cuda.synchronize(dev)
 
+        # the mirrored reference API: a Model whose table is the synthetic one; the timed region hands the K batches to
+        # Model.forward_batches as ONE list (plan built on first use, cached on the model)
+        class _A:       # the args object Model reads (model.py:8-14)
+            manifold, dims, num_points = model, n, nodes
+            scale_coef, scale_init, train_scale = 1.0, 1.0, False
+        _A.metric = metric
+        net = Model(_A)
+        with torch.no_grad():
+            net.embeddings.embeds.data = table_cpu.clone()
+        net = net.to(dev)
+        table = net.embeddings.embeds.data      # the single-step kernels below read the same table
+        scale = net.scale.data
+
         class Fused:
-            """K steps = ceil(K / spl) launches of up to spl consecutive steps each, enqueued by one C call per
-            group of launches (step i reads batches[i % nb], writes outs[i % nb])."""
+            """K steps = ceil(K / spl) launches of up to spl consecutive steps each (step i reads batches[i % nb],
+            writes dst[i % nb]).  spl = 32: Model.forward_batches(list of K batches), one C call; another spl (A/B
+            only): ops.BatchedForward ranges."""
             def __init__(self, dst):
+                self.lists = {}
                 self.plans = {}
                 self.dst = dst
 
-            def plan(self, k):
-                if k not in self.plans:
-                    self.plans[k] = ops.BatchedForward(table, [batches[i % nb] for i in range(k)],
-                                                       [self.dst[i % nb] for i in range(k)], model, metric, None,
-                                                       scale, 1.0, flags=ops.FLAG_FUSE,
-                                                       streams=[torch.cuda.current_stream(dev)])
-                return self.plans[k]
+            def lists_for(self, k):
+                if k not in self.lists:
+                    self.lists[k] = ([batches[i % nb] for i in range(k)], [self.dst[i % nb] for i in range(k)])
+                return self.lists[k]
 
             def run(self, k):
-                p = self.plan(k)
+                bl, ol = self.lists_for(k)
                 if spl == ops.MAX_FUSED_BATCHES:
-                    p.run()                       # the C entry cuts the list into launches of 32 steps itself
-                else:
-                    for i0 in range(0, k, spl):
-                        p.run(i0, min(spl, k - i0))
+                    net.forward_batches(bl, ol)        # the mirrored API (plan cached on the model after the first call)
+                    return
+                if k not in self.plans:
+                    self.plans[k] = ops.BatchedForward(table, bl, ol, model, metric, None, scale, 1.0,
+                                                       flags=ops.FLAG_FUSE)
+                p = self.plans[k]
+                p.set_streams(None)
+                for i0 in range(0, k, spl):
+                    p.run(i0, min(spl, k - i0))
 
         fused = Fused(outs)
-        for k_ in {args.steps, args.warmup, args.steps if args.steps <= 4 * spl else 4 * spl} - {0}:
-            fused.plan(k_)
 
     def run_steps(k):
         if fused is not None:
@@ -336,10 +435,14 @@ def main():
     torch.cuda.synchronize(dev)
     device_ms = ev0.elapsed_time(ev1)
     ops.check_status(dev)
+    ranks_seen = 1
     if use_dist:
         t = torch.tensor([elapsed, device_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, device_ms = float(t[0].item()), float(t[1].item())
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)       # every rank that took part in the timed region counts itself
+        ranks_seen = int(ones.item())
 
     # ---- every output of the timed variant against a strictly sequential pass of the default kernel form
     # (different instantiation when the timed region ran the minimum-LDS form): same arithmetic => bit-identical
@@ -391,7 +494,8 @@ def main():
         # launch stream -- its average duration IS the event-bracketed repetition of the timed region over its launches
         n_launches = (args.steps + spl - 1) // spl
         timed_kernel = f"siegel_dist_multi_kernel<{n}, {MODEL_ID[model]}>"
-        k_timed = (device_ms / n_launches, device_ms / n_launches)
+        # >= 8 event-bracketed repetitions of the timed region's launches (average and median), not one sample
+        k_timed = timed_groups(lambda: run_steps(args.steps), n_launches)
         timed_pairs_per_launch = my_pairs * args.steps / n_launches
         k_default = kernel_time(0)
     else:
@@ -439,22 +543,30 @@ def main():
             "metric": "pairwise Siegel distances/sec (upper, riem, n=4)" if args.workload == "upper-riem-n4-b65536"
                       else (f"pairwise SPD affine-invariant distances/sec (n={n})" if model == "spd"
                             else f"pairwise Siegel distances/sec ({model}, {metric}, n={n})"),
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             # HIP events on the launch stream around an identical repetition of the K steps (max over ranks): what the GPU
             # side of the timed region takes, launch latency of the first graph included
             "ms_per_step_device": device_ms / args.steps,
+            # wall-clock-free throughput of the same region (the ~10 us of launch + sync latency of a K = 20 region excluded)
+            "value_device": global_pairs * args.steps / (device_ms * 1e-3),
+            "launch_mode": args.launch, "steps_per_launch": (min(spl, args.steps) if fused is not None else 1),
             "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "manifold": model, "dist_metric": metric,
                        "dims": n, "nodes": nodes, "pairs_per_gpu_per_step": my_pairs,
-                       "global_pairs_per_step": global_pairs, "table": args.table, "launch": args.launch,
+                       "global_pairs_per_step": global_pairs, "table": args.table, "pairs": args.pairs,
+                       "launch": args.launch,
+                       "api": ("Model.forward_batches(list of K batches)" if (fused is not None and
+                                                                                spl == ops.MAX_FUSED_BATCHES)
+                               else "ops (C-ABI binding) directly"),
                        "streams": args.streams,
                        "parallelism": f"pairs sharded rank::{world}, table replicated, no collective"},
             # the kernel the timed region ran, its launches strictly sequential (what rocprofv3 --kernel-trace reports)
             "roofline": roof(timed_kernel, k_timed, timed_pairs_per_launch,
                              ("the timed region's kernel: one launch evaluates up to %d consecutive steps (batches); duration = "
-                              "HIP-event time of an identical repetition of the timed region / its %d launch(es), launch "
+                              "HIP-event time of 8 identical repetitions of the timed region / its %d launch(es) each, launch "
                               "latency included; " % (spl, (args.steps + spl - 1) // spl)
                               if fused is not None else "the timed region's kernel instantiation, one step per launch, "
                               "launches strictly sequential on one stream, HIP events per group; ")
@@ -477,7 +589,8 @@ def main():
         if valu_per_wave:
             rec["valu_issue_fraction"] = (value / world) / 64.0 * valu_per_wave * 4.0 / (1024 * 2.4e9)
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, my_pairs, args.seed)
+            rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, my_pairs, args.seed,
+                                               pairs=None if args.pairs == "sampled" else batches[0][:, :2].cpu())
         else:
             rec["cpu_baseline"] = None
     if use_dist:

@@ -92,6 +92,22 @@ const char* sympa_version(void);
 const char* sympa_last_error(void);
 int sympa_max_dims(void);
 
+/* Kernel families whose default instantiations use the sixteen- / eight-lanes-per-pair layout with inline-asm DPP
+ * instructions (the compiler cannot see their hazards; the build scans the ISA, and a numerical self-check
+ * compares every instantiation with the one-lane kernel on first use -- sympa_amd/selfcheck.py).  An instantiation
+ * (family, model, n) marked here is routed to the one-lane-per-pair / one-row-per-lane kernel by every entry point, whatever
+ * the flags; model is SYMPA_MODEL_* (0 for the spd families).  Process-wide, thread-safe, no GPU call.  No reference
+ * counterpart (the reference has no native kernels). */
+#define SYMPA_FAMILY_SIEGEL_FWD 0   /* sympa_siegel_dist_fwd / sympa_model_forward*, n = 9..16 */
+#define SYMPA_FAMILY_SIEGEL_BWD 1   /* sympa_siegel_dist_bwd / sympa_model_backward / sympa_model_loss_backward*, n = 5..16 */
+#define SYMPA_FAMILY_SIEGEL_TABLE 2 /* sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step* / sympa_tangent_sqnorm, n = 7..16 */
+#define SYMPA_FAMILY_SPD_FWD 3      /* sympa_spd_dist_fwd / sympa_spd_model_forward, n = 6..16 */
+#define SYMPA_FAMILY_SPD_BWD 4      /* sympa_spd_backward_rows / sympa_spd_loss_backward, n = 3..16 */
+#define SYMPA_FAMILY_SPD_TABLE 5    /* sympa_spd_egrad2rgrad / sympa_spd_rsgd_step, n = 3..16 */
+#define SYMPA_NUM_FAMILIES 6
+int sympa_set_instance_fallback(int family, int model, int n, int on);
+int sympa_get_instance_fallback(int family, int model, int n);
+
 /* manifold.dist(z1, z2) for pre-gathered points.
  * Replaces SiegelManifold.dist (sympa/manifolds/siegel_manifold.py:41-72) for model = UPPER and
  * BoundedDomainManifold.dist (sympa/manifolds/bounded_domain.py:27-39) for model = BOUNDED,

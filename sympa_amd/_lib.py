@@ -1,8 +1,9 @@
 """ctypes binding of the C-ABI in include/sympa_hip.h.
 
 The product path has NO fallback: if libsympa_hip.so is missing or does not export a declared
-symbol, importing/using the ops raises.  (Build it with `python -c "import __graft_entry__ as g; g.build()"`
-or `make -C sympa_amd/csrc`.)"""
+symbol, importing/using the ops raises.  (Build it with `python -c "import __graft_entry__ as g; g.build()"`;
+`make -C sympa_amd/csrc` runs the same function -- there is ONE build path, the one that scans every translation
+unit's ISA for the DPP hazard and rebuilds the units that show it.)"""
 import ctypes
 import os
 
@@ -14,6 +15,8 @@ SYMBOLS = (
     "sympa_version",
     "sympa_last_error",
     "sympa_max_dims",
+    "sympa_set_instance_fallback",
+    "sympa_get_instance_fallback",
     "sympa_siegel_dist_fwd",
     "sympa_model_forward",
     "sympa_model_forward_batches",
@@ -70,6 +73,10 @@ def load():
     lib.sympa_version.restype = ctypes.c_char_p
     lib.sympa_last_error.restype = ctypes.c_char_p
     lib.sympa_max_dims.restype = ctypes.c_int
+    lib.sympa_set_instance_fallback.restype = ctypes.c_int
+    lib.sympa_set_instance_fallback.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.sympa_get_instance_fallback.restype = ctypes.c_int
+    lib.sympa_get_instance_fallback.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.sympa_siegel_dist_fwd.restype = ctypes.c_int
     lib.sympa_siegel_dist_fwd.argtypes = [
         _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -15,7 +15,8 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     // (tools/bwd_coop_ab_small.py, per 262 144 pairs): the fused step at n = 8 (upper 1.78 -> 1.49 ms, bounded 2.59 -> 1.99 ms),
     // bounded n = 8 dense rows (2.51 -> 2.15 ms), bounded n = 7 fused (1.70 -> 1.56 ms).  SYMPA_FLAG_COOP forces it for
     // dims 5..8, SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels.
-    if (n >= 5 && n <= 8 && !(a.f.flags & SYMPA_FLAG_GENERIC)) {
+    const bool one_lane = (a.f.flags & SYMPA_FLAG_GENERIC) || instance_fallback(SYMPA_FAMILY_SIEGEL_BWD, model, n);
+    if (n >= 5 && n <= 8 && !one_lane) {
         const bool bounded = model == SYMPA_MODEL_BOUNDED;
         const bool faster = (n == 8 && (scatter || bounded)) || (n == 7 && bounded && scatter);
         if (faster || (a.f.flags & SYMPA_FLAG_COOP)) return launch_bwd_half(a, n, model, scatter, s);
@@ -33,7 +34,7 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     }
     if (n > 8 && n <= SYMPA_MAX_DIMS_BACKWARD) {
         // sixteen lanes per pair (siegel_coop_bwd.hpp); SYMPA_FLAG_GENERIC keeps the one-lane-per-pair kernel over scratch
-        if (!(a.f.flags & SYMPA_FLAG_GENERIC)) return launch_bwd_coop(a, n, model, scatter, s);
+        if (!one_lane) return launch_bwd_coop(a, n, model, scatter, s);
         return launch_bwd_rolled(a, n, model, scatter, s);
     }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "backward: dims outside [1, SYMPA_MAX_DIMS_BACKWARD]");

@@ -66,6 +66,11 @@ __device__ __forceinline__ void ap_store(const DistArgs& a, const int64_t p, con
 }
 #endif
 
+// Registry of kernel instantiations of the inline-asm DPP layouts (sixteen / eight lanes per pair or row) that a numerical
+// self-check found to disagree with the one-lane kernels (C-ABI sympa_set_instance_fallback; sympa_amd/selfcheck.py runs the
+// check on first use of every instantiation): the dispatchers route those to the one-lane kernels.  family = SYMPA_FAMILY_*.
+bool instance_fallback(int family, int model, int n);
+
 // thread-local message behind sympa_last_error()
 char* last_error_buffer();
 int fail(int code, const char* msg);

@@ -6,6 +6,7 @@
 // cross-lane traffic at all and no lane idles in an elementwise stage.  The only wave-level
 // operation is the ballot that ends the Jacobi loop when all 64 pairs have converged.
 // The workload is VALU-fp64 bound: the table rows come out of L2 / Infinity Cache.
+#include <atomic>
 #include "siegel_common.hpp"
 #include "siegel_math_generic.hpp"
 #include <hip/hip_ext.h>
@@ -261,7 +262,8 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
         default: break;
     }
     if (n > SYMPA_MAX_DIMS && n <= sympa::GENERIC_MAX_N) {
-        if (!(a.flags & SYMPA_FLAG_GENERIC)) return launch_siegel_coop(a, n, model, s);
+        if (!(a.flags & SYMPA_FLAG_GENERIC) && !instance_fallback(SYMPA_FAMILY_SIEGEL_FWD, model, n))
+            return launch_siegel_coop(a, n, model, s);
         hipLaunchKernelGGL(siegel_dist_generic_kernel, dim3((unsigned)((a.b + 63) / 64)), dim3(64), 0, s, a, n, model);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -342,7 +344,26 @@ int launch_multi(const double* table, int64_t num_rows, int n, const int64_t* co
 
 }  // namespace
 
+namespace sympa_hip {
+namespace {
+std::atomic<unsigned char> g_instance_fallback[SYMPA_NUM_FAMILIES][2][SYMPA_MAX_DIMS_GENERIC + 1];
+}
+bool instance_fallback(int family, int model, int n) {
+    if (family < 0 || family >= SYMPA_NUM_FAMILIES || model < 0 || model > 1 || n < 0 || n > SYMPA_MAX_DIMS_GENERIC) return false;
+    return g_instance_fallback[family][model][n].load(std::memory_order_relaxed) != 0;
+}
+}  // namespace sympa_hip
+
 extern "C" {
+
+int sympa_set_instance_fallback(int family, int model, int n, int on) {
+    if (family < 0 || family >= SYMPA_NUM_FAMILIES || model < 0 || model > 1 || n < 1 || n > SYMPA_MAX_DIMS_GENERIC)
+        return sympa_hip::fail(SYMPA_ERR_BAD_ARG, "no such kernel instantiation");
+    sympa_hip::g_instance_fallback[family][model][n].store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
+int sympa_get_instance_fallback(int family, int model, int n) { return sympa_hip::instance_fallback(family, model, n) ? 1 : 0; }
 
 const char* sympa_version(void) { return "sympa_hip 0.1.0 (gfx950)"; }
 const char* sympa_last_error(void) { return sympa_hip::last_error_buffer(); }

@@ -2,14 +2,22 @@
 // (SURVEY 8f-2): egrad2rgrad, projx, and the fused RiemannianSGD step.  One table row per lane; these run
 // once per optimiser step over N rows (N = 5 041 .. 100 000) and are bandwidth-trivial next to the
 // distance kernels, so rows are loaded directly.
+#include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "siegel_table_kernel.hpp"
 
 namespace {
 using namespace sympa_hip;
 
-__device__ int g_rows_outside;      // rows that left the eps-interior in the last sixteen-lanes RSGD step
+// Rows that left the eps-interior in a sixteen- / eight-lanes RSGD step or projx: the word the exact projection is gated on.
+// One word per (device, stream): the module's copy of this array on the CURRENT device, slot chosen by the stream, so that
+// two devices of one process never share an address and two streams of one device never race on memset -> count -> gate.
+// No allocation (the symbol exists once the code object is loaded), so the first call may come from inside a stream capture.
+constexpr int GATE_SLOTS = 64;
+constexpr int GATE_MAX_DEVICES = 64;
+__device__ int g_rows_outside[GATE_SLOTS];
 
 // OP 0: out = projx(z).   OP 1: table <- retr(table, -lr * egrad2rgrad(table, grad + wd * table)) in place.
 // sum of squares of `count` doubles, accumulated into acc[0] (the total gradient norm of clip_grad_norm_)
@@ -50,6 +58,35 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_rows_kernel(const double* _
     }
 }
 
+struct GateSlots {
+    int* base = nullptr;
+    void* stream[GATE_SLOTS];
+    int used = 0;
+};
+GateSlots g_gate[GATE_MAX_DEVICES];
+std::mutex g_gate_mu;
+
+int* gate_word(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GATE_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_gate_mu);
+    GateSlots& g = g_gate[dev];
+    if (g.base == nullptr &&
+        hipGetSymbolAddress(reinterpret_cast<void**>(&g.base), HIP_SYMBOL(g_rows_outside)) != hipSuccess) {
+        g.base = nullptr;
+        return nullptr;
+    }
+    for (int i = 0; i < g.used; ++i)
+        if (g.stream[i] == s) return g.base + i;
+    if (g.used < GATE_SLOTS) {
+        g.stream[g.used] = s;
+        return g.base + g.used++;
+    }
+    // more than GATE_SLOTS distinct streams on one device: slots are shared by hash (the race of two streams on one slot is
+    // back, for those streams only)
+    return g.base + (int)((reinterpret_cast<uintptr_t>(s) >> 4) % GATE_SLOTS);
+}
+
 int dispatch_table(int op, int n, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
                    double eps, int32_t* projected, int32_t* status, void* stream, const double* clip = nullptr,
                    double max_norm = 0.0) {
@@ -60,15 +97,14 @@ int dispatch_table(int op, int n, int model, double* z, const double* g, double*
     if (b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "too many rows for one launch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const bool generic = std::getenv("SYMPA_TABLE_GENERIC") != nullptr;      // one-row-per-lane kernels for A/B
-    if (n >= 7 && n <= SYMPA_MAX_DIMS_GENERIC && !generic) {
+    if (n >= 7 && n <= SYMPA_MAX_DIMS_GENERIC && !generic && !instance_fallback(SYMPA_FAMILY_SIEGEL_TABLE, model, n)) {
         // Eight (n = 7, 8) or sixteen (n = 9..16) lanes per row (siegel_coop_table.hpp).  egrad2rgrad and the tangent norm
         // are complete there.  The RSGD step and projx symmetrise, test "inside the eps-interior" by a Cholesky
         // factorisation and count the rows that fail in a device word; the exact one-row-per-lane projx (the reference's
         // eigenvalue clamp, which leaves inside rows untouched) then runs gated on that word -- it returns at once in the
         // usual case of zero.  No host synchronisation, no allocation, capturable in the training hipGraph.
-        static int* outside = nullptr;
-        if (outside == nullptr && hipGetSymbolAddress(reinterpret_cast<void**>(&outside), HIP_SYMBOL(g_rows_outside)) != hipSuccess)
-            return fail(SYMPA_ERR_BAD_ARG, "no device symbol for the interior test");
+        int* outside = gate_word(s);
+        if (outside == nullptr) return fail(SYMPA_ERR_BAD_ARG, "no device symbol for the interior test");
         const bool gated = (op == 0 || op == 1);
         if (gated && hipMemsetAsync(outside, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "memset failed");
         int* word = gated ? outside : (op == 3 ? reinterpret_cast<int*>(status) : nullptr);

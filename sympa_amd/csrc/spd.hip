@@ -161,7 +161,7 @@ int launch_spd(const DistArgs& a, int n, void* stream) {
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
     const dim3 grid((unsigned)((a.b + 63) / 64));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n >= 6 && !(a.flags & SYMPA_FLAG_GENERIC)) {     // measured crossover against the one-lane-per-pair kernel: n = 6
+    if (n >= 6 && !(a.flags & SYMPA_FLAG_GENERIC) && !instance_fallback(SYMPA_FAMILY_SPD_FWD, 0, n)) {     // measured crossover against the one-lane-per-pair kernel: n = 6
         switch (n) {
 #define SYMPA_SPD_COOP_CASE(MM) case MM: hipLaunchKernelGGL(spd16_coop_kernel<MM>, grid, dim3(64), 0, s, a); break;
             SYMPA_SPD_COOP_CASE(6) SYMPA_SPD_COOP_CASE(7) SYMPA_SPD_COOP_CASE(8) SYMPA_SPD_COOP_CASE(9)

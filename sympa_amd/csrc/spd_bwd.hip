@@ -119,7 +119,7 @@ int launch_spd_table(int op, double* x, const double* g, double* out, int64_t b,
     if (n < 1 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: dims outside [1, 16]");
     // SYMPA_SPD_TABLE_GENERIC=1 keeps the one-row-per-lane kernel for A/B measurements (tools/spd_time.py)
     static const bool generic = std::getenv("SYMPA_SPD_TABLE_GENERIC") != nullptr;
-    if (op != 0 && n >= SPD_COOP_BWD_MIN_N && !generic)
+    if (op != 0 && n >= SPD_COOP_BWD_MIN_N && !generic && !instance_fallback(SYMPA_FAMILY_SPD_TABLE, 0, n))
         launch_spd_coop_table(op, n, x, g, out, b, lr, wd, clip, max_norm, status, reinterpret_cast<hipStream_t>(stream));
     else
         hipLaunchKernelGGL(spd_table_kernel, dim3((unsigned)((b + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
@@ -142,8 +142,11 @@ static int spd_backward_impl(const double* x, const double* y, int64_t num_rows,
     if (b == 0) return 0;
     if (x == nullptr || y == nullptr || (grad_table == nullptr && (grad_x_rows == nullptr || grad_y_rows == nullptr)))
         return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (instance_fallback(SYMPA_FAMILY_SPD_BWD, 0, n)) flags |= SYMPA_FLAG_GENERIC;
     if (grad_table != nullptr && (n < SPD_COOP_BWD_MIN_N || src == nullptr || (flags & SYMPA_FLAG_GENERIC)))
-        return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: the in-kernel scatter needs n >= 3 and index lists");
+        return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd: the in-kernel scatter needs n >= 3, index lists and the sixteen-lanes kernel "
+                                                "(not SYMPA_FLAG_GENERIC / an instance fallback): use sympa_spd_backward_rows + "
+                                                "sympa_scatter_add_flat_rows");
     if ((src == nullptr) != (dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "give both index lists or neither");
     if (src != nullptr && num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
     if (grad_out == nullptr && graph_dist == nullptr) return fail(SYMPA_ERR_BAD_ARG, "need grad_out or graph_dist");

@@ -11,6 +11,23 @@ from sympa_amd.embeddings import EmbeddingsFactory, ManifoldFactory
 from sympa_amd.manifolds.metrics import MetricType
 
 
+class _SpdBatches:
+    """forward_batches for the spd model: one launch per batch (its kernel is already many waves per SIMD deep at
+    the batch sizes it is used with; no multi-batch kernel)."""
+
+    def __init__(self, model, batches, outs):
+        self.model, self.batches, self.outs = model, batches, outs
+
+    def set_streams(self, streams):
+        pass
+
+    def run(self):
+        from sympa_amd import ops
+        m = self.model
+        for t, o in zip(self.batches, self.outs):
+            ops.spd_model_forward(m.embeddings.embeds.data, t, m.scale.data, m.scale_coef, out=o)
+
+
 class Model(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -31,6 +48,76 @@ class Model(nn.Module):
         weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
         return sa.model_forward(self.embeddings.embeds, input_triplet, man.model_name, man.metric.kind.value,
                                 weights, self.scale, self.scale_coef)
+
+    # ---- lists of batches: the consumer is Runner.evaluate's loop (runner.py:124-135), one forward() per batch ----
+    def prepare_batches(self, batches, outs=None):
+        """Validates a list of int64 [b_i, 2|3] batches once, allocates one output per batch (or takes `outs`) and
+        builds the host-side pointer arrays of C-ABI sympa_model_forward_batches.  The returned plan is what
+        `forward_batches` runs; it keeps the tensors alive and reads table, scale and metric weights through their
+        device pointers, so parameter updates in place are seen, while `model.to(...)` needs a new plan."""
+        from sympa_amd import ops
+        man = self.manifold
+        table = self.embeddings.embeds.data
+        batches = list(batches)
+        if outs is None:
+            flat = torch.empty(sum(int(t.shape[0]) for t in batches), dtype=torch.float64, device=table.device)
+            outs, s = [], 0
+            for t in batches:
+                outs.append(flat[s:s + t.shape[0]])
+                s += t.shape[0]
+        outs = list(outs)
+        if man.model_name == "spd":
+            return _SpdBatches(self, batches, outs)
+        weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
+        plan = ops.BatchedForward(table, batches, outs, man.model_name, man.metric.kind.value, weights, self.scale.data,
+                                  self.scale_coef, flags=ops.FLAG_FUSE)
+        plan.outs = outs
+        return plan
+
+    def forward_batches(self, batches, outs=None):
+        """forward() over a list of batches (no autograd): ONE C call; for dims <= 8 the batches go 32 at a time
+        through the fused multi-batch kernel (`siegel_dist_multi_kernel`), which is what fills the chip when a batch is
+        one wave per SIMD or less.  `batches` is a list of int64 [b_i, 2|3] tensors or a plan from `prepare_batches`;
+        for a list the plan is built on first use and cached (keyed by the identity of the tensors, which the plan keeps
+        alive; at most 8 plans).  Returns the list of [b_i] outputs, enqueued on the current stream."""
+        if isinstance(batches, (list, tuple)):
+            table = self.embeddings.embeds
+            key = (tuple(map(id, batches)), None if outs is None else tuple(map(id, outs)),
+                   table.data_ptr(), self.scale.data_ptr())
+            cache = self.__dict__.setdefault("_batch_plans", {})
+            plan = cache.get(key)
+            if plan is None:
+                if len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                plan = cache[key] = self.prepare_batches(batches, outs)
+        else:
+            plan = batches
+        plan.set_streams(None)       # torch's current stream
+        plan.run()
+        return plan.outs
+
+    def evaluate(self, src_dst_ids, graph_distances, batch_size):
+        """Runner.evaluate (runner.py:124-135): average distortion |d_manifold - d_graph| / d_graph (metrics.py:21) over
+        every triplet, the model called once per `batch_size` triplets.  Here the batches are row slices of
+        `src_dst_ids` [T, 2|3] handed over as one list; the plan and the [T] output are cached on the model (the
+        evaluation split is the same every epoch).  One host sync (the returned float)."""
+        ids = src_dst_ids if src_dst_ids.is_contiguous() else src_dst_ids.contiguous()
+        total = ids.shape[0]
+        if total == 0:
+            raise ValueError("evaluate() over an empty split (statistics.mean raises in the reference too)")
+        table = self.embeddings.embeds
+        key = (ids.data_ptr(), total, int(batch_size), table.data_ptr(), self.scale.data_ptr())
+        ev = self.__dict__.get("_eval_plan")
+        if ev is None or ev[0] != key:
+            out = torch.empty(total, dtype=torch.float64, device=table.device)
+            batches = [ids[s:s + batch_size] for s in range(0, total, batch_size)]
+            outs = [out[s:s + batch_size] for s in range(0, total, batch_size)]
+            ev = (key, self.prepare_batches(batches, outs), out, ids)
+            self.__dict__["_eval_plan"] = ev
+        with torch.no_grad():
+            self.forward_batches(ev[1])
+            gd = graph_distances.to(device=table.device, dtype=torch.float64)
+            return float(((ev[2] - gd).abs() / gd).sum()) / total
 
     def fused_loss_backward(self, input_triplet, graph_distances, loss_scale=1.0, loss_out=None, zero_loss_out=True):
         """Extension (not in the reference API): the body of Runner.train_epoch's inner loop

@@ -11,6 +11,7 @@ import ctypes
 import torch
 
 from sympa_amd import _lib
+from sympa_amd import selfcheck as _sc
 from sympa_amd.config import EPS
 
 MODEL_IDS = {"upper": 0, "bounded": 1}
@@ -55,6 +56,13 @@ def check_status(device=None, reset=True):
             f"Siegel distance: {count} pairs outside the manifold / non-finite (status bits {bits}); "
             "reference: 'assert 0 <= eigvalues <= 1' (siegel_manifold.py:64-66)")
     return bits, count
+
+
+def _gate(family, model, n, dev):
+    """First use of a lanes-per-pair kernel instantiation on a device: compare it with the one-lane kernel
+    (sympa_amd/selfcheck.py).  One tuple lookup afterwards; dims below the family's range cost one comparison."""
+    if n >= _sc.RANGE[family][0] and (family, model, n, dev.index) not in _sc.CHECKED:
+        _sc.ensure(family, model, n, dev)
 
 
 def _need_gpu(t, name):
@@ -105,6 +113,7 @@ def siegel_dist_forward(z1, z2, model="upper", metric="riem", weights=None, eps=
     b, _, n, _ = z1.shape
     out = torch.empty(b, dtype=torch.float64, device=z1.device)
     vvd = torch.empty(b, n, dtype=torch.float64, device=z1.device) if return_vvd else None
+    _gate(_sc.SIEGEL_FWD, model, n, z1.device)
     w = _weights(metric, weights, n, z1.device)
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(z1.device)
@@ -143,6 +152,8 @@ def model_forward(table, triplets, model="upper", metric="riem", weights=None, s
         out = torch.empty(b, dtype=torch.float64, device=dev)
     if b == 0:
         return out
+    if n > 8:
+        _gate(_sc.SIEGEL_FWD, model, n, dev)
     w = _weights(metric, weights, n, dev) if metric == "wsum" else None
     sc_ptr = None
     if scale is not None:
@@ -201,6 +212,8 @@ class BatchedForward:
         self.keep = (table, list(batches), list(outs), weights, scale)
         self.dev = table.device
         self.n = table.shape[2]
+        if self.n > 8:
+            _gate(_sc.SIEGEL_FWD, model, self.n, self.dev)
         self.num_rows = table.shape[0]
         self.stride = stride or 2
         self.k = k
@@ -255,6 +268,7 @@ def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights
     go = grad_out.detach().to(torch.float64).contiguous()
     b, _, n, _ = z1.shape
     g1 = torch.empty_like(z1)
+    _gate(_sc.SIEGEL_BWD, model, n, z1.device)
     g2 = torch.empty_like(z2)
     w = _weights(metric, weights, n, z1.device)
     gw = torch.zeros(n, dtype=torch.float64, device=z1.device) if metric == "wsum" else None
@@ -282,6 +296,7 @@ def model_backward(table, triplets, grad_out, model="upper", metric="riem", weig
         tab = tab.contiguous()
     num_rows, _, n, _ = tab.shape
     b = triplets.shape[0]
+    _gate(_sc.SIEGEL_BWD, model, n, tab.device)
     if triplets.stride(1) != 1:
         triplets = triplets.contiguous()
     stride = triplets.stride(0) if b > 1 else triplets.shape[1]
@@ -321,6 +336,8 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
     b = triplets.shape[0]
     if b == 0:
         return loss
+    if n >= 7:
+        _gate(_sc.SIEGEL_BWD, model, n, tab.device)
     if triplets.stride(1) != 1:
         triplets = triplets.contiguous()
     stride = triplets.stride(0) if b > 1 else triplets.shape[1]
@@ -363,6 +380,8 @@ def model_loss_backward_rows(table, triplets, graph_dist, grad_rows, loss, model
     b = triplets.shape[0]
     if b == 0:
         return loss
+    if n >= 7:
+        _gate(_sc.SIEGEL_BWD, model, n, tab.device)
     _need_gpu(tab, "table"); _need_gpu(triplets, "triplets"); _need_gpu(graph_dist, "graph_dist"); _need_gpu(grad_rows, "grad_rows")
     if triplets.stride(1) != 1:
         triplets = triplets.contiguous()
@@ -429,6 +448,7 @@ def _rows(t, name):
 def egrad2rgrad(z, u, model):
     lib = _lib.load()
     z, u = _rows(z.detach(), "z"), _rows(u.detach(), "u")
+    _gate(_sc.SIEGEL_TABLE, model, z.shape[2], z.device)
     out = torch.empty_like(z)
     with torch.cuda.device(z.device):
         rc = lib.sympa_egrad2rgrad(z.data_ptr(), u.data_ptr(), z.shape[0], z.shape[2], MODEL_IDS[model], out.data_ptr(),
@@ -441,6 +461,7 @@ def tangent_sqnorm(z, u, model):
     """inner(z, u, u) per row (C-ABI sympa_tangent_sqnorm; upper_half.py:68-91 / bounded_domain.py:86-116) -> [b]."""
     lib = _lib.load()
     z, u = _rows(z.detach(), "z"), _rows(u.detach(), "u")
+    _gate(_sc.SIEGEL_TABLE, model, z.shape[2], z.device)
     out = torch.empty(z.shape[0], dtype=torch.float64, device=z.device)
     st = _status_buf(z.device)
     with torch.cuda.device(z.device):
@@ -454,6 +475,7 @@ def projx(z, model, eps=None, counter=None):
     """Returns projx(z); `counter` (int32[1] device tensor) += rows that were moved."""
     lib = _lib.load()
     z = _rows(z.detach(), "z")
+    _gate(_sc.SIEGEL_TABLE, model, z.shape[2], z.device)
     out = torch.empty_like(z)
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(z.device)
@@ -499,6 +521,11 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None,
     if not table.is_contiguous():
         raise ValueError("table must be contiguous for the in-place step")
     grad = _rows(grad.detach(), "grad")
+    if table.dtype != torch.float64 or table.shape != grad.shape:
+        raise ValueError(f"table must be a float64 tensor of the gradient's shape {tuple(grad.shape)}, got "
+                         f"{tuple(table.shape)} {table.dtype}")
+    if table.shape[2] >= 7:
+        _gate(_sc.SIEGEL_TABLE, model, table.shape[2], table.device)
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(table.device)
     with torch.cuda.device(table.device):
@@ -524,6 +551,8 @@ def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None
     tab = table.detach()
     tab = tab if tab.is_contiguous() else tab.contiguous()
     num_rows, n = tab.shape[0], tab.shape[2]
+    if n > 8:
+        _gate(_sc.SIEGEL_FWD, model, n, tab.device)
     row_count = num_rows - row_begin if row_count is None else int(row_count)
     if out is None:
         out = torch.empty(row_count, num_rows, dtype=torch.float64, device=tab.device)
@@ -577,6 +606,7 @@ def spd_dist_forward(x, y, flags=0):
     if x.dtype != torch.float64 or x.shape != y.shape or x.dim() != 3 or x.shape[1] != x.shape[2]:
         raise ValueError(f"expected two float64 [b,n,n] tensors, got {tuple(x.shape)} and {tuple(y.shape)}")
     x, y = x.detach().contiguous(), y.detach().contiguous()
+    _gate(_sc.SPD_FWD, "spd", x.shape[1], x.device)
     out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
     st = _status_buf(x.device)
     with torch.cuda.device(x.device):
@@ -605,6 +635,7 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, fla
         out = torch.empty(b, dtype=torch.float64, device=tab.device)
     if b == 0:
         return out
+    _gate(_sc.SPD_FWD, "spd", tab.shape[1], tab.device)
     sc = None
     if scale is not None:
         sc = scale.detach().reshape(-1)[:1].to(device=tab.device, dtype=torch.float64).contiguous()
@@ -635,6 +666,7 @@ def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale
     y = y if y.is_contiguous() else y.contiguous()
     n = x.shape[1]
     dev = x.device
+    _gate(_sc.SPD_BWD, "spd", n, dev)
     if triplets is not None:
         if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
             raise TypeError("triplets must be an int64 [b, >=2] tensor")
@@ -692,6 +724,15 @@ def spd_loss_backward(table, triplets, grad_table, grad_out=None, graph_dist=Non
     out = torch.empty(b, dtype=torch.float64, device=dev) if want_out else None
     if b == 0:
         return out
+    _gate(_sc.SPD_BWD, "spd", n, dev)
+    if n < 3 or (flags & FLAG_GENERIC) or lib.sympa_get_instance_fallback(_sc.SPD_BWD, 0, n):
+        # no one-lane kernel has the scatter inside: per-pair rows, then the coalesced scatter-add (two launches)
+        rows, out = spd_backward_rows(tab, tab, triplets, grad_out=grad_out, graph_dist=graph_dist, scale=scale,
+                                      scale_coef=scale_coef, loss_scale=loss_scale, loss=loss, grad_scale=grad_scale,
+                                      want_out=want_out, flags=flags)
+        idx = torch.cat((triplets[:, 0], triplets[:, 1])).contiguous()
+        scatter_add_flat_rows_(grad_table, rows[:2 * b].reshape(2 * b, -1), idx)
+        return out
     stride = triplets.stride(0) if b > 1 else triplets.shape[1]
     go = None if grad_out is None else grad_out.detach().to(torch.float64).contiguous()
     gd = None if graph_dist is None else graph_dist.detach().to(torch.float64).contiguous()
@@ -743,6 +784,7 @@ def _spd_rows(t, name):
 def spd_egrad2rgrad(x, u):
     lib = _lib.load()
     x, u = _spd_rows(x.detach(), "x"), _spd_rows(u.detach(), "u")
+    _gate(_sc.SPD_TABLE, "spd", x.shape[1], x.device)
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         rc = lib.sympa_spd_egrad2rgrad(x.data_ptr(), u.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream())
@@ -769,6 +811,10 @@ def spd_rsgd_step_(table, grad, lr, weight_decay=0.0, clip_sqnorm=None, max_norm
     if not table.is_contiguous():
         raise ValueError("table must be contiguous for the in-place step")
     grad = _spd_rows(grad.detach(), "grad")
+    if table.dtype != torch.float64 or table.dim() != 3 or table.shape != grad.shape:
+        raise ValueError(f"table must be a float64 [N, n, n] tensor of the gradient's shape {tuple(grad.shape)}, got "
+                         f"{tuple(table.shape)} {table.dtype}")
+    _gate(_sc.SPD_TABLE, "spd", table.shape[1], table.device)
     st = _status_buf(table.device)
     with torch.cuda.device(table.device):
         rc = lib.sympa_spd_rsgd_step(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[1], float(lr),

@@ -15,6 +15,8 @@ from sympa_amd.manifolds.spd import SymmetricPositiveDefinite
 
 
 class RiemannianSGD(torch.optim.Optimizer):
+    graph_capturable = True      # step() keeps no host-side state that changes between calls (sympa_amd.train_step)
+
     def __init__(self, params, lr, weight_decay=0.0, stabilize=None):
         if lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
@@ -54,6 +56,8 @@ class RiemannianSGD(torch.optim.Optimizer):
                     continue
                 manifold = getattr(p, "manifold", None)
                 if isinstance(manifold, SymmetricPositiveDefinite) and p.is_cuda:
+                    if p.dtype != torch.float64:
+                        raise TypeError("the spd table must be float64 (config.py:17-18)")
                     # geoopt's SPD step: retr(x, -lr x sym(g + wd x) x), one kernel over the table
                     ops.spd_rsgd_step_(p.data, p.grad, lr, wd, clip_sqnorm=sq,
                                        max_norm=self.clip_max_norm if sq is not None else None)
@@ -91,6 +95,7 @@ class RiemannianAdam(torch.optim.Optimizer):
     (SiegelManifold.transp returns the vector unchanged, siegel_manifold.py:142-154).  egrad2rgrad, inner and retr
     (= projx(x + u)) are HIP kernels over the table rows; the moment updates are elementwise torch ops on the device.
     Parameters without a manifold get the ordinary Adam update.  amsgrad is not built."""
+    graph_capturable = False     # bias corrections and the step count live on the host and change every step
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, stabilize=None):
         if amsgrad:

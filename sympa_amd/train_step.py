@@ -13,6 +13,11 @@ from sympa_amd import ops
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, batch_size, max_grad_norm, device):
+        # the capture bakes every host-side scalar of the optimiser's step in as an immediate: only optimisers whose step has
+        # no host state that changes from step to step may be captured (RiemannianAdam's bias corrections and step count do)
+        if not getattr(optimizer, "graph_capturable", False):
+            raise TypeError(f"{type(optimizer).__name__} cannot be captured in a hipGraph (its step() changes host-side state "
+                            "every call); use sympa_amd.optim.RiemannianSGD or run the step eagerly")
         self.model, self.opt = model, optimizer
         self.batch_size, self.max_grad_norm = int(batch_size), float(max_grad_norm)
         self.ids = torch.zeros(self.batch_size, 2, dtype=torch.int64, device=device)

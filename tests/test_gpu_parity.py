@@ -229,7 +229,7 @@ def test_generic_dims_fallback_kernel(dev, model, n):
         assert rel_err(got, so.manifold_dist(model, z1, z2, metric)) < 1e-8, (model, n, metric)
 
 
-@pytest.mark.parametrize("n", [9, 10, 13, 16])
+@pytest.mark.parametrize("n", list(range(9, 17)))      # EVERY instantiation of the layout
 @pytest.mark.parametrize("model", MODELS)
 def test_dims_9_to_16_cooperative_kernel(dev, model, n):
     """9 <= n <= 16: sixteen lanes per pair (csrc/siegel_coop.hpp), n < 16 padded with the point i I (upper) / 0 (bounded).
@@ -514,3 +514,144 @@ def test_all_pairs_symmetric_mode_of_the_pairwise_kernels(dev, model, n):
             assert torch.equal(sym[iu[0], iu[1]], both[iu[0], iu[1]])      # on which pairs share a wave)
         else:
             assert rel_err(sym[iu[0], iu[1]].cpu(), both[iu[0], iu[1]].cpu()) < 1e-11
+
+
+def test_fused_multi_batch_kernel_against_the_reference_golden_directly(dev):
+    """The headline kernel (siegel_dist_multi_kernel behind SYMPA_FLAG_FUSE) against the imported reference's
+    Model.forward outputs themselves, not only through its bit-identity with the single-step kernel: the golden batch
+    cut into ragged pieces that one fused launch evaluates together."""
+    from sympa_amd import ops
+    g = np.load(f"{GOLDEN}/model_forward.npz")
+    trip = torch.from_numpy(g["triplets"]).to(dev)
+    b = trip.shape[0]
+    cuts = [0, 1, 7, b // 3, b // 3 + 65, b]
+    for model in MODELS:
+        table = T(g[f"table_{model}"]).to(dev)
+        for scale, coef in ((1.0, 1.0), (3.0, 2.0)):
+            sc = torch.tensor([scale], device=dev)
+            batches = [trip[a:e].contiguous() for a, e in zip(cuts[:-1], cuts[1:])]
+            outs = [torch.empty(t.shape[0], dtype=torch.float64, device=dev) for t in batches]
+            ops.BatchedForward(table, batches, outs, model, "riem", None, sc, coef, flags=ops.FLAG_FUSE).run()
+            ops.check_status(dev)
+            assert rel_err(torch.cat(outs).cpu(), g[f"{model}__scale{scale}_coef{coef}"]) < TOL
+
+
+def _model(manifold, metric, dims, num_points, dev, table=None, scale_init=1.0, scale_coef=1.0):
+    from sympa_amd.model import Model
+
+    class A:
+        pass
+    A.manifold, A.metric, A.dims, A.num_points = manifold, metric, dims, num_points
+    A.scale_coef, A.scale_init, A.train_scale = scale_coef, scale_init, False
+    m = Model(A)
+    if table is not None:
+        with torch.no_grad():
+            m.embeddings.embeds.data = table.clone()
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("model,metric,n", [("upper", "riem", 4), ("bounded", "finf", 4), ("upper", "wsum", 3),
+                                            ("upper", "riem", 8), ("bounded", "fone", 10), ("spd", "riem", 5)])
+def test_model_forward_batches_equals_one_forward_per_batch(dev, model, metric, n):
+    """Model.forward_batches (one C call, fused multi-batch launches for dims <= 8) == the loop of Runner.evaluate
+    (runner.py:126-131: one forward() per batch), bit for bit for n <= 4; list form, plan form, cached plan, outputs
+    handed in, empty and ragged batches."""
+    from sympa_amd import data, ops
+    N = 300
+    g = torch.Generator().manual_seed(11)
+    table = data.spd_table(N, n, seed=3) if model == "spd" else points(model, N, n, 0.4, g)
+    m = _model(model, metric, n, N, dev, table, scale_init=1.7, scale_coef=2.0)
+    sizes = [257, 0, 1, 64, 1000, 33] + [97] * 40          # 46 batches: two fused launches (32 + 14)
+    batches = [torch.randint(0, N, (s, 3), generator=g).to(dev) for s in sizes]
+    with torch.no_grad():
+        want = [m(t) for t in batches]
+    got = m.forward_batches(batches)
+    ops.check_status(dev)
+    exact = model != "spd" and n <= 4
+    for a, b_ in zip(got, want):
+        assert a.shape == b_.shape
+        assert torch.equal(a, b_) if exact else torch.allclose(a, b_, rtol=1e-11, atol=1e-13)
+    assert m.forward_batches(batches)[0].data_ptr() == got[0].data_ptr()          # cached plan, same outputs
+    plan = m.prepare_batches(batches[:5])
+    got2 = m.forward_batches(plan)
+    assert all(torch.equal(a, b_) if exact else torch.allclose(a, b_, rtol=1e-11, atol=1e-13)
+               for a, b_ in zip(got2, want[:5]))
+    outs = [torch.full((s,), -1.0, dtype=torch.float64, device=dev) for s in sizes]
+    got3 = m.forward_batches(batches, outs)
+    assert all(a.data_ptr() == o.data_ptr() for a, o in zip(got3, outs) if o.numel())
+    assert all((o >= 0).all() for o in outs)
+    # the parameters are read through their device pointers: an in-place update is seen by a cached plan
+    with torch.no_grad():
+        m.scale.mul_(2.0)
+        want2 = m(batches[4])
+    assert torch.allclose(m.forward_batches(batches)[4], want2, rtol=1e-12, atol=0)
+
+
+def test_model_evaluate_equals_the_reference_loop_on_configs1_triplets(dev):
+    """Model.evaluate == Runner.evaluate (runner.py:124-135) with the oracle as the model, on every one of the 596 778
+    (i < j, d) triplets of configs[1]'s graph (balanced tree b = 3, h = 6; batch 8 192): per-triplet distortions
+    |d_m - d_g| / d_g (metrics.py:21), their mean, and the per-triplet distances themselves."""
+    from statistics import mean
+    from sympa_amd import data, ops
+    trip, id2node = data.graph_triplets(data.named_graph("tree-b3-h6"))
+    assert trip.shape == (596778, 3)
+    N, n, batch = len(id2node), 4, 8192
+    table = data.trained_like_table(N, n, seed=5)
+    m = _model("upper", "riem", n, N, dev, table)
+    ids, gd = trip[:, :2].contiguous().to(dev), trip[:, 2].to(torch.float64).to(dev)
+    got = m.evaluate(ids, gd, batch)
+    ops.check_status(dev)
+    dists = m._eval_plan[2].cpu()
+    # the reference's loop: forward per batch, extend a python list, statistics.mean
+    total = []
+    torch.set_num_threads(8)
+    want_d = torch.empty(trip.shape[0], dtype=torch.float64)
+    for s in range(0, trip.shape[0], 65536):
+        want_d[s:s + 65536] = so.model_forward(table, trip[s:s + 65536], "upper", "riem")
+    for s in range(0, trip.shape[0], batch):
+        d = want_d[s:s + batch]
+        gdb = trip[s:s + batch, 2].to(torch.float64)
+        total.extend((torch.abs(d - gdb) / gdb).tolist())
+    assert rel_err(dists, want_d) < TOL
+    assert abs(got - mean(total)) < 1e-12 * max(1.0, mean(total))
+    # second call: cached plan, same answer; [T,3] triplets work as well
+    assert m.evaluate(ids, gd, batch) == got
+    assert abs(m.evaluate(trip.to(dev), gd, batch) - got) < 1e-15
+
+
+def test_selfcheck_gate_passes_for_every_instantiation_and_falls_back_when_told(dev):
+    """sympa_amd/selfcheck.py: every (family, model, n) of the lanes-per-pair layout agrees with the one-lane kernel on this
+    build (the gate that runs on first use in production); and an instantiation marked through the C-ABI registry really
+    is served by the one-lane kernel (same numbers as FLAG_GENERIC, bit for bit)."""
+    from sympa_amd import _lib, ops, selfcheck
+    assert selfcheck.ENABLED
+    failures = selfcheck.check_all(dev)
+    assert failures == [], failures
+    assert len(selfcheck.CHECKED) >= 2 * 8 + 2 * 10 + 2 * 10 + 11 + 14 + 14
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    z1, z2 = points("upper", 130, 11, 0.3, g).to(dev), points("upper", 130, 11, 0.3, g).to(dev)
+    fast = ops.siegel_dist_forward(z1, z2)
+    generic = ops.siegel_dist_forward(z1, z2, flags=ops.FLAG_GENERIC)
+    assert lib.sympa_set_instance_fallback(selfcheck.SIEGEL_FWD, 0, 11, 1) == 0
+    try:
+        assert lib.sympa_get_instance_fallback(selfcheck.SIEGEL_FWD, 0, 11) == 1
+        routed = ops.siegel_dist_forward(z1, z2)
+    finally:
+        lib.sympa_set_instance_fallback(selfcheck.SIEGEL_FWD, 0, 11, 0)
+    assert torch.equal(routed, generic) and rel_err(fast.cpu(), generic.cpu()) < 1e-10
+    assert lib.sympa_set_instance_fallback(9, 0, 11, 1) != 0          # no such family
+    # spd: a routed backward-with-scatter goes through rows + scatter-add
+    from sympa_amd import data
+    table = data.spd_table(60, 7, scale=0.3, seed=3).to(dev)
+    trip = torch.randint(0, 60, (500, 2), generator=g).to(dev)
+    gd = torch.ones(500, dtype=torch.float64, device=dev)
+    a, b_ = torch.zeros_like(table), torch.zeros_like(table)
+    la, lb = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    ops.spd_loss_backward(table, trip, a, graph_dist=gd, loss=la)
+    lib.sympa_set_instance_fallback(selfcheck.SPD_BWD, 0, 7, 1)
+    try:
+        ops.spd_loss_backward(table, trip, b_, graph_dist=gd, loss=lb)
+    finally:
+        lib.sympa_set_instance_fallback(selfcheck.SPD_BWD, 0, 7, 0)
+    assert float((a - b_).abs().max()) < 1e-9 * float(a.abs().max()) and abs(float(la - lb)) < 1e-9 * float(la)

@@ -196,3 +196,35 @@ def test_two_rank_gradient_exchange_dense_and_touched_rows():
     # below the dense table
     assert results["rows_bytes"] <= results["rows_bound"] * 1.2 + 64
     assert results["rows_bytes"] < results["dense_bytes"]
+
+
+def _run_bench_self_launch(extra_env, argv):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["SYMPA_BENCH_WORKER"] = os.path.join(root, "tests", "bench_stub_worker.py")
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=300)
+
+
+def test_bench_gpus_n_launches_its_own_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus 2 --steps K --warmup W` (the driver's command shape, no torchrun around it) starts the
+    ranks itself as a child torch.distributed.run -- before any GPU call: this container has no GPU and the parent
+    never needs one -- and relays rank 0's single JSON line.  The rank body is a gloo stub here."""
+    import json
+    p = _run_bench_self_launch({}, ["--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["steps"] == 20 and rec["warmup"] == 5
+    assert rec["max_over_ranks"] == 2.0
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    p = _run_bench_self_launch({"STUB_FAIL_RANK": "1"}, ["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert p.returncode != 0
+    assert p.stdout.decode().strip() == "" or "stub" in p.stdout.decode()

@@ -113,7 +113,7 @@ def test_gpu_spd16_cooperative_kernel_against_oracle_and_generic_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [6, 7, 8, 11, 12, 15])
+@pytest.mark.parametrize("n", list(range(6, 17)))     # EVERY instantiation of the layout
 def test_gpu_spd_padded_cooperative_kernel(n):
     """6 <= n < 16 runs the sixteen-lanes-per-pair kernel on diag(X, I), diag(Y, I); FLAG_GENERIC forces the runtime-n
     kernel.  Both read only the upper triangle."""

@@ -25,13 +25,9 @@ from sympa_amd.train_step import GraphedTrainStep  # noqa: E402
 
 
 def evaluate(model, ids, gd, batch):
-    """Average distortion |d_manifold - d_graph| / d_graph (sympa/metrics.py:21, runner.py:124-135)."""
-    tot = torch.zeros(1, dtype=torch.float64, device=ids.device)
-    with torch.no_grad():
-        for s in range(0, ids.shape[0], batch):
-            d = model(ids[s:s + batch])
-            tot += ((d - gd[s:s + batch]).abs() / gd[s:s + batch]).sum()
-    return float(tot) / ids.shape[0]
+    """Average distortion |d_manifold - d_graph| / d_graph (sympa/metrics.py:21, runner.py:124-135): Model.evaluate hands
+    the batches of the split to the fused multi-batch kernel as one list (one C call per evaluation)."""
+    return model.evaluate(ids, gd, batch)
 
 
 def train(args, log=print):
