@@ -270,6 +270,56 @@ int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows,
                             double weight_decay, double eps, const double* total_sqnorm, double max_norm,
                             int32_t* projected_count, int32_t* status, void* stream);
 
+/* The backward half of a training step inside a replayed hipGraph (sympa/runner.py:98-105), dims 1..8.  Like
+ * sympa_model_loss_backward (grad_table given: fp64-atomic scatter into the dense gradient) or
+ * sympa_model_loss_backward_rows (grad_rows [2 b, 2, n, n] given: rows [0, b) belong to src, [b, 2 b) to dst), plus
+ *   step_counter   device int64 c (may be NULL = 0): the launch processes pairs [c b, (c + 1) b) of src / dst / graph_dist,
+ *                  i.e. an epoch's shuffled triplets (train.py:105-110) stay in ONE buffer, sympa_rsgd_step_fused increments
+ *                  c, and the replayed graph needs no per-step copy of the batch;
+ *   wave_partials  (rows form; may be NULL) [ceil(b / 64)][2 + n] fp64, WRITTEN: per-wavefront sums of the loss, of
+ *                  d loss / d scale and of d loss / d w_k, which sympa_segment_sum_rows adds to loss / grad_scale / grad_w in
+ *                  a fixed order -- together with the row sums below this makes a training step bitwise reproducible
+ *                  (the reference's CPU autograd is; fp64 atomics are not).  With wave_partials loss / grad_* are untouched. */
+int sympa_model_train_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                               const int64_t* dst, int64_t dst_stride, const double* graph_dist, int64_t b,
+                               const int64_t* step_counter, int model, int metric, const double* metric_w, double eps,
+                               const double* scale, double scale_coef, double loss_scale, double* loss, double* grad_table,
+                               double* grad_rows, double* grad_w, double* grad_scale, double* wave_partials, int32_t* status,
+                               int flags, void* stream);
+
+/* Deterministic counterpart of sympa_scatter_add_flat_rows ("sort-by-row + segmented sum"):
+ *   grad_table[r] (= | +=, by `accumulate`) alpha * sum_{p in [rowptr[r], rowptr[r + 1])} rows[order[p]]     r = 0 .. num_rows - 1
+ * added in the order of `order`, no atomics: every element is written by exactly one thread, rows nobody touched are
+ * written as 0 when accumulate = 0 (no zeroing pass).  order: int32 slot numbers (rows of `rows`, row_doubles each)
+ * sorted by table row -- stable, so the order inside a row is the batch order; rowptr: int32 [num_rows + 1].  With
+ * step_counter c (device int64, may be NULL) the lists of batch c are used: order + c * order_stride, rowptr + c *
+ * (num_rows + 1) (sympa_amd/train_step.py builds them for a whole epoch with one sort).  wave_partials (may be NULL): see
+ * sympa_model_train_backward; partial_stride = 2 + n (doubles per wavefront), num_weights = n for the wsum metric, else 0
+ * (then grad_w may be NULL); grad_scale may be NULL. */
+int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32_t* rowptr, int64_t num_rows, int row_doubles,
+                           int64_t order_stride, const int64_t* step_counter, double alpha, int accumulate, double* grad_table,
+                           const double* wave_partials, int64_t num_waves, int partial_stride, int num_weights, double* loss,
+                           double* grad_scale, double* grad_w, void* stream);
+
+/* The optimiser side of one training step as ONE launch (sympa/runner.py:113-118: clip_grad_norm_(parameters, max_norm),
+ * optimizer.step(), zero_grad()), dims 1..6, tables of at most (CUs x 256) rows (a grid barrier inside: every block must be
+ * resident; otherwise SYMPA_ERR_UNSUPPORTED_DIMS -- use sympa_sqnorm_accum + sympa_rsgd_step_clipped + sympa_sgd_step_clipped):
+ *   total = ||grad||^2 + sum_k ||extra_grad[k]||^2, summed in a fixed order (bitwise reproducible);
+ *   coef = max_norm > 0 ? min(1, max_norm / (sqrt(total) + 1e-6)) : 1;
+ *   table <- retr(table, -lr * egrad2rgrad(table, coef * grad + weight_decay * table))           (sympa_rsgd_step)
+ *   extra_param[k] <- extra_param[k] - extra_lr[k] * (coef * extra_grad[k] + extra_weight_decay[k] * extra_param[k])
+ *   zero_grads != 0: grad and extra_grad[k] are zeroed (the next step's backward accumulates into them);
+ *   step_counter (device int64, may be NULL) += 1: the batch index the next sympa_model_loss_backward_indexed call reads.
+ * extra_*: up to 2 parameters without a manifold (the model's scale, the wsum weights), 1..64 elements each.
+ * workspace: sympa_rsgd_step_fused_workspace_bytes(num_rows) bytes of device memory, ZERO before the first call (the
+ * kernel leaves it ready for the next one); one workspace per concurrently running step. */
+int64_t sympa_rsgd_step_fused_workspace_bytes(int64_t num_rows);
+int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
+                          double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
+                          const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
+                          void* workspace, int64_t workspace_bytes, int64_t* step_counter, int32_t* projected_count,
+                          int32_t* status, void* stream);
+
 /* ---- SPD model (manifold "spd": geoopt.manifolds.SymmetricPositiveDefinite, sympa/embeddings.py:6,70-72,142) ----
  * Points are [n, n] fp64 symmetric positive definite matrices (upper triangle read), n <= 16.
  * dist = || log(x^-1/2 y x^-1/2) ||_F  (geoopt's default affine-invariant metric; geoopt is absent from the

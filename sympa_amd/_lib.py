@@ -35,6 +35,10 @@ SYMBOLS = (
     "sympa_sqnorm_accum",
     "sympa_sgd_step_clipped",
     "sympa_rsgd_step_clipped",
+    "sympa_model_train_backward",
+    "sympa_segment_sum_rows",
+    "sympa_rsgd_step_fused_workspace_bytes",
+    "sympa_rsgd_step_fused",
     "sympa_spd_dist_fwd",
     "sympa_spd_model_forward",
     "sympa_scatter_add_flat_rows",
@@ -144,6 +148,27 @@ def load():
     lib.sympa_projx.restype = ctypes.c_int
     lib.sympa_projx.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, _c_double_p,
                                 _c_i32_p, _c_i32_p, ctypes.c_void_p]
+    lib.sympa_model_train_backward.restype = ctypes.c_int
+    lib.sympa_model_train_backward.argtypes = [
+        _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
+        ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p,
+        ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+        _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+    ]
+    lib.sympa_segment_sum_rows.restype = ctypes.c_int
+    lib.sympa_segment_sum_rows.argtypes = [
+        _c_double_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_double, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
+        _c_double_p, _c_double_p, ctypes.c_void_p,
+    ]
+    lib.sympa_rsgd_step_fused_workspace_bytes.restype = ctypes.c_int64
+    lib.sympa_rsgd_step_fused_workspace_bytes.argtypes = [ctypes.c_int64]
+    lib.sympa_rsgd_step_fused.restype = ctypes.c_int
+    lib.sympa_rsgd_step_fused.argtypes = [
+        _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+        ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _c_i32_p, _c_i32_p, ctypes.c_void_p,
+    ]
     lib.sympa_rsgd_step.restype = ctypes.c_int
     lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]

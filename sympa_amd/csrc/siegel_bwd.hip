@@ -15,7 +15,10 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     // (tools/bwd_coop_ab_small.py, per 262 144 pairs): the fused step at n = 8 (upper 1.78 -> 1.49 ms, bounded 2.59 -> 1.99 ms),
     // bounded n = 8 dense rows (2.51 -> 2.15 ms), bounded n = 7 fused (1.70 -> 1.56 ms).  SYMPA_FLAG_COOP forces it for
     // dims 5..8, SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels.
-    const bool one_lane = (a.f.flags & SYMPA_FLAG_GENERIC) || instance_fallback(SYMPA_FAMILY_SIEGEL_BWD, model, n);
+    // the training graph's batch window and the deterministic per-wave sums exist in the one-pair-per-lane kernels only
+    const bool graph_mode = a.f.batch_counter != nullptr || a.wave_partials != nullptr;
+    if (graph_mode && n > 8) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "step_counter / wave_partials: dims 1..8");
+    const bool one_lane = (a.f.flags & SYMPA_FLAG_GENERIC) || instance_fallback(SYMPA_FAMILY_SIEGEL_BWD, model, n) || graph_mode;
     if (n >= 5 && n <= 8 && !one_lane) {
         const bool bounded = model == SYMPA_MODEL_BOUNDED;
         const bool faster = (n == 8 && (scatter || bounded)) || (n == 7 && bounded && scatter);
@@ -135,6 +138,53 @@ int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, cons
     a.loss = loss;
     a.loss_scale = loss_scale;
     return launch_bwd(a, n, model, true, stream);
+}
+
+int sympa_model_train_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
+                               const int64_t* dst, int64_t dst_stride, const double* graph_dist, int64_t b,
+                               const int64_t* step_counter, int model, int metric, const double* metric_w, double eps,
+                               const double* scale, double scale_coef, double loss_scale, double* loss, double* grad_table,
+                               double* grad_rows, double* grad_w, double* grad_scale, double* wave_partials, int32_t* status,
+                               int flags, void* stream) {
+    if (b > 0 && (src == nullptr || dst == nullptr || graph_dist == nullptr))
+        return fail(SYMPA_ERR_BAD_ARG, "null index / graph-distance buffer");
+    if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    if ((grad_table == nullptr) == (grad_rows == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "give grad_table or grad_rows, not both");
+    if (wave_partials != nullptr && grad_rows == nullptr)
+        return fail(SYMPA_ERR_BAD_ARG, "wave_partials belongs to the rows form (the scatter form is atomic anyway)");
+    BwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.f.base1 = table;
+    a.f.base2 = table;
+    a.f.idx1 = src;
+    a.f.idx2 = dst;
+    a.f.idx1_stride = src_stride;
+    a.f.idx2_stride = dst_stride;
+    a.f.num_rows = num_rows;
+    a.f.b = b;
+    a.f.metric_w = metric_w;
+    a.f.scale = scale;
+    a.f.inv_scale_coef = 1.0 / scale_coef;
+    a.f.inv_eps = 1.0 / eps;
+    a.f.status = status;
+    a.f.metric = metric;
+    a.f.flags = flags;
+    a.f.batch_counter = step_counter;
+    a.gw = grad_w;
+    a.gscale = grad_scale;
+    a.graph_dist = graph_dist;
+    a.loss = loss;
+    a.loss_scale = loss_scale;
+    a.wave_partials = wave_partials;
+    if (grad_table != nullptr) {
+        a.g1 = grad_table;
+        a.g2 = grad_table;
+        return launch_bwd(a, n, model, true, stream);
+    }
+    a.g1 = grad_rows;
+    a.g2 = grad_rows + b * 2 * (int64_t)n * n;
+    return launch_bwd(a, n, model, false, stream);
 }
 
 int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n, const int64_t* src,

@@ -17,6 +17,9 @@ struct BwdArgs {
     const double* graph_dist;   // fused loss: [b] graph distances (then `go` is ignored), or null
     double* loss;               // fused loss: [1] accumulated sum |(d/g)^2 - 1| * loss_scale
     double loss_scale;
+    double* wave_partials;      // deterministic mode: [waves][2 + n] per-wave sums (loss, d loss / d scale, d loss / d w_k) are
+                                // WRITTEN here instead of being added to loss / gscale / gw with atomics; a later kernel
+                                // (sympa_segment_sum_rows) adds them up in a fixed order
 };
 
 // (Scattering only the n(n+1) upper-triangle entries of the symmetric rows and mirroring afterwards was
@@ -77,6 +80,31 @@ SYMPA_UNROLL
     }
 }
 
+// Per-pair gradient rows ([b, 2, n, n]: row i = pair i) written through the same tile: the 64 rows of a wave are contiguous
+// in memory, so every store instruction covers 512 contiguous bytes instead of one 8-byte word in each of 64 rows.
+template <int N>
+__device__ __forceinline__ void store_rows_coalesced(const sympa::CMat<N>& g, double* __restrict__ out_wave, double* __restrict__ tile,
+                                                     const bool zero, const int live_pairs) {
+    constexpr int ROWD = ScatterTile<N>::ROWD, PITCH = ScatterTile<N>::PITCH;
+    static_assert(!ScatterTile<N>::BY_PLANE, "whole rows through the tile: n <= 6");
+    const int lane = threadIdx.x & 63;
+    wave_lds_fence();
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            tile[lane * PITCH + i * N + j] = zero ? 0.0 : g.re[i][j];
+            tile[lane * PITCH + N * N + i * N + j] = zero ? 0.0 : g.im[i][j];
+        }
+    wave_lds_fence();
+#pragma unroll 4
+    for (int t = 0; t < ROWD; ++t) {
+        const int gidx = t * 64 + lane;
+        const int p = gidx / ROWD, e = gidx - p * ROWD;
+        if (p < live_pairs) __builtin_nontemporal_store(tile[p * PITCH + e], out_wave + gidx);
+    }
+}
+
 // n >= 7: the scatter tile of a wave is 25-33 KB (one plane at a time), so a block is one wave and four blocks share
 // a CU; the adjoint's working
 // set (E, H, its eigenvectors, the adjoints of all of them) does not fit the register file and spills to scratch.
@@ -95,10 +123,18 @@ template <int N, int MODEL, bool SCATTER>
 __global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArgs a) {
     constexpr int BLOCK = bwd_block<N>();
     constexpr int GATHER_SLOTS = DmaTile<N>::ENABLED ? DmaTile<N>::WAVE_SLOTS_LOW : Tile<N>::WAVE_SLOTS;
-    constexpr int SCATTER_SLOTS = SCATTER ? (ScatterTile<N>::WAVE_DOUBLES + 1) / 2 : 1;
+    constexpr bool ROWS_TILE = !SCATTER && !ScatterTile<N>::BY_PLANE;      // per-pair rows leave through the tile too (n <= 6)
+    constexpr int SCATTER_SLOTS = (SCATTER || ROWS_TILE) ? (ScatterTile<N>::WAVE_DOUBLES + 1) / 2 : 1;
     constexpr int WAVE_SLOTS = GATHER_SLOTS > SCATTER_SLOTS ? GATHER_SLOTS : SCATTER_SLOTS;
     __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
-    const DistArgs& f = a.f;
+    DistArgs f = a.f;
+    const double* graph_dist = a.graph_dist;
+    if (f.batch_counter != nullptr) {            // the training graph's batch window (see DistArgs)
+        const int64_t off = f.batch_counter[0] * f.b;
+        f.idx1 += off * f.idx1_stride;
+        f.idx2 += off * f.idx2_stride;
+        if (graph_dist != nullptr) graph_dist += off;
+    }
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < f.b;
     const int64_t ii = live ? i : f.b - 1;
@@ -142,8 +178,8 @@ SYMPA_UNROLL
     const double dist = sympa::pair_backward<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, 1.0, g1, g2, gw, st);
     const bool bad = (st & sympa::ST_BAD_INDEX) != 0;
     double go = 0.0, loss_i = 0.0;
-    if (a.graph_dist != nullptr) {   // AverageDistortionLoss (losses.py:10-19): sum |(d/g)^2 - 1|
-        const double gd = live ? a.graph_dist[i] : 1.0;
+    if (graph_dist != nullptr) {   // AverageDistortionLoss (losses.py:10-19): sum |(d/g)^2 - 1|
+        const double gd = live ? graph_dist[i] : 1.0;
         const double ratio = dist * sc / gd;
         const double e = ratio * ratio - 1.0;
         loss_i = (live && !bad) ? fabs(e) * a.loss_scale : 0.0;
@@ -175,8 +211,15 @@ SYMPA_UNROLL
             scatter_add_rows<N>(g1, (int)r1, a.g1, dtile, live && !bad);
             scatter_add_rows<N>(g2, (int)r2, a.g2, dtile, live && !bad);
         }
-    } else if (live) {
+    } else if constexpr (ROWS_TILE) {
         // per-pair rows (a pair with an out-of-range index contributes zeros, like the scatter form skips it)
+        double* dtile = reinterpret_cast<double*>(tile);
+        const int64_t wave_first = i - (threadIdx.x & 63);
+        const int64_t left = f.b - wave_first;
+        const int live_pairs = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+        store_rows_coalesced<N>(g1, a.g1 + wave_first * ROW, dtile, bad, live_pairs);
+        store_rows_coalesced<N>(g2, a.g2 + wave_first * ROW, dtile, bad, live_pairs);
+    } else if (live) {
 SYMPA_UNROLL
         for (int r = 0; r < N; ++r)
 SYMPA_UNROLL
@@ -187,7 +230,22 @@ SYMPA_UNROLL
                 a.g2[i * ROW + N * N + r * N + c] = bad ? 0.0 : g2.im[r][c];
             }
     }
-    // reductions over the wave, one atomic per wave
+    // reductions over the wave: one atomic per wave, or (deterministic mode) the wave's sums stored for a fixed-order sum
+    if (a.wave_partials != nullptr) {
+        double* wp = a.wave_partials + (i >> 6) * (2 + N);
+        double x = loss_i;
+        double y = (live && !bad && sc_active) ? go * dist * f.inv_scale_coef : 0.0;
+SYMPA_UNROLL
+        for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
+        if ((threadIdx.x & 63) == 0) { wp[0] = x; wp[1] = y; }
+SYMPA_UNROLL
+        for (int k = 0; k < N; ++k) {
+            double w = (live && !bad && f.metric == sympa::METRIC_WSUM) ? gw[k] : 0.0;
+SYMPA_UNROLL
+            for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+            if ((threadIdx.x & 63) == 0) wp[2 + k] = w;
+        }
+    } else {
     if (a.gw != nullptr && f.metric == sympa::METRIC_WSUM) {
 SYMPA_UNROLL
         for (int k = 0; k < N; ++k) {
@@ -203,11 +261,12 @@ SYMPA_UNROLL
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
         if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.gscale, x);
     }
-    if (a.loss != nullptr && a.graph_dist != nullptr) {
+    if (a.loss != nullptr && graph_dist != nullptr) {
         double x = loss_i;
 SYMPA_UNROLL
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
         if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(a.loss, x);
+    }
     }
     if (f.status != nullptr) {
         const int flagged = (live && st != 0) ? 1 : 0;

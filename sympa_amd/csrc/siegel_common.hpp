@@ -36,6 +36,9 @@ struct DistArgs {
     int64_t ap_row0;
     int ap_sym;            // all-pairs mode over the FULL matrix using d(i, j) = d(j, i): pair p runs over the
                            // ap_cols (ap_cols + 1) / 2 pairs i <= j in row-major triangular order and is stored twice
+    const int64_t* batch_counter;   // training graph (backward, one pair per lane): device word c -> this launch processes
+                                    // pairs [c b, (c + 1) b) of idx1 / idx2 / graph_dist (an epoch's triplets stay in one buffer
+                                    // and the step kernel increments c: no per-step copy of the batch); null: off
 };
 
 #if defined(__HIPCC__)

@@ -116,8 +116,15 @@ __device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t firs
     }
 }
 
+// Blocks per CU the compiler must make room for (dims >= 5).  1: one 512-register wave per SIMD.  A/B hook
+// (tools/build_variant.sh -DSYMPA_FWD_BIG_BLOCKS=2: two 256-register waves per SIMD, the rest spilled to scratch).
+#ifndef SYMPA_FWD_BIG_BLOCKS
+#define SYMPA_FWD_BIG_BLOCKS 1
+#endif
+template <int N> constexpr int fwd_min_blocks() { return N >= 5 ? SYMPA_FWD_BIG_BLOCKS : 1; }
+
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
-__global__ __launch_bounds__(BLOCK) void siegel_dist_kernel(const DistArgs a) {
+__global__ __launch_bounds__(BLOCK, fwd_min_blocks<N>()) void siegel_dist_kernel(const DistArgs a) {
     __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
     dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * BLOCK, lds);
 }

@@ -58,6 +58,60 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_rows_kernel(const double* _
     }
 }
 
+// Deterministic counterpart of the atomic scatter: grad[r] (=|+=) alpha * sum of the per-pair gradient rows that belong to
+// table row r, added IN THE ORDER of a precomputed list (order[rowptr[r] .. rowptr[r + 1]) = the slots of row r in `rows`,
+// sorted once per epoch on the host side of the step).  One thread per (table row, element): consecutive lanes read
+// consecutive doubles of a slot row.  No atomics, every element of grad is written by exactly one thread, so two runs give
+// the same bits; untouched rows are written as 0 (accumulate = 0): no separate zeroing pass either.
+// The last block (when wave_partials is given) adds the per-wave sums of the loss, of d loss / d scale and of
+// d loss / d w_k that the backward kernel left (siegel_bwd_kernel.hpp) in a fixed order as well.
+__global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* __restrict__ rows, const int32_t* __restrict__ order,
+                                                                 const int32_t* __restrict__ rowptr, int64_t num_rows, int rowd,
+                                                                 int64_t order_stride, const int64_t* __restrict__ counter,
+                                                                 double alpha, int accumulate, double* __restrict__ grad,
+                                                                 const double* __restrict__ wave_partials, int64_t num_waves,
+                                                                 int quantities, int partial_stride, double* loss, double* gscale,
+                                                                 double* gw, unsigned row_blocks) {
+    __shared__ double red[BLOCK];
+    if (blockIdx.x >= row_blocks) {
+        // fixed-order sums of the per-wave partials: thread t takes waves t, t + 256, ...; then a tree over the block
+        for (int k = 0; k < quantities; ++k) {
+            double s = 0.0;
+            for (int64_t w = threadIdx.x; w < num_waves; w += BLOCK) s += wave_partials[w * partial_stride + k];
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int off = BLOCK / 2; off > 0; off >>= 1) {
+                if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                double* dst = (k == 0) ? loss : (k == 1 ? gscale : (gw != nullptr ? gw + (k - 2) : nullptr));
+                if (dst != nullptr) dst[0] += red[0];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int64_t c = counter != nullptr ? counter[0] : 0;
+    order += c * order_stride;
+    rowptr += c * (num_rows + 1);
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= num_rows * rowd) return;
+    const int64_t r = t / rowd;
+    const int e = (int)(t - r * rowd);
+    const int p0 = rowptr[r], p1 = rowptr[r + 1];
+    double s = 0.0;
+    int p = p0;
+    for (; p + 4 <= p1; p += 4) {       // four loads in flight, added in list order
+        const double v0 = rows[(int64_t)order[p] * rowd + e], v1 = rows[(int64_t)order[p + 1] * rowd + e];
+        const double v2 = rows[(int64_t)order[p + 2] * rowd + e], v3 = rows[(int64_t)order[p + 3] * rowd + e];
+        s = ((s + v0) + v1) + v2 + v3;
+    }
+    for (; p < p1; ++p) s += rows[(int64_t)order[p] * rowd + e];
+    s *= alpha;
+    grad[t] = accumulate ? grad[t] + s : s;
+}
+
 struct GateSlots {
     int* base = nullptr;
     void* stream[GATE_SLOTS];
@@ -215,6 +269,76 @@ int sympa_scatter_add_flat_rows(const double* rows, const int64_t* idx, int64_t 
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
+}
+
+int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32_t* rowptr, int64_t num_rows, int row_doubles,
+                           int64_t order_stride, const int64_t* step_counter, double alpha, int accumulate, double* grad_table,
+                           const double* wave_partials, int64_t num_waves, int partial_stride, int num_weights, double* loss,
+                           double* grad_scale, double* grad_w, void* stream) {
+    if (num_rows <= 0 || row_doubles < 1 || row_doubles > 2 * SYMPA_MAX_DIMS_GENERIC * SYMPA_MAX_DIMS_GENERIC)
+        return fail(SYMPA_ERR_BAD_ARG, "bad table shape");
+    if (rows == nullptr || order == nullptr || rowptr == nullptr || grad_table == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (num_rows * row_doubles > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "table too large for one launch");
+    if (wave_partials != nullptr && (num_waves < 0 || num_weights < 0 || partial_stride < 2 + num_weights || loss == nullptr ||
+                                     (num_weights > 0 && grad_w == nullptr)))
+        return fail(SYMPA_ERR_BAD_ARG, "bad partial-sum arguments");
+    const unsigned row_blocks = (unsigned)((num_rows * row_doubles + BLOCK - 1) / BLOCK);
+    const unsigned grid = row_blocks + (wave_partials != nullptr ? 1u : 0u);
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows, order,
+                       rowptr, num_rows, row_doubles, order_stride, step_counter, alpha, accumulate, grad_table, wave_partials,
+                       num_waves, 2 + num_weights, partial_stride, loss, grad_scale, grad_w, row_blocks);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
+                          double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
+                          const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
+                          void* workspace, int64_t workspace_bytes, int64_t* step_counter, int32_t* projected_count,
+                          int32_t* status, void* stream) {
+    if (num_rows <= 0 || table == nullptr || grad == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer / empty table");
+    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
+    if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
+    if (num_extra < 0 || num_extra > FUSED_MAX_EXTRA) return fail(SYMPA_ERR_BAD_ARG, "at most 2 plain parameters");
+    if (n < 1 || n > 6) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "fused step: dims 1..6 (one row per lane)");
+    const int64_t grid = (num_rows + BLOCK - 1) / BLOCK;
+    // the grid barrier needs every block resident at once: one block per CU is always possible
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return fail(SYMPA_ERR_BAD_ARG, "no device");
+    if (grid > cus) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "fused step: more row blocks than CUs (use sympa_rsgd_step_clipped)");
+    const int64_t need = sympa_rsgd_step_fused_workspace_bytes(num_rows);
+    if (workspace == nullptr || workspace_bytes < need) return fail(SYMPA_ERR_BAD_ARG, "workspace too small");
+    FusedStepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.table = table; a.grad = grad; a.rows = num_rows;
+    a.lr = lr; a.wd = weight_decay; a.eps = eps; a.max_norm = max_norm;
+    a.sync = reinterpret_cast<unsigned*>(workspace);
+    a.partial = reinterpret_cast<double*>(workspace) + 1;
+    for (int k = 0; k < num_extra; ++k) {
+        if (extra_param == nullptr || extra_grad == nullptr || extra_count == nullptr || extra_lr == nullptr ||
+            extra_weight_decay == nullptr || extra_param[k] == nullptr || extra_grad[k] == nullptr)
+            return fail(SYMPA_ERR_BAD_ARG, "null plain parameter");
+        if (extra_count[k] < 1 || extra_count[k] > 64) return fail(SYMPA_ERR_BAD_ARG, "plain parameters of 1..64 elements");
+        a.xp[k] = extra_param[k]; a.xg[k] = extra_grad[k]; a.xn[k] = extra_count[k];
+        a.xlr[k] = extra_lr[k]; a.xwd[k] = extra_weight_decay[k];
+    }
+    a.counter = step_counter; a.projected = projected_count; a.status = status; a.zero_grads = zero_grads;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (n) {
+        case 1: return launch_fused_step<1>(a, model, s);
+        case 2: return launch_fused_step<2>(a, model, s);
+        case 3: return launch_fused_step<3>(a, model, s);
+        case 4: return launch_fused_step<4>(a, model, s);
+        case 5: return launch_fused_step<5>(a, model, s);
+        default: return launch_fused_step<6>(a, model, s);
+    }
+}
+
+int64_t sympa_rsgd_step_fused_workspace_bytes(int64_t num_rows) {
+    const int64_t grid = (num_rows + BLOCK - 1) / BLOCK;
+    return 8 * (grid + 2);          // one 8-byte slot for the two barrier words, grid + 1 partial sums
 }
 
 int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,

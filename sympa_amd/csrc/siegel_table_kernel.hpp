@@ -78,6 +78,150 @@ SYMPA_UNROLL
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The optimiser side of one training step as ONE kernel (runner.py:113-118: clip_grad_norm_, optimizer.step, zero_grad):
+//   phase 1  every block writes the sum of squares of its rows' gradients to partial[blockIdx]; block 0 adds the plain
+//            parameters' (scale, wsum weights) to partial[gridDim];
+//   barrier  all blocks are resident (the host refuses a grid larger than the number of CUs), one counter word;
+//   phase 2  every block sums the partials IN INDEX ORDER (bitwise the same total in every block and in every run),
+//            coef = min(1, max_norm / (sqrt(total) + 1e-6)), RiemannianSGD step of its rows, gradient rows zeroed for the
+//            next step; block 0 steps the plain parameters (sympa_sgd_step_clipped's formula) and zeroes their gradients;
+//   exit     the last block to finish resets the barrier words and increments the device step counter (the batch the
+//            next replay of the training graph reads).
+// Replaces five graph nodes (zero, two squared norms, the table step, the scale's step) by one.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FUSED_MAX_EXTRA = 2;
+struct FusedStepArgs {
+    double* table;
+    double* grad;
+    int64_t rows;
+    double lr, wd, eps, max_norm;      // max_norm <= 0: no clip (then no barrier either)
+    double* partial;                   // [gridDim + 1] workspace
+    unsigned* sync;                    // [2], zero on entry, zero on exit
+    double* xp[FUSED_MAX_EXTRA];       // plain parameters (<= 64 elements each), or null
+    double* xg[FUSED_MAX_EXTRA];
+    int xn[FUSED_MAX_EXTRA];
+    double xlr[FUSED_MAX_EXTRA], xwd[FUSED_MAX_EXTRA];
+    int64_t* counter;                  // device step counter (+= 1 on exit) or null
+    int32_t* projected;
+    int32_t* status;
+    int zero_grads;
+};
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void fused_step_kernel(const FusedStepArgs a) {
+    __shared__ double red[BLOCK / 64];
+    __shared__ double total_s;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < a.rows;
+    const int64_t ii = live ? i : a.rows - 1;
+    constexpr int64_t ROW = 2 * N * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sympa::CMat<N> z, g;
+    sympa::load_full<N>(a.table + ii * ROW, z);
+    sympa::load_full<N>(a.grad + ii * ROW, g);
+    int st = 0;
+    double coef = 1.0;
+    if (a.max_norm > 0.0) {
+        double s = 0.0;
+SYMPA_UNROLL
+        for (int r = 0; r < N; ++r)
+SYMPA_UNROLL
+            for (int c = 0; c < N; ++c) s = fma(g.re[r][c], g.re[r][c], fma(g.im[r][c], g.im[r][c], s));
+        s = live ? s : 0.0;
+SYMPA_UNROLL
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) red[wave] = s;
+        double xs = 0.0;
+        if (blockIdx.x == 0 && wave == 0) {
+SYMPA_UNROLL
+            for (int k = 0; k < FUSED_MAX_EXTRA; ++k)
+                if (a.xg[k] != nullptr && lane < a.xn[k]) { const double v = a.xg[k][lane]; xs = fma(v, v, xs); }
+SYMPA_UNROLL
+            for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+SYMPA_UNROLL
+            for (int w = 0; w < BLOCK / 64; ++w) t += red[w];
+            __hip_atomic_store(a.partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) __hip_atomic_store(a.partial + gridDim.x, xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // grid barrier: release my partial, count myself, wait for everybody (bounded: a stranded block must not hang
+            // the device -- it raises the status word instead and the step is garbage)
+            __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { st |= sympa::ST_NO_CONVERGENCE; break; }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // fixed order: lane l sums partial[l], partial[l + 64], ...; then the xor tree -- the same bits in every block
+            double t = 0.0;
+            for (unsigned k = lane; k <= gridDim.x; k += 64)
+                t += __hip_atomic_load(a.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+SYMPA_UNROLL
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if (lane == 0) total_s = t;
+        }
+        __syncthreads();
+        coef = fmin(1.0, a.max_norm / (sqrt(total_s) + 1e-6));
+SYMPA_UNROLL
+        for (int r = 0; r < N; ++r)
+SYMPA_UNROLL
+            for (int c = 0; c < N; ++c) { g.re[r][c] *= coef; g.im[r][c] *= coef; }
+    }
+    const bool moved = sympa::rsgd_row<N, MODEL>(z, g, a.lr, a.wd, a.eps, st);
+    if (live) {
+        sympa::store_full<N>(a.table + i * ROW, z);
+        if (a.zero_grads) {
+SYMPA_UNROLL
+            for (int e = 0; e < ROW; e += 2) *reinterpret_cast<v2d*>(a.grad + i * ROW + e) = v2d{0.0, 0.0};
+        }
+    }
+    if (blockIdx.x == 0 && wave == 0) {
+SYMPA_UNROLL
+        for (int k = 0; k < FUSED_MAX_EXTRA; ++k)
+            if (a.xp[k] != nullptr && lane < a.xn[k]) {
+                const double p = a.xp[k][lane];
+                a.xp[k][lane] = fma(-a.xlr[k], fma(a.xwd[k], p, coef * a.xg[k][lane]), p);
+                if (a.zero_grads) a.xg[k][lane] = 0.0;
+            }
+    }
+    const unsigned long long m = __ballot(live && moved);
+    if (a.projected != nullptr && m != 0ull && lane == 0) atomicAdd(a.projected, (int)__popcll(m));
+    if (a.status != nullptr) {
+        const unsigned long long f = __ballot(st != 0 && (live || threadIdx.x == 0));
+        if (f != 0ull) {
+            if (st != 0) atomicOr(&a.status[0], st);
+            if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(f));
+        }
+    }
+    if (a.max_norm > 0.0 || a.counter != nullptr) {
+        __syncthreads();       // every wave of the block has read total_s / the partials
+        if (threadIdx.x == 0) {
+            const unsigned done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == gridDim.x - 1) {
+                __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.counter != nullptr) a.counter[0] += 1;
+            }
+        }
+    }
+}
+
+template <int N>
+int launch_fused_step(const FusedStepArgs& a, int model, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.rows + BLOCK - 1) / BLOCK);
+    if (model == SYMPA_MODEL_UPPER) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
 template <int N>
 int launch_table(int op, int model, double* z, const double* g, double* out, int64_t b, double lr, double wd,
                  double eps, int32_t* projected, int32_t* status, hipStream_t s, const double* clip, double max_norm,

@@ -542,6 +542,155 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None,
     return table
 
 
+def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper", metric="riem", weights=None,
+                         grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, grad_table=None,
+                         grad_rows=None, step_counter=None, wave_partials=None, eps=None, flags=0):
+    """The backward half of a training step for replayed graphs (C-ABI sympa_model_train_backward, dims <= 8): pairs
+    [c * batch, (c + 1) * batch) of `triplets` [T, >=2] int64 / `graph_dist` [T] fp64, c = step_counter[0] (device int64; None:
+    0).  grad_table: atomic scatter into the dense gradient; grad_rows [2 batch, 2, n, n]: per-pair rows (written).
+    wave_partials [ceil(batch / 64), 2 + n]: deterministic mode, see segment_sum_rows_."""
+    lib = _lib.load()
+    _need_gpu(table, "table"); _need_gpu(triplets, "triplets"); _need_gpu(graph_dist, "graph_dist")
+    if table.dtype != torch.float64 or not table.is_contiguous() or table.dim() != 4:
+        raise ValueError("table must be a contiguous float64 [N,2,n,n] tensor")
+    if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2 or triplets.stride(1) != 1:
+        raise TypeError("triplets must be an int64 [T, >=2] tensor with unit column stride")
+    if graph_dist.dtype != torch.float64 or not graph_dist.is_contiguous():
+        raise TypeError("graph_dist must be a contiguous float64 tensor")
+    n = table.shape[2]
+    dev = table.device
+    if step_counter is None and triplets.shape[0] < batch:
+        raise ValueError("fewer triplets than the batch size")
+    if grad_rows is not None and (grad_rows.dtype != torch.float64 or not grad_rows.is_contiguous()
+                                  or grad_rows.numel() < 2 * batch * 2 * n * n):
+        raise ValueError("grad_rows must be a contiguous float64 tensor of at least [2 batch, 2, n, n]")
+    if wave_partials is not None and (wave_partials.dtype != torch.float64 or not wave_partials.is_contiguous()
+                                      or wave_partials.numel() < ((batch + 63) // 64) * (2 + n)):
+        raise ValueError("wave_partials must be a contiguous float64 tensor of at least [ceil(batch / 64), 2 + n]")
+    w = _weights(metric, weights, n, dev) if metric == "wsum" else None
+    sc_ptr = None
+    if scale is not None:
+        sc = scale if (scale.device == dev and scale.dtype == torch.float64) else scale.detach().to(dev, torch.float64)
+        sc_ptr = sc.data_ptr()
+    st = _status_buf(dev)
+    tp = triplets.data_ptr()
+    stride = triplets.stride(0)
+    with torch.cuda.device(dev):
+        rc = lib.sympa_model_train_backward(
+            table.data_ptr(), table.shape[0], n, tp, stride, tp + 8, stride, graph_dist.data_ptr(), int(batch),
+            None if step_counter is None else step_counter.data_ptr(), MODEL_IDS[model], METRIC_IDS[metric],
+            None if w is None else w.data_ptr(), 1e-5 if eps is None else float(eps), sc_ptr, float(scale_coef),
+            float(loss_scale), loss.data_ptr(), None if grad_table is None else grad_table.data_ptr(),
+            None if grad_rows is None else grad_rows.data_ptr(), None if grad_weights is None else grad_weights.data_ptr(),
+            None if grad_scale is None else grad_scale.data_ptr(),
+            None if wave_partials is None else wave_partials.data_ptr(), st.data_ptr(), int(flags), _stream())
+    if rc != 0:
+        _lib.check(rc)
+    return loss
+
+
+def sorted_slots(row_index_lists, num_rows):
+    """The lists the deterministic gradient accumulation adds in (segment_sum_rows_): for every batch s, the slots
+    0 .. 2b-1 of its per-pair gradient rows (slot k < b: row src[k]; slot b + k: row dst[k]) sorted by table row -- stable,
+    so inside a table row the slots stay in batch order -- and the CSR pointers of the table rows into that list.
+    row_index_lists: int64 [steps, 2b] (table row of every slot).  Returns (order int32 [steps, 2b], rowptr int32
+    [steps, num_rows + 1]).  Torch ops on the device the indices live on: one sort per EPOCH, not per step."""
+    keys = row_index_lists
+    if keys.dim() == 1:
+        keys = keys.unsqueeze(0)
+    sorted_rows, order = torch.sort(keys, dim=1, stable=True)
+    bounds = torch.arange(num_rows + 1, device=keys.device, dtype=keys.dtype).unsqueeze(0).expand(keys.shape[0], -1)
+    rowptr = torch.searchsorted(sorted_rows.contiguous(), bounds.contiguous(), right=False)
+    return order.to(torch.int32).contiguous(), rowptr.to(torch.int32).contiguous()
+
+
+def segment_sum_rows_(grad_table, rows, order, rowptr, alpha=1.0, accumulate=False, step_counter=None,
+                      wave_partials=None, num_waves=0, partial_stride=0, loss=None, grad_scale=None, grad_weights=None):
+    """grad_table[r] (= | +=) alpha * sum of rows[order[p]], p in [rowptr[r], rowptr[r + 1]), added in list order: the
+    deterministic counterpart of scatter_add_rows_ (C-ABI sympa_segment_sum_rows).  order / rowptr from sorted_slots();
+    with step_counter the lists of batch step_counter[0] are used.  wave_partials: the per-wave sums model_train_backward
+    left; they are added to loss / grad_scale / grad_weights in a fixed order."""
+    lib = _lib.load()
+    _need_gpu(grad_table, "grad_table"); _need_gpu(rows, "rows"); _need_gpu(order, "order"); _need_gpu(rowptr, "rowptr")
+    if grad_table.dtype != torch.float64 or rows.dtype != torch.float64 or not grad_table.is_contiguous() or not rows.is_contiguous():
+        raise TypeError("contiguous float64 gradient table and rows expected")
+    if order.dtype != torch.int32 or rowptr.dtype != torch.int32 or not order.is_contiguous() or not rowptr.is_contiguous():
+        raise TypeError("order and rowptr must be contiguous int32 tensors (sorted_slots())")
+    num_rows = grad_table.shape[0]
+    rowd = grad_table[0].numel()
+    if rowptr.shape[-1] != num_rows + 1:
+        raise ValueError("rowptr must have num_rows + 1 entries per batch")
+    if step_counter is None and rows.numel() < order.shape[-1] * rowd:
+        raise ValueError("rows must hold one gradient row per slot")
+    nw = 0 if grad_weights is None else grad_weights.numel()
+    with torch.cuda.device(grad_table.device):
+        rc = lib.sympa_segment_sum_rows(
+            rows.data_ptr(), order.data_ptr(), rowptr.data_ptr(), num_rows, rowd, order.shape[-1],
+            None if step_counter is None else step_counter.data_ptr(), float(alpha), 1 if accumulate else 0,
+            grad_table.data_ptr(), None if wave_partials is None else wave_partials.data_ptr(), int(num_waves),
+            int(partial_stride), nw,
+            None if loss is None else loss.data_ptr(), None if grad_scale is None else grad_scale.data_ptr(),
+            None if grad_weights is None else grad_weights.data_ptr(), _stream())
+    _lib.check(rc)
+    return grad_table
+
+
+class FusedStep:
+    """clip_grad_norm_ + RiemannianSGD step of the table + plain SGD step of up to two small parameters (the scale, the
+    wsum weights) + zero_grad as ONE launch (C-ABI sympa_rsgd_step_fused; runner.py:113-118).  Built once per (table,
+    gradient, parameters): the pointer arrays and the zeroed workspace live here, `run()` is one ctypes call.  Raises
+    SympaHipError with code SYMPA_ERR_UNSUPPORTED_DIMS when the table does not qualify (dims > 6 or more row blocks than
+    CUs): the caller then keeps the separate kernels.  `supported()` tells in advance."""
+
+    @staticmethod
+    def supported(table):
+        if not (table.is_cuda and table.dtype == torch.float64 and table.dim() == 4 and table.shape[2] <= 6):
+            return False
+        cus = torch.cuda.get_device_properties(table.device).multi_processor_count
+        return (table.shape[0] + 255) // 256 <= cus
+
+    def __init__(self, table, grad, model, extras=(), counter=None, projected=None, zero_grads=True):
+        self.lib = _lib.load()
+        _need_gpu(table, "table"); _need_gpu(grad, "grad")
+        if table.dtype != torch.float64 or grad.dtype != torch.float64 or table.shape != grad.shape \
+                or not table.is_contiguous() or not grad.is_contiguous() or table.dim() != 4 or table.shape[1] != 2:
+            raise ValueError("table and grad must be contiguous float64 [N,2,n,n] tensors of the same shape")
+        if len(extras) > 2:
+            raise ValueError("at most two plain parameters")
+        for p, g in extras:
+            _need_gpu(p, "extra parameter"); _need_gpu(g, "extra gradient")
+            if p.dtype != torch.float64 or g.dtype != torch.float64 or p.numel() != g.numel() or not (1 <= p.numel() <= 64) \
+                    or not p.is_contiguous() or not g.is_contiguous():
+                raise ValueError("plain parameters: contiguous float64, 1..64 elements, gradient of the same size")
+        self.keep = (table, grad, list(extras), counter, projected)
+        self.dev = table.device
+        self.model = MODEL_IDS[model]
+        k = len(extras)
+        self.k = k
+        self.xp = (ctypes.c_void_p * max(k, 1))(*[p.data_ptr() for p, _ in extras])
+        self.xg = (ctypes.c_void_p * max(k, 1))(*[g.data_ptr() for _, g in extras])
+        self.xn = (ctypes.c_int * max(k, 1))(*[p.numel() for p, _ in extras])
+        need = self.lib.sympa_rsgd_step_fused_workspace_bytes(table.shape[0])
+        self.ws = torch.zeros(need // 8, dtype=torch.float64, device=self.dev)
+        self.zero_grads = 1 if zero_grads else 0
+        self.status = _status_buf(self.dev)
+
+    def run(self, lr, weight_decay=0.0, max_norm=None, extra_lr=(), extra_weight_decay=(), eps=None):
+        table, grad, extras, counter, projected = self.keep
+        xlr = (ctypes.c_double * max(self.k, 1))(*[float(x) for x in extra_lr])
+        xwd = (ctypes.c_double * max(self.k, 1))(*[float(x) for x in extra_weight_decay])
+        if len(extra_lr) != self.k or len(extra_weight_decay) != self.k:
+            raise ValueError("one learning rate and weight decay per plain parameter")
+        with torch.cuda.device(self.dev):
+            rc = self.lib.sympa_rsgd_step_fused(
+                table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], self.model, float(lr),
+                float(weight_decay), EPS[torch.float64] if eps is None else float(eps),
+                float(max_norm) if max_norm is not None else 0.0, self.zero_grads, self.xp, self.xg, self.xn, xlr, xwd, self.k,
+                self.ws.data_ptr(), self.ws.numel() * 8, None if counter is None else counter.data_ptr(),
+                None if projected is None else projected.data_ptr(), self.status.data_ptr(), _stream())
+        _lib.check(rc)
+
+
 def all_pairs_dist(table, model="upper", metric="riem", weights=None, scale=None, scale_coef=1.0, row_begin=0,
                    row_count=None, eps=None, out=None, packed=None, workspace=None, flags=0):
     """Rows [row_begin, row_begin + row_count) of the N x N distance matrix (C-ABI sympa_all_pairs_dist;

@@ -1,18 +1,30 @@
 """The body of the reference's training loop (sympa/runner.py:98-118: zero_grad, forward, AverageDistortionLoss,
 backward, gradient clip, optimiser step) as ONE hipGraph replay per batch.
 
-Eagerly the step is a handful of launches (memset, the fused loss+backward kernel, the norm / clip kernels of
-torch.nn.utils.clip_grad_norm_, the fused RSGD kernel) issued from Python; at the reference's batch sizes (512 .. 8192
-triplets) the Python and launch overhead (~0.3 ms) is several times the GPU time.  Everything in the step is
-stream-ordered and allocation-free after the first call, so it is captured once per (batch size, learning rate) and
-replayed: the batch is copied into static buffers, the graph runs, the loss stays on the device."""
+Eagerly the step is a handful of launches issued from Python; at the reference's batch sizes (512 .. 8192 triplets)
+the Python and launch overhead (~0.3 ms) is several times the GPU time.  Everything in the step is stream-ordered and
+allocation-free after the first call, so it is captured once per (batch size, learning rate) and replayed.
+
+Two graph shapes:
+
+* **two kernels** (Siegel models, dims <= 6, RiemannianSGD, table of at most CUs x 256 rows): `sympa_model_train_backward`
+  (distances + loss + backward + scatter) and `sympa_rsgd_step_fused` (clip norm, table step, scale / wsum-weight step,
+  zero_grad).  The batch is addressed through a device step counter that the second kernel increments, so an epoch's
+  shuffled triplets are loaded ONCE (`load_epoch`) and `run_steps(k)` is k replays with no copy, no memset and no host
+  arithmetic in between.  `deterministic=True` swaps the atomic scatter for per-pair gradient rows + a segmented sum in
+  a precomputed order (one sort per epoch) and the scalar atomics for fixed-order sums: two runs of an epoch give the
+  same bits, like the reference's CPU autograd.
+* **classic** (everything else: dims 7..16, spd, other optimisers' parameters): zero (one multi-tensor launch), the fused
+  loss + backward kernel, squared norms, the RSGD kernel(s), the scale's step -- round 2's graph."""
 import torch
 
 from sympa_amd import ops
+from sympa_amd.manifolds.metrics import MetricType
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, batch_size, max_grad_norm, device):
+    def __init__(self, model, optimizer, batch_size, max_grad_norm, device, deterministic=False, accumulate_loss=False,
+                 two_kernels=True):
         # the capture bakes every host-side scalar of the optimiser's step in as an immediate: only optimisers whose step has
         # no host state that changes from step to step may be captured (RiemannianAdam's bias corrections and step count do)
         if not getattr(optimizer, "graph_capturable", False):
@@ -20,24 +32,104 @@ class GraphedTrainStep:
                             "every call); use sympa_amd.optim.RiemannianSGD or run the step eagerly")
         self.model, self.opt = model, optimizer
         self.batch_size, self.max_grad_norm = int(batch_size), float(max_grad_norm)
-        self.ids = torch.zeros(self.batch_size, 2, dtype=torch.int64, device=device)
-        self.gd = torch.ones(self.batch_size, dtype=torch.float64, device=device)
+        self.device = torch.device(device)
+        self.deterministic = bool(deterministic)
+        self.accumulate_loss = bool(accumulate_loss)
         self.loss = torch.zeros(1, dtype=torch.float64, device=device)
         self.graph = None
         self.key = None
         self.grad_ptrs = []
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._zero_list = None
+        self.mode = "two_kernels" if (two_kernels and self._two_kernels_possible()) else "classic"
+        if self.deterministic and self.mode != "two_kernels":
+            raise ValueError("deterministic accumulation is built for the two-kernel step (Siegel models, dims <= 6, "
+                             "RiemannianSGD, tables of at most CUs x 256 rows)")
+        # the batches of an epoch (two-kernel mode) / the static batch (classic mode)
+        self.capacity = self.batch_size
+        self._alloc_epoch(self.batch_size)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.steps_loaded = 0
+        self._fused = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _two_kernels_possible(self):
+        from sympa_amd.optim import RiemannianSGD
+        m = self.model
+        man = m.manifold
+        table = m.embeddings.embeds
+        if not isinstance(self.opt, RiemannianSGD) or getattr(man, "model_name", None) not in ("upper", "bounded"):
+            return False
+        if not ops.FusedStep.supported(table.data):
+            return False
+        extras = [p for p in self.params if p is not table]
+        if not table.requires_grad or len(extras) > 2 or any(p.numel() > 64 or p.dtype != torch.float64 or not p.is_cuda
+                                                            for p in extras):
+            return False
+        known = [m.scale] + ([man.metric.weights] if man.metric.kind is MetricType.WEIGHTED_SUM else [])
+        if any(all(p is not k for k in known) for p in extras):
+            return False
+        in_opt = [p for g in self.opt.param_groups for p in g["params"]]
+        return all(any(p is q for q in in_opt) for p in self.params)
+
+    def _alloc_epoch(self, pairs):
+        dev = self.device
+        self.capacity = int(pairs)
+        self.ids = torch.zeros(self.capacity, 2, dtype=torch.int64, device=dev)
+        self.gd = torch.ones(self.capacity, dtype=torch.float64, device=dev)
+        if self.deterministic:
+            steps = max(1, self.capacity // self.batch_size)
+            n_rows = self.model.embeddings.embeds.shape[0]
+            self.order = torch.zeros(steps, 2 * self.batch_size, dtype=torch.int32, device=dev)
+            self.rowptr = torch.zeros(steps, n_rows + 1, dtype=torch.int32, device=dev)
+        self.graph = None            # the captured launches hold the old addresses
+
+    def _group_of(self, p):
+        for g in self.opt.param_groups:
+            if any(p is q for q in g["params"]):
+                return g
+        raise KeyError("parameter not in the optimiser")
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _backward(self, counter):
+        """distances + loss + gradients of batch `counter` of the loaded triplets (two-kernel mode)."""
+        m = self.model
+        man = m.manifold
+        table = m.embeddings.embeds
+        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
+        weights = man.metric.weights if wsum else None
+        gw = weights.grad if wsum else None
+        gs = m.scale.grad if m.scale.requires_grad else None
+        b = self.batch_size
+        if not self.deterministic:
+            ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
+                                     None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                     grad_table=table.grad, step_counter=counter)
+            return
+        ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
+                                 None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                 grad_rows=self.rows, step_counter=counter, wave_partials=self.partials)
+        ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=counter,
+                              wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
+                              loss=self.loss, grad_scale=gs, grad_weights=gw)
 
     def _body(self):
+        if self.mode == "two_kernels":
+            if not self.accumulate_loss:
+                self.loss.zero_()
+            self._backward(self.counter)
+            self._fused_step()
+            return
         if self._zero_list is None:
             self.opt.zero_grad(set_to_none=False)
-            self.model.fused_loss_backward(self.ids, self.gd, loss_out=self.loss)      # accumulated straight into self.loss
+            self.model.fused_loss_backward(self.ids[:self.batch_size], self.gd[:self.batch_size],
+                                           loss_out=self.loss, zero_loss_out=not self.accumulate_loss)
             self._clip_and_step()
             return
         # gradients, the loss word and the optimiser's squared-norm word zeroed by ONE multi-tensor launch
         torch._foreach_zero_(self._zero_list)
-        self.model.fused_loss_backward(self.ids, self.gd, loss_out=self.loss, zero_loss_out=False)
+        self.model.fused_loss_backward(self.ids[:self.batch_size], self.gd[:self.batch_size], loss_out=self.loss,
+                                       zero_loss_out=False)
         self.opt._sqnorm_zeroed_by_caller = True
         try:
             self._clip_and_step()
@@ -53,11 +145,69 @@ class GraphedTrainStep:
             torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
             self.opt.step()
 
+    def _ensure_fused(self):
+        """Gradient tensors (zero) and the fused optimiser kernel's plan (two-kernel mode)."""
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p.data)
+        if self.mode != "two_kernels" or self._fused is not None:
+            return
+        table = self.model.embeddings.embeds
+        man = self.model.manifold
+        self._extra_params = [p for p in self.params if p is not table]
+        extras = [(p.data, p.grad) for p in self._extra_params]
+        # zero_grads: the scatter accumulates into the table gradient, the scalar sums into the scale / weight gradients
+        self._fused = ops.FusedStep(table.data, table.grad, man.model_name, extras, counter=self.counter,
+                                    projected=man.projected_counter(table.device), zero_grads=True)
+        if self.deterministic:
+            n = table.shape[2]
+            self.rows = torch.empty(2 * self.batch_size, 2, n, n, dtype=torch.float64, device=self.device)
+            self.partials = torch.zeros((self.batch_size + 63) // 64, 2 + n, dtype=torch.float64, device=self.device)
+        for p in self.params:          # the step leaves the gradients zero; it must find them zero the first time
+            p.grad.zero_()
+
+    def _fused_step(self):
+        tg = self._group_of(self.model.embeddings.embeds)
+        xg = [self._group_of(p) for p in self._extra_params]
+        self._fused.run(tg["lr"], tg.get("weight_decay", 0.0), self.max_grad_norm,
+                        [g["lr"] for g in xg], [g.get("weight_decay", 0.0) for g in xg])
+
     def eager(self, ids, gd):
-        """The same step without a graph (ragged last batch of an epoch, multi-GPU steps with an all-reduce inside)."""
-        self.opt.zero_grad(set_to_none=False)
-        loss = self.model.fused_loss_backward(ids, gd)
-        self._clip_and_step()
+        """The same step without a graph (ragged last batch of an epoch, multi-GPU steps with an all-reduce inside).
+        Two-kernel mode: the same two kernels launched directly (deterministic: per-pair rows + one sort + the segmented
+        sum, so the epoch stays reproducible).  Returns the batch loss (a fresh 1-element tensor)."""
+        if self.mode != "two_kernels":
+            self.opt.zero_grad(set_to_none=False)
+            loss = self.model.fused_loss_backward(ids, gd)
+            self._clip_and_step()
+            return loss
+        self._ensure_fused()
+        m = self.model
+        man = m.manifold
+        table = m.embeddings.embeds
+        b = ids.shape[0]
+        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
+        weights = man.metric.weights if wsum else None
+        gw = weights.grad if wsum else None
+        gs = m.scale.grad if m.scale.requires_grad else None
+        n = table.shape[2]
+        loss = torch.zeros(1, dtype=torch.float64, device=table.device)
+        ids = ids[:, :2].contiguous()
+        gd = gd.to(torch.float64).contiguous()
+        if b > 0 and not self.deterministic:
+            ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
+                                     None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                     grad_table=table.grad)
+        elif b > 0:
+            rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=table.device)
+            partials = torch.empty((b + 63) // 64, 2 + n, dtype=torch.float64, device=table.device)
+            ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
+                                     None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                     grad_rows=rows, wave_partials=partials)
+            order, rowptr = ops.sorted_slots(torch.cat((ids[:, 0], ids[:, 1])), table.shape[0])
+            ops.segment_sum_rows_(table.grad, rows, order, rowptr, wave_partials=partials, num_waves=(b + 63) // 64,
+                                  partial_stride=2 + n, loss=loss, grad_scale=gs, grad_weights=gw)
+        self._fused_step()
         return loss
 
     def _key(self):
@@ -69,25 +219,31 @@ class GraphedTrainStep:
         if ops._debug:
             raise RuntimeError("ops.set_debug(True) synchronises after every kernel and cannot run inside a hipGraph "
                                "capture: switch it off for graphed training steps")
-        # warm-up outside the capture with lr = 0: allocates the gradients / status words / foreach workspaces and
-        # leaves the parameters where they are (retr(x, 0) = projx(x), the identity for points on the manifold);
-        # every group gets its own lr back afterwards
+        self._ensure_fused()
+        # warm-up outside the capture with lr = 0: allocates the status words / workspaces and leaves the parameters where
+        # they are (retr(x, 0) = projx(x), the identity for points on the manifold); every group gets its own lr back
         saved = [g["lr"] for g in self.opt.param_groups]
+        saved_loss = self.loss.clone()
+        saved_counter = self.counter.clone()
         for g in self.opt.param_groups:
             g["lr"] = 0.0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
+                self.counter.zero_()
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         for g, lr in zip(self.opt.param_groups, saved):
             g["lr"] = lr
-        # after the warm-up every buffer exists: from here on one foreach launch zeroes them all
+        self.loss.copy_(saved_loss)
+        self.counter.copy_(saved_counter)
+        # after the warm-up every buffer exists: from here on one foreach launch zeroes them all (classic mode)
         self._zero_list = None
-        if hasattr(self.opt, "_sqnorm_zeroed_by_caller") and hasattr(self.opt, "clip_max_norm"):
+        if self.mode == "classic" and hasattr(self.opt, "_sqnorm_zeroed_by_caller") and hasattr(self.opt, "clip_max_norm"):
             grads = [p.grad for p in self.params if p.grad is not None]
-            words = [self.loss] + [t for t in getattr(self.opt, "_sqnorm", {}).values() if t.device == self.loss.device]
+            words = ([] if self.accumulate_loss else [self.loss]) + \
+                [t for t in getattr(self.opt, "_sqnorm", {}).values() if t.device == self.loss.device]
             if grads and all(g.is_cuda for g in grads):
                 self._zero_list = grads + words
         self.graph = torch.cuda.CUDAGraph()
@@ -97,13 +253,7 @@ class GraphedTrainStep:
         # the graph writes the gradients through these addresses
         self.grad_ptrs = [None if p.grad is None else p.grad.data_ptr() for p in self.params]
 
-    def __call__(self, ids, gd):
-        """ids [b, 2] int64, gd [b] fp64 on the device.  Returns the batch loss as a 1-element device tensor that is
-        overwritten by the next call (add it to an accumulator, do not keep it)."""
-        if ids.shape[0] != self.batch_size:
-            return self.eager(ids, gd)
-        self.ids.copy_(ids)
-        self.gd.copy_(gd)
+    def _ready(self):
         if self.graph is None or self._key() != self.key:
             self._capture()          # learning rate / weight decay / clip norm of any group changed (end of burn-in)
         for p, ptr in zip(self.params, self.grad_ptrs):
@@ -111,8 +261,70 @@ class GraphedTrainStep:
                 # e.g. zero_grad(set_to_none=True) between replays: the graph would write freed memory
                 raise RuntimeError("a parameter's .grad was replaced since the step was captured; keep the gradient "
                                    "tensors (zero_grad(set_to_none=False)) or build a new GraphedTrainStep")
+
+    # ------------------------------------------------------------------------------------------------------------
+    def __call__(self, ids, gd):
+        """ids [b, 2] int64, gd [b] fp64 on the device.  Returns the loss word: the batch loss (accumulate_loss=False: it is
+        overwritten by the next call -- add it to an accumulator, do not keep it) or the running sum since reset_loss()."""
+        if ids.shape[0] != self.batch_size:
+            loss = self.eager(ids, gd)
+            if self.accumulate_loss:
+                self.loss += loss
+                return self.loss
+            return loss
+        b = self.batch_size
+        self.ids[:b].copy_(ids[:, :2])
+        self.gd[:b].copy_(gd)
+        if self.mode == "two_kernels":
+            self.counter.zero_()
+            if self.deterministic:
+                order, rowptr = ops.sorted_slots(torch.cat((self.ids[:b, 0], self.ids[:b, 1])),
+                                                 self.model.embeddings.embeds.shape[0])
+                self.order[0].copy_(order[0])
+                self.rowptr[0].copy_(rowptr[0])
+        self._ready()
         self.graph.replay()
         return self.loss
+
+    def load_epoch(self, triplets):
+        """triplets [T, 3] int64 (src, dst, graph distance) in the order the epoch visits them (the DistributedSampler
+        shard, train.py:105-110).  Copies them into the step's persistent buffers once, builds the deterministic mode's
+        sorted slot lists with ONE sort, resets the device step counter.  Returns the number of FULL batches
+        `run_steps` may replay; the ragged remainder triplets[steps * batch:] goes through `eager` (or `__call__`)."""
+        if self.mode != "two_kernels":
+            raise RuntimeError("load_epoch / run_steps need the two-kernel step; this model runs the classic graph: "
+                               "call the object once per batch")
+        total = triplets.shape[0]
+        b = self.batch_size
+        steps = total // b
+        if total > self.capacity:
+            self._alloc_epoch(total)
+        self.ids[:total].copy_(triplets[:, :2])
+        self.gd[:total].copy_(triplets[:, 2])
+        if self.deterministic and steps > 0:
+            used = self.ids[:steps * b].view(steps, b, 2)
+            order, rowptr = ops.sorted_slots(torch.cat((used[:, :, 0], used[:, :, 1]), dim=1),
+                                             self.model.embeddings.embeds.shape[0])
+            self.order[:steps].copy_(order)
+            self.rowptr[:steps].copy_(rowptr)
+        self.counter.zero_()
+        self.steps_loaded = steps
+        return steps
+
+    def run_steps(self, k=None):
+        """k replays of the two-kernel graph on the next k batches of the loaded epoch (default: all that are left).
+        Nothing else is enqueued between the replays."""
+        self._ready()
+        k = self.steps_loaded if k is None else int(k)
+        if k > self.steps_loaded:
+            raise ValueError("more steps than full batches left in the loaded epoch")
+        for _ in range(k):
+            self.graph.replay()
+        self.steps_loaded -= k
+        return self.loss
+
+    def reset_loss(self):
+        self.loss.zero_()
 
 
 def check(device):

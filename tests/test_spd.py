@@ -475,6 +475,18 @@ def test_gpu_spd_loss_backward_in_kernel_scatter(n):
     assert torch.isnan(out3[4])
     with pytest.raises(IndexError):
         ops.check_status(dev)
-    with pytest.raises(Exception):
-        ops.spd_loss_backward(spd_points(5, 2, 0.3, g).to(dev), trip[:3] % 5, torch.zeros(5, 2, 2, dtype=torch.float64, device=dev),
-                              graph_dist=gd[:3])                       # n = 2: rows + scatter is the path
+    # n = 2 (and SYMPA_FLAG_GENERIC, and an instantiation the self-check routed to the one-lane kernel): no kernel has the
+    # scatter inside; ops.spd_loss_backward takes rows + scatter-add itself and gives the same gradient
+    t2 = spd_points(5, 2, 0.3, g).to(dev)
+    g2 = torch.zeros(5, 2, 2, dtype=torch.float64, device=dev)
+    ops.spd_loss_backward(t2, trip[:3] % 5, g2, graph_dist=gd[:3])
+    rows2, _ = ops.spd_backward_rows(t2, t2, trip[:3] % 5, graph_dist=gd[:3])
+    want2 = torch.zeros_like(g2)
+    ops.scatter_add_flat_rows_(want2, rows2.reshape(6, -1), torch.cat((trip[:3, 0] % 5, trip[:3, 1] % 5)))
+    assert torch.equal(g2, want2)
+    gt4 = torch.zeros_like(table)
+    trip[4, 0] = 0
+    ops.spd_loss_backward(table, trip, gt4, graph_dist=gd, flags=ops.FLAG_GENERIC)
+    gt5 = torch.zeros_like(table)
+    ops.spd_loss_backward(table, trip, gt5, graph_dist=gd)
+    assert rel_err(gt4.cpu(), gt5.cpu(), atol=1e-13) < 1e-9

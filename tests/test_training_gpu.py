@@ -109,3 +109,192 @@ def test_training_through_the_sixteen_lanes_kernels(manifold, dims):
     assert last < 0.8 * first, hist
     ok, point, reason = model.check_all_points()
     assert ok, reason
+
+
+def _toy_model(manifold, metric, dims, nodes, dev, train_scale=True, seed=1):
+    from sympa_amd import data
+    from sympa_amd.model import Model
+
+    class A:
+        pass
+    A.manifold, A.metric, A.dims, A.num_points = manifold, metric, dims, nodes
+    A.scale_coef, A.scale_init, A.train_scale = 2.0, 1.5, train_scale
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.trained_like_table(nodes, dims, model=manifold, seed=seed)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("model,n,nodes", [("upper", 4, 700), ("bounded", 3, 1000), ("upper", 6, 300), ("upper", 1, 70)])
+def test_fused_optimiser_kernel_equals_the_separate_kernels(model, n, nodes):
+    """sympa_rsgd_step_fused (clip norm with a grid barrier + table step + scale / weight step + zero_grad + step counter,
+    one launch) == sympa_sqnorm_accum + sympa_rsgd_step_clipped + sympa_sgd_step_clipped + memsets, with and without an
+    active clip; the workspace is left ready for the next call; more row blocks than CUs are refused."""
+    from sympa_amd import _lib, data, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3 + n)
+    table0 = data.trained_like_table(nodes, n, model=model, seed=2).to(dev)
+    grad0 = torch.randn(table0.shape, generator=g, dtype=torch.float64)
+    grad0 = (0.5 * (grad0 + grad0.transpose(-1, -2))).to(dev)
+    scale0 = torch.tensor([1.3], dtype=torch.float64, device=dev)
+    gs0 = torch.tensor([0.7], dtype=torch.float64, device=dev)
+    w0 = torch.linspace(0.2, 1.1, n, dtype=torch.float64).to(dev)
+    gw0 = torch.linspace(-0.5, 0.4, n, dtype=torch.float64).to(dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    for max_norm, lr in ((1e9, 1e-3), (0.5, 0.3), (None, 1e-2)):
+        # separate kernels
+        t1, s1, w1 = table0.clone(), scale0.clone(), w0.clone()
+        c1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        if max_norm is not None:
+            sq = torch.zeros(1, dtype=torch.float64, device=dev)
+            for t in (grad0, gs0, gw0):
+                ops.sqnorm_accum_(t, sq)
+            ops.rsgd_step_(t1, grad0, model, lr, 1e-3, counter=c1, clip_sqnorm=sq, max_norm=max_norm)
+            ops.sgd_step_clipped_(s1, gs0, 0.5 * lr, 0.0, clip_sqnorm=sq, max_norm=max_norm)
+            ops.sgd_step_clipped_(w1, gw0, lr, 1e-2, clip_sqnorm=sq, max_norm=max_norm)
+        else:
+            ops.rsgd_step_(t1, grad0, model, lr, 1e-3, counter=c1)
+            ops.sgd_step_clipped_(s1, gs0, 0.5 * lr, 0.0)
+            ops.sgd_step_clipped_(w1, gw0, lr, 1e-2)
+        # one kernel
+        t2, s2, w2 = table0.clone(), scale0.clone(), w0.clone()
+        g2, gs2, gw2 = grad0.clone(), gs0.clone(), gw0.clone()
+        c2 = torch.zeros(1, dtype=torch.int32, device=dev)
+        fs = ops.FusedStep(t2, g2, model, [(s2, gs2), (w2, gw2)], counter=counter, projected=c2)
+        before = int(counter)
+        fs.run(lr, 1e-3, max_norm, [0.5 * lr, lr], [0.0, 1e-2])
+        ops.check_status(dev)
+        assert int(counter) == before + 1
+        scale_t = float(t1.abs().max())
+        assert float((t1 - t2).abs().max()) < 1e-11 * scale_t, (max_norm, lr)
+        assert abs(float(s1 - s2)) < 1e-13 and float((w1 - w2).abs().max()) < 1e-13
+        assert int(c1) == int(c2)
+        assert float(g2.abs().max()) == 0.0 and float(gs2.abs().max()) == 0.0 and float(gw2.abs().max()) == 0.0
+        assert int(fs.ws.view(torch.int32)[:2].abs().sum()) == 0          # barrier words reset
+        # a second step with the same object: the workspace needs no host-side reset
+        g2.copy_(grad0); gs2.copy_(gs0); gw2.copy_(gw0)
+        t3 = t2.clone()
+        fs.run(lr, 1e-3, max_norm, [0.5 * lr, lr], [0.0, 1e-2])
+        assert torch.isfinite(t2).all() and not torch.equal(t2, t3)
+    big = torch.zeros(300 * 256, 2, 1, 1, dtype=torch.float64, device=dev)
+    big[:, 1] = 1.0
+    assert not ops.FusedStep.supported(big)
+    with pytest.raises(_lib.SympaHipError):
+        ops.FusedStep(big, torch.zeros_like(big), "upper").run(1e-3, 0.0, 1.0)
+
+
+@pytest.mark.parametrize("model,n", [("upper", 4), ("bounded", 2), ("upper", 6), ("upper", 8)])
+def test_deterministic_gradient_accumulation(model, n):
+    """SURVEY 8f-1's alternative to atomics: per-pair gradient rows (coalesced through the LDS tile) + segmented sum in a
+    precomputed order + fixed-order scalar sums.  Two runs give bit-identical embeds.grad, loss and scale gradient; they
+    equal the fp64-atomic scatter to 1e-12 (relative to the largest entry); a small case equals the sum evaluated
+    sequentially in slot order on the host bit for bit; the step-counter window picks the right batch."""
+    from sympa_amd import data, ops
+    dev = torch.device("cuda:0")
+    nodes, b, steps = 211, 4099 if n < 8 else 1500, 3
+    g = torch.Generator().manual_seed(40 + n)
+    table = data.trained_like_table(nodes, n, model=model, seed=4).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (steps * b,), generator=g), torch.randint(0, nodes, (steps * b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (steps * b,), generator=g).to(torch.float64).to(dev)
+    sc = torch.tensor([1.7], dtype=torch.float64, device=dev)
+    w = torch.linspace(0.3, 1.2, n, dtype=torch.float64).to(dev)
+    order, rowptr = ops.sorted_slots(torch.cat((trip[:, 0].view(steps, b), trip[:, 1].view(steps, b)), dim=1), nodes)
+    assert order.shape == (steps, 2 * b) and rowptr.shape == (steps, nodes + 1) and int(rowptr[:, -1].min()) == 2 * b
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    for metric in ("riem", "wsum"):
+        for step in (0, 2):
+            counter.fill_(step)
+
+            def det():
+                rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+                part = torch.empty((b + 63) // 64, 2 + n, dtype=torch.float64, device=dev)
+                loss, gs = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+                gw = torch.zeros(n, dtype=torch.float64, device=dev)
+                ops.model_train_backward(table, trip, gd, b, loss, model, metric, w, gw, sc, gs, 2.0, 1.0, grad_rows=rows,
+                                         step_counter=counter, wave_partials=part)
+                grad = torch.full_like(table, 7.0)          # overwritten, not accumulated into
+                ops.segment_sum_rows_(grad, rows, order, rowptr, step_counter=counter, wave_partials=part,
+                                      num_waves=(b + 63) // 64, partial_stride=2 + n, loss=loss, grad_scale=gs,
+                                      grad_weights=gw if metric == "wsum" else None)
+                return grad, loss, gs, gw, rows
+            a1, a2 = det(), det()
+            for x, y in zip(a1[:4], a2[:4]):
+                assert torch.equal(x, y)
+            # the atomic form of the same batch
+            grad = torch.zeros_like(table)
+            loss, gs = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+            gw = torch.zeros(n, dtype=torch.float64, device=dev)
+            sl = slice(step * b, (step + 1) * b)
+            ops.model_loss_backward(table, trip[sl], gd[sl], grad, loss, model, metric, w, gw, sc, gs, 2.0, 1.0)
+            ops.check_status(dev)
+            big = float(grad.abs().max())
+            tol = 1e-12 if n <= 6 else 1e-8      # n = 8: the atomic form runs the eight-lanes-per-pair kernel (another route)
+            assert float((a1[0] - grad).abs().max()) < tol * big, (metric, step)
+            assert abs(float(a1[1] - loss)) < tol * abs(float(loss)) and abs(float(a1[2] - gs)) < 10 * tol * abs(float(gs))
+            if metric == "wsum":
+                assert float((a1[3] - gw).abs().max()) < 10 * tol * float(gw.abs().max())
+    # bit for bit the sequential sum in slot order (rows of the last det() call, batch 2)
+    rows_c = a1[4].cpu().reshape(2 * b, -1)
+    o, rp = order[2].cpu(), rowptr[2].cpu()
+    want = torch.zeros(nodes, rows_c.shape[1], dtype=torch.float64)
+    for r in range(0, nodes, 17):
+        s = torch.zeros(rows_c.shape[1], dtype=torch.float64)
+        for p in range(int(rp[r]), int(rp[r + 1])):
+            s = s + rows_c[int(o[p])]
+        want[r] = s
+        assert torch.equal(a1[0][r].cpu().reshape(-1), want[r]), r
+    # accumulate / alpha
+    acc = torch.ones_like(table)
+    ops.segment_sum_rows_(acc, a1[4], order[2].contiguous(), rowptr[2].contiguous(), alpha=0.5, accumulate=True)
+    assert float((acc - (1.0 + 0.5 * a1[0])).abs().max()) < 1e-13 * max(1.0, float(a1[0].abs().max()))
+
+
+def test_two_kernel_epoch_trains_like_the_classic_graph_and_the_deterministic_form_is_reproducible():
+    """The two-kernel step driven by the device step counter (load_epoch + run_steps) == round 2's classic graph called
+    batch by batch (tolerance: atomics); the deterministic form run twice gives bit-identical tables, scales and losses."""
+    from sympa_amd import ops
+    from sympa_amd.optim import RiemannianSGD
+    from sympa_amd.train_step import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    nodes, n, batch, steps = 400, 3, 1024, 7
+    g = torch.Generator().manual_seed(9)
+    trip = torch.stack((torch.randint(0, nodes, (steps * batch + 300,), generator=g),
+                        torch.randint(0, nodes, (steps * batch + 300,), generator=g),
+                        torch.randint(1, 9, (steps * batch + 300,), generator=g)), 1).to(dev)
+
+    def run(form):
+        m = _toy_model("upper", "riem", n, nodes, dev)
+        opt = RiemannianSGD(m.parameters(), lr=5e-3)
+        st = GraphedTrainStep(m, opt, batch, 2.0, dev, two_kernels=form != "classic", deterministic=form == "det",
+                              accumulate_loss=True)
+        assert st.mode == ("classic" if form == "classic" else "two_kernels")
+        for epoch in range(2):
+            if form == "classic":
+                for s in range(0, trip.shape[0], batch):
+                    st(trip[s:s + batch, :2], trip[s:s + batch, 2].to(torch.float64))
+            else:
+                full = st.load_epoch(trip)
+                assert full == steps
+                st.run_steps()
+                st(trip[full * batch:, :2], trip[full * batch:, 2].to(torch.float64))      # ragged remainder
+        ops.check_status(dev)
+        return m.embeddings.embeds.detach().clone(), m.scale.detach().clone(), st.loss.clone()
+    classic, two, det1, det2 = run("classic"), run("two"), run("det"), run("det")
+    for a, b_ in zip(det1, det2):
+        assert torch.equal(a, b_)
+    for other in (two, det1):
+        assert float((other[0] - classic[0]).abs().max()) < 1e-9
+        assert abs(float(other[1] - classic[1])) < 1e-9 and abs(float(other[2] - classic[2])) < 1e-8 * abs(float(classic[2]))
+    assert float((classic[0] - _toy_model("upper", "riem", n, nodes, dev).embeddings.embeds.detach()).abs().max()) > 1e-4
+
+
+def test_harness_deterministic_training_is_bitwise_reproducible():
+    import train_siegel
+    common = ["--graph", "grid3d-125", "--manifold", "bounded", "--metric", "fone", "--dims", "2", "--epochs", "6",
+              "--batch_size", "512", "--val_every", "2", "--learning_rate", "0.02", "--burnin", "2", "--train_scale",
+              "--deterministic"]
+    m1, h1 = train_siegel.train(train_siegel.parser().parse_args(common), log=lambda *_: None)
+    m2, h2 = train_siegel.train(train_siegel.parser().parse_args(common), log=lambda *_: None)
+    assert h1 == h2
+    assert torch.equal(m1.embeddings.embeds, m2.embeddings.embeds) and torch.equal(m1.scale, m2.scale)
+    assert h1[-1][2] < h1[0][2]

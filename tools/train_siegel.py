@@ -50,7 +50,8 @@ def train(args, log=print):
     batch = max(1, args.batch_size // world)
     history = []
     # single GPU: the whole step is one hipGraph replay; multi-GPU steps have an all-reduce in the middle and run eagerly
-    graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev) \
+    graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev, deterministic=args.deterministic,
+                               accumulate_loss=True) \
         if (world == 1 and args.graph_step and args.grad_exchange == "none" and args.optim == "rsgd") else None
     # (RiemannianAdam's bias corrections change every step on the host: its step is not captured)
     # N > 1 (or --grad_exchange given): gradients live in one persistent flat buffer; the table gradient travels dense
@@ -68,10 +69,18 @@ def train(args, log=print):
         for g in opt.param_groups:
             g["lr"] = lr
         loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
-        for s in range(0, mine.shape[0], batch):
+        first = 0
+        if graphed is not None:
+            graphed.reset_loss()
+            if graphed.mode == "two_kernels":
+                # the epoch's triplets are loaded once; every full batch is one replay of a two-kernel graph that finds
+                # its batch through a device counter (no per-step copy, memset or host arithmetic)
+                first = graphed.load_epoch(mine) * batch
+                graphed.run_steps()
+        for s in range(first, mine.shape[0], batch):
             b = mine[s:s + batch]
             if graphed is not None:
-                loss_sum += graphed(b[:, :2], b[:, 2].to(torch.float64))
+                graphed(b[:, :2], b[:, 2].to(torch.float64))        # accumulates into graphed.loss
                 continue
             ids, gd = b[:, :2].contiguous(), b[:, 2].to(torch.float64)
             if ex is None:
@@ -90,6 +99,8 @@ def train(args, log=print):
         # the reference asserts inside every dist() call (siegel_manifold.py:64-66) and checks all points once per epoch
         # (runner.py:180-184); here the status word of the kernels is read once per epoch (one host sync)
         ops.check_status(dev)
+        if graphed is not None:
+            loss_sum += graphed.loss
         if epoch % args.val_every == 0 or epoch == args.epochs:
             torch.cuda.synchronize(dev)
             t_train = time.perf_counter() - t0
@@ -123,6 +134,10 @@ def parser():
     ap.add_argument("--grad_exchange", default="none", choices=["none", "auto", "dense", "rows"],
                     help="single GPU: run the step through sympa_amd.distributed.GradientExchange anyway (tests); with "
                          "N > 1 GPUs the exchange is always on and this picks its mode (none = auto)")
+    ap.add_argument("--deterministic", action="store_true", default=False,
+                    help="graphed two-kernel step only: per-pair gradient rows + a segmented sum in a precomputed order "
+                         "instead of the fp64-atomic scatter, fixed-order sums for the loss and the scale gradient: two "
+                         "runs give the same bits")
     ap.add_argument("--no_graph_step", dest="graph_step", action="store_false", default=True,
                     help="launch the kernels of a step one by one instead of replaying one hipGraph per batch")
     return ap

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Whole training step of the reference's loop (runner.py:98-118: forward, AverageDistortionLoss, backward, gradient clip,
-RiemannianSGD step) as ONE hipGraph replay per batch (sympa_amd/train_step.py), on the BASELINE.json workloads.
+RiemannianSGD step on the table and the scale) as hipGraph replays (sympa_amd/train_step.py), on the BASELINE.json
+workloads, every form the step exists in:
+   classic         round 2's graph (zero, fused loss+backward, norms, RSGD, scale step), the batch copied in per step
+   2k, copy        two kernels per step (train_backward + rsgd_step_fused), the batch copied in per step
+   2k, epoch       two kernels per step, batches addressed by the device step counter: K replays, nothing in between
+   2k, epoch, det  the same with per-pair rows + segmented sum + fixed-order scalar sums (bitwise reproducible)
    python tools/train_step_time.py [steps]"""
 import os
 import sys
@@ -21,8 +26,11 @@ dev = torch.device("cuda:0")
 WORKLOADS = [("grid", "upper", "riem", 2, 125, 512), ("tree", "upper", "riem", 4, 364, 8192),
              ("margulis", "bounded", "finf", 4, 5041, 65536), ("headline", "upper", "riem", 4, 5041, 65536),
              ("cartesian", "upper", "riem", 8, 45500, 262144), ("custom-spd", "spd", "riem", 16, 100000, 1048576)]
+only = os.environ.get("WORKLOADS")
 g = torch.Generator().manual_seed(5)
-for name, manifold, metric, n, nodes, batch in WORKLOADS:
+
+
+def fresh(manifold, metric, n, nodes):
     class A:
         pass
     A.manifold, A.metric, A.dims, A.num_points = manifold, metric, n, nodes
@@ -30,22 +38,49 @@ for name, manifold, metric, n, nodes, batch in WORKLOADS:
     m = Model(A)
     with torch.no_grad():
         if manifold == "spd":
-            m.embeddings.embeds.data = spd_points(nodes, n, 0.3, g)
+            m.embeddings.embeds.data = spd_points(nodes, n, 0.3, torch.Generator().manual_seed(5))
         else:
             m.embeddings.embeds.data = data.trained_like_table(nodes, n, model=manifold, seed=1)
-    m = m.to(dev)
-    opt = RiemannianSGD(m.parameters(), lr=1e-4)
-    step = GraphedTrainStep(m, opt, batch, 50.0, dev)
-    ids = torch.stack((torch.randint(0, nodes, (batch,), generator=g), torch.randint(0, nodes, (batch,), generator=g)), 1).to(dev)
-    gd = torch.randint(1, 9, (batch,), generator=g).to(torch.float64).to(dev)
-    for _ in range(3):
-        step(ids, gd)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(ids, gd)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    ops.check_status(dev)
-    print(f"{name:10s} {manifold:7s} {metric} n={n:2d} nodes={nodes:6d} batch={batch:7d}: {dt * 1e6:10.1f} us per training step  "
-          f"{batch / dt / 1e6:9.2f} M pairs/s trained")
+    return m.to(dev)
+
+
+for name, manifold, metric, n, nodes, batch in WORKLOADS:
+    if only and name not in only.split(","):
+        continue
+    k_epoch = max(steps, 8)
+    trip = torch.stack((torch.randint(0, nodes, (batch * k_epoch,), generator=g),
+                        torch.randint(0, nodes, (batch * k_epoch,), generator=g),
+                        torch.randint(1, 9, (batch * k_epoch,), generator=g)), 1).to(dev)
+    ids, gd = trip[:batch, :2].contiguous(), trip[:batch, 2].to(torch.float64)
+    for form in ("classic", "2k, copy", "2k, epoch", "2k, epoch, det"):
+        m = fresh(manifold, metric, n, nodes)
+        opt = RiemannianSGD(m.parameters(), lr=1e-4)
+        try:
+            step = GraphedTrainStep(m, opt, batch, 50.0, dev, two_kernels=form != "classic", deterministic=form.endswith("det"),
+                                    accumulate_loss=form != "classic")
+        except ValueError:
+            continue
+        if form != "classic" and step.mode != "two_kernels":
+            continue
+        if "epoch" in form:
+            def run(k):
+                step.load_epoch(trip[:batch * k])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step.run_steps(k)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / k
+            run(3)
+            dt = min(run(k_epoch) for _ in range(3))
+        else:
+            for _ in range(3):
+                step(ids, gd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(ids, gd)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        ops.check_status(dev)
+        print(f"{name:10s} {manifold:7s} {metric} n={n:2d} nodes={nodes:6d} batch={batch:7d} [{form:14s}]: {dt * 1e6:10.1f} us per "
+              f"training step  {batch / dt / 1e6:9.2f} M pairs/s trained", flush=True)
