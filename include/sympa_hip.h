@@ -79,9 +79,8 @@ extern "C" {
                                       sixteen lanes per pair, csrc/siegel_coop_bwd.hpp; SYMPA_FLAG_GENERIC selects the same
                                       adjoint as rolled loops over per-lane scratch arrays; SYMPA_FLAG_COOP at n = 7, 8 runs
                                       the sixteen-lanes kernel for A/B) */
-#define SYMPA_MAX_DIMS_ALL_PAIRS_PACKED 7 /* sympa_all_pairs_dist_packed: per-point factor reuse, dims 1..7 (n = 8 does not
-                                             fit the register file next to the packed column point: 9.1 ms against 6.2 ms for
-                                             the pairwise kernel at N = 5 041) */
+#define SYMPA_MAX_DIMS_ALL_PAIRS_PACKED 8 /* sympa_all_pairs_dist_packed: per-point factor reuse, dims 1..8 (dims 8: the 64
+                                             packed column points of a block live in an LDS tile, 55 / 70 KB) */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* n in (SYMPA_MAX_DIMS, 16]: the forward runs sixteen lanes per pair (csrc/siegel_coop.hpp;
                                      SYMPA_FLAG_GENERIC selects the runtime-n fallback over scratch); the table operations
                                      (sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step* / sympa_tangent_sqnorm) run the

@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsympa_hip.so")
+# SYMPA_HIP_LIB: another BUILD of the same library (tools/build_variant.sh: A/B timing, compiler-flag experiments); never a
+# different implementation -- the symbol check below applies to it as well
+LIB_PATH = os.environ.get("SYMPA_HIP_LIB") or os.path.join(_HERE, "csrc", "libsympa_hip.so")
 
 # every symbol include/sympa_hip.h declares (tests check the header against this list)
 SYMBOLS = (

@@ -64,24 +64,49 @@ struct UniformPack {
     __device__ __forceinline__ double operator[](int k) const { return v[k]; }
 };
 
+// column point of a lane kept in LDS: entry k of the 64 points of the tile is one conflict-free 512-byte row
+struct LdsPack {
+    const double* base;       // tile + lane
+    __device__ __forceinline__ double operator[](int k) const { return base[k * 64]; }
+};
+
+// dims 8: the packed column point (108 doubles upper, 136 bounded) does not fit the register file beside E and H
+// (round 2: 9.1 ms against 6.2 ms for the pairwise kernel at N = 5 041).  The four waves of a block work on the SAME column
+// tile (they differ in their row strips), so the tile -- 55 / 70 KB, already laid out [entry][lane] in the workspace -- is
+// copied into LDS once per block and every lane reads its column's entries from there, each once per row point.
+template <int N>
+constexpr bool allpairs_lds_columns() { return N >= 8; }
+
 template <int N, int MODEL>
 __global__ __launch_bounds__(BLOCK) void allpairs_kernel(const AllPairsArgs a) {
     using P = sympa::PointPack<N, MODEL>;
+    constexpr bool LDS_COLS = allpairs_lds_columns<N>();
+    __shared__ double col_tile[LDS_COLS ? P::LEN * 64 : 1];
     const int jt = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t i0 = (int64_t)a.row0 + ((int64_t)blockIdx.y * 4 + wave) * a.rows_per_wave;
     const int it = (int)(i0 >> 6);
+    if constexpr (LDS_COLS) {
+        // block-uniform exit only (a barrier follows): the first wave of the block has the smallest row tile
+        const int it0 = (int)(((int64_t)a.row0 + (int64_t)blockIdx.y * 4 * a.rows_per_wave) >> 6);
+        if (a.symmetric && jt < it0) return;
+        const double* src = a.pack + ((int64_t)jt * P::LEN) * 64;
+        for (int t = threadIdx.x; t < P::LEN * 64 / 2; t += BLOCK)
+            reinterpret_cast<v2d*>(col_tile)[t] = reinterpret_cast<const v2d*>(src)[t];
+        __syncthreads();
+    }
     if (a.symmetric && jt < it) return;
     const int64_t j = (int64_t)jt * 64 + lane;
     const bool jlive = j < a.num_rows;
     // my column point
-    double pj[P::LEN];
-    {
+    double pj_regs[LDS_COLS ? 1 : P::LEN];
+    if constexpr (!LDS_COLS) {
         const double* src = a.pack + ((int64_t)jt * P::LEN) * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < P::LEN; ++k) pj[k] = src[(int64_t)k * 64];
+        for (int k = 0; k < P::LEN; ++k) pj_regs[k] = src[(int64_t)k * 64];
     }
+    const LdsPack pj_lds{col_tile + lane};
     double sc = 1.0;
     if (a.scale != nullptr) sc = fmax(a.scale[0] * a.inv_scale_coef, 0.1);     // model.py:40-41
     int st = 0;
@@ -96,7 +121,8 @@ __global__ __launch_bounds__(BLOCK) void allpairs_kernel(const AllPairsArgs a) {
             for (int k = 0; k < P::LEN; ++k) pi.v[k] = src[(int64_t)k * 64];
         }
         sympa::CMat<N> e;
-        sympa::e_from_packed<N, MODEL>(pi, pj, e);
+        if constexpr (LDS_COLS) sympa::e_from_packed<N, MODEL>(pi, pj_lds, e);
+        else sympa::e_from_packed<N, MODEL>(pi, pj_regs, e);
         double d = sympa::distance_from_e<N, MODEL>(e, true, a.metric, a.metric_w, a.inv_eps, nullptr, st) * sc;
         if (jlive) {
             if (!a.symmetric) {
@@ -202,6 +228,7 @@ int sympa_all_pairs_dist_packed(const double* table, int64_t num_rows, int n, in
         case 5: return launch_allpairs_n<5>(table, num_rows, a, pack, model, s);
         case 6: return launch_allpairs_n<6>(table, num_rows, a, pack, model, s);
         case 7: return launch_allpairs_n<7>(table, num_rows, a, pack, model, s);
+        case 8: return launch_allpairs_n<8>(table, num_rows, a, pack, model, s);
         default: break;
     }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed all-pairs kernel: unsupported dims");

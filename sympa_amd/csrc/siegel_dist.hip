@@ -7,9 +7,8 @@
 // operation is the ballot that ends the Jacobi loop when all 64 pairs have converged.
 // The workload is VALU-fp64 bound: the table rows come out of L2 / Infinity Cache.
 #include <atomic>
-#include "siegel_common.hpp"
+#include "siegel_dist_kernel.hpp"
 #include "siegel_math_generic.hpp"
-#include <hip/hip_ext.h>
 
 namespace sympa_hip {
 
@@ -41,131 +40,6 @@ int validate(const DistArgs& a, int model, int n) {
 
 namespace {
 using namespace sympa_hip;
-
-// Body of one 256-thread block: pairs [first, first + 256) of the batch described by `a`.
-// EXPERIMENT: a spare instantiation selected by flags bit 0x100 for in-process A/B timing (tools/ab_bench.py);
-// identical to the product kernel unless a variant is being measured.
-template <int N, int MODEL, bool LOWLDS>
-struct BlockLds {
-    static constexpr bool PASS4 = (N == 4) && LOWLDS;   // minimum-LDS gather: three blocks of different launches per CU
-    static constexpr int WAVE_SLOTS = PASS4 ? PASS4_WAVE_SLOTS
-                                      : DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
-                                      : (PassTile<N>::ENABLED ? PassTile<N>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
-};
-
-template <int N, int MODEL, bool LOWLDS>
-__device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t first, v2d* __restrict__ lds) {
-    constexpr bool PASS4 = BlockLds<N, MODEL, LOWLDS>::PASS4;
-    constexpr int WAVE_SLOTS = BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS;
-    const int64_t i = first + threadIdx.x;
-    const bool live = i < a.b;
-    const int64_t ii = live ? i : a.b - 1;   // idle tail lanes recompute the last pair (wave ballots need them)
-
-    int st = 0;
-    int64_t r1 = ii, r2 = ii;
-    if (a.ap_cols > 0) {          // all-pairs block of the distance matrix (runner.py:142-154)
-        ap_pair(a, ii, r1, r2);
-    } else if (a.idx1 != nullptr) {
-        // index batches and outputs stream through once: non-temporal, so they do not evict table rows from L2
-        r1 = __builtin_nontemporal_load(a.idx1 + ii * a.idx1_stride);
-        r2 = __builtin_nontemporal_load(a.idx2 + ii * a.idx2_stride);
-        if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) {
-            st |= sympa::ST_BAD_INDEX;
-            r1 = 0;
-            r2 = 0;
-        }
-    }
-    constexpr int64_t ROW = 2 * N * N;
-    double* vv = (a.vvd != nullptr && live) ? a.vvd + i * N : nullptr;
-    double d;
-    if constexpr (PassTile<N>::ENABLED) {
-        sympa::CMat<N> z1, z2;
-        v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
-        gather_pair_passes<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
-        d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);
-    } else if constexpr (Tile<N>::STAGED) {
-        sympa::CMat<N> z1, z2;
-        v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
-        if constexpr (PASS4)
-            gather_pair_pass4(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
-        else if constexpr (DmaTile<N>::ENABLED && LOWLDS)
-            gather_pair_dma_low<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
-        else if constexpr (DmaTile<N>::ENABLED)
-            gather_pair_dma_split<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
-        else
-            gather_pair_staged<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
-        d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);
-    } else {
-        d = sympa::pair_distance<N, MODEL>(a.base1 + r1 * ROW, a.base2 + r2 * ROW, a.metric, a.metric_w,
-                                           a.inv_eps, vv, st);
-    }
-    if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
-    if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
-    if (live) {
-        if (a.ap_cols > 0) ap_store(a, i, r1, r2, d);
-        else __builtin_nontemporal_store(d, a.out + i);
-    }
-
-    if (a.status != nullptr) {
-        const int flagged = (live && st != 0) ? 1 : 0;
-        const unsigned long long m = __ballot(flagged);
-        if (m != 0ull) {   // rare path
-            if (flagged) atomicOr(&a.status[0], st);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
-        }
-    }
-}
-
-// Blocks per CU the compiler must make room for (dims >= 5).  1: one 512-register wave per SIMD.  A/B hook
-// (tools/build_variant.sh -DSYMPA_FWD_BIG_BLOCKS=2: two 256-register waves per SIMD, the rest spilled to scratch).
-#ifndef SYMPA_FWD_BIG_BLOCKS
-#define SYMPA_FWD_BIG_BLOCKS 1
-#endif
-template <int N> constexpr int fwd_min_blocks() { return N >= 5 ? SYMPA_FWD_BIG_BLOCKS : 1; }
-
-template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
-__global__ __launch_bounds__(BLOCK, fwd_min_blocks<N>()) void siegel_dist_kernel(const DistArgs a) {
-    __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
-    dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * BLOCK, lds);
-}
-
-// Several batches in ONE launch (C-ABI sympa_model_forward_batches with SYMPA_FLAG_FUSE): block x belongs to the
-// batch k with blk_end[k-1] <= x < blk_end[k]; the batches share table, metric and scale and differ in their index
-// list, size and output.  The grid is several blocks per CU deep, so the minimum-LDS gather form is used: three
-// blocks of different batches share a CU and one batch's gather hides behind another's arithmetic -- what
-// overlapping the launches on streams achieves, without kernel boundaries, fork/join dependencies or idle SIMDs
-// when a batch is smaller than one wave per SIMD.
-struct MultiArgs {
-    DistArgs c;                                    // idx1/idx2/out/b are taken from the lists below
-    const int64_t* trip[SYMPA_MAX_FUSED_BATCHES];
-    double* out[SYMPA_MAX_FUSED_BATCHES];
-    int64_t b[SYMPA_MAX_FUSED_BATCHES];
-    unsigned blk_end[SYMPA_MAX_FUSED_BATCHES];     // exclusive prefix end, in blocks
-    int num_batches;
-};
-
-template <int N, int MODEL>
-__global__ __launch_bounds__(BLOCK) void siegel_dist_multi_kernel(const MultiArgs m) {
-    constexpr bool LOW = DmaTile<N>::ENABLED;
-    __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOW>::WAVE_SLOTS];
-    // batch of this block: binary search over <= 32 prefix ends (block-uniform, scalar)
-    int lo = 0, hi = m.num_batches - 1;
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int mid = (lo + hi) >> 1;
-        const bool right = blockIdx.x >= m.blk_end[mid];
-        lo = right ? mid + 1 : lo;
-        hi = right ? hi : mid;
-    }
-    const int k = lo;
-    const unsigned blk0 = (k == 0) ? 0u : m.blk_end[k - 1];
-    DistArgs a = m.c;
-    a.idx1 = m.trip[k];
-    a.idx2 = m.trip[k] + 1;
-    a.out = m.out[k];
-    a.b = m.b[k];
-    dist_block<N, MODEL, LOW>(a, (int64_t)(blockIdx.x - blk0) * BLOCK, lds);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Backward.  Same lane-per-pair mapping; the forward quantities are recomputed.
@@ -209,39 +83,6 @@ __global__ __launch_bounds__(64) void siegel_dist_generic_kernel(const DistArgs 
     }
 }
 
-// One launch.  SYMPA_FLAG_ANY_ORDER: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch), so the command
-// processor may start it while earlier launches of the SAME stream are still running -- independent steps overlap
-// without any cross-stream dependency.
-template <typename K>
-hipError_t launch_kernel(K kern, unsigned grid, const DistArgs& a, hipStream_t s) {
-    if (a.flags & SYMPA_FLAG_ANY_ORDER) {
-        void* args[] = {const_cast<DistArgs*>(&a)};
-        return hipExtLaunchKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(BLOCK), args, 0, s, nullptr,
-                                  nullptr, hipExtAnyOrderLaunch);
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, a);
-    return hipGetLastError();
-}
-
-template <int N>
-int launch_n(const DistArgs& a, int model, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
-    // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
-    const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256);
-    hipError_t e;
-    if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
-        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, a, s);
-    } else if (model == SYMPA_MODEL_UPPER) {
-        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, a, s);
-        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, a, s);
-    } else {
-        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>, grid, a, s);
-        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>, grid, a, s);
-    }
-    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    return 0;
-}
-
 int launch(const DistArgs& a, int n, int model, void* stream) {
     if (a.b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (a.b == 0) return 0;
@@ -262,10 +103,7 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
         case 2: return launch_n<2>(a, model, s);
         case 3: return launch_n<3>(a, model, s);
         case 4: return launch_n<4>(a, model, s);
-        case 5: return launch_n<5>(a, model, s);
-        case 6: return launch_n<6>(a, model, s);
-        case 7: return launch_n<7>(a, model, s);
-        case 8: return launch_n<8>(a, model, s);
+        case 5: case 6: case 7: case 8: return launch_dist_big(a, n, model, s);
         default: break;
     }
     if (n > SYMPA_MAX_DIMS && n <= sympa::GENERIC_MAX_N) {
@@ -277,17 +115,6 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
         return 0;
     }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "dims outside [1, SYMPA_MAX_DIMS_GENERIC]");
-}
-
-template <int N>
-int launch_multi_n(const MultiArgs& m, unsigned grid, int model, hipStream_t s) {
-    if (model == SYMPA_MODEL_UPPER)
-        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, m);
-    else
-        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, m);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    return 0;
 }
 
 int launch_multi(const double* table, int64_t num_rows, int n, const int64_t* const* triplets, int64_t stride,
@@ -340,10 +167,7 @@ int launch_multi(const double* table, int64_t num_rows, int n, const int64_t* co
         case 2: return launch_multi_n<2>(m, (unsigned)blocks, model, s);
         case 3: return launch_multi_n<3>(m, (unsigned)blocks, model, s);
         case 4: return launch_multi_n<4>(m, (unsigned)blocks, model, s);
-        case 5: return launch_multi_n<5>(m, (unsigned)blocks, model, s);
-        case 6: return launch_multi_n<6>(m, (unsigned)blocks, model, s);
-        case 7: return launch_multi_n<7>(m, (unsigned)blocks, model, s);
-        case 8: return launch_multi_n<8>(m, (unsigned)blocks, model, s);
+        case 5: case 6: case 7: case 8: return launch_multi_big(m, (unsigned)blocks, n, model, s);
         default: break;
     }
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "fused batches need dims <= SYMPA_MAX_DIMS");

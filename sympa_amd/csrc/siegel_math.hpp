@@ -943,64 +943,80 @@ SYMPA_UNROLL
     return ok;
 }
 
-// E = A1 (Z2 - Z1) A2^T from two packed points.  P1 / P2 are any indexable sources of doubles (registers, or scalar
-// registers for the wave-uniform row point of the all-pairs kernel).
+// E = A1 (Z2 - Z1) A2^T from two packed points.  P1 / P2 are any indexable sources of doubles (registers, scalar
+// registers for the wave-uniform row point of the all-pairs kernel, or a column of an LDS tile for the dims-8 column
+// points).  Everything happens IN PLACE in e, one n x n complex matrix: D = Z2 - Z1, then T = A1 D with the rows taken
+// from the last to the first (row r of T needs rows k <= r of D only), then E = T A2^T with the columns taken from the last
+// to the first -- the products of an 8 x 8 pair then fit the register file next to nothing else (the ascending order kept
+// D, T and E alive together: 384 doubles).  Every entry of p1 / p2 is read once (twice for the points themselves).
 template <int N, int MODEL, class P1, class P2>
 SYMPA_HD void e_from_packed(const P1& p1, const P2& p2, CMat<N>& e) {
     using P = PointPack<N, MODEL>;
     constexpr bool CPLX = MODEL != MODEL_UPPER;
     // D = Z2 - Z1 (symmetric: upper triangle)
-    double dr[N][N], di[N][N];
 SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
 SYMPA_UNROLL
         for (int j = i; j < N; ++j) {
-            dr[i][j] = p2[tri_index(N, i, j)] - p1[tri_index(N, i, j)];
-            di[i][j] = p2[P::OFF_IM + tri_index(N, i, j)] - p1[P::OFF_IM + tri_index(N, i, j)];
-            dr[j][i] = dr[i][j];
-            di[j][i] = di[i][j];
+            const double xr = p2[tri_index(N, i, j)] - p1[tri_index(N, i, j)];
+            const double xi = p2[P::OFF_IM + tri_index(N, i, j)] - p1[P::OFF_IM + tri_index(N, i, j)];
+            e.re[i][j] = xr; e.im[i][j] = xi;
+            e.re[j][i] = xr; e.im[j][i] = xi;
         }
-    // T = A1 D   (A1 lower triangular)
-    double tr[N][N], ti[N][N];
+    // T = A1 D   (A1 lower triangular), rows N-1 .. 0
 SYMPA_UNROLL
-    for (int r = 0; r < N; ++r)
+    for (int rr = 0; rr < N; ++rr) {
+        const int r = N - 1 - rr;
+        const double dg = p1[P::OFF_DIAG + r];
+        double lr[N], li[N];
+SYMPA_UNROLL
+        for (int k = 0; k < r; ++k) {
+            lr[k] = p1[P::OFF_LRE + low_index(r, k)];
+            if constexpr (CPLX) li[k] = p1[P::OFF_LIM + low_index(r, k)];
+        }
 SYMPA_UNROLL
         for (int c = 0; c < N; ++c) {
-            double xr = p1[P::OFF_DIAG + r] * dr[r][c], xi = p1[P::OFF_DIAG + r] * di[r][c];
+            double xr = dg * e.re[r][c], xi = dg * e.im[r][c];
 SYMPA_UNROLL
             for (int k = 0; k < r; ++k) {
-                const double lr = p1[P::OFF_LRE + low_index(r, k)];
-                xr = d_fma(lr, dr[k][c], xr);
-                xi = d_fma(lr, di[k][c], xi);
+                xr = d_fma(lr[k], e.re[k][c], xr);
+                xi = d_fma(lr[k], e.im[k][c], xi);
                 if constexpr (CPLX) {
-                    const double li = p1[P::OFF_LIM + low_index(r, k)];
-                    xr = d_fma(-li, di[k][c], xr);
-                    xi = d_fma(li, dr[k][c], xi);
-                }
-            }
-            tr[r][c] = xr;
-            ti[r][c] = xi;
-        }
-    // E = T A2^T (plain transpose):  E[r][c] = sum_{k <= c} T[r][k] A2[c][k]
-SYMPA_UNROLL
-    for (int r = 0; r < N; ++r)
-SYMPA_UNROLL
-        for (int c = 0; c < N; ++c) {
-            double xr = tr[r][c] * p2[P::OFF_DIAG + c], xi = ti[r][c] * p2[P::OFF_DIAG + c];
-SYMPA_UNROLL
-            for (int k = 0; k < c; ++k) {
-                const double lr = p2[P::OFF_LRE + low_index(c, k)];
-                xr = d_fma(tr[r][k], lr, xr);
-                xi = d_fma(ti[r][k], lr, xi);
-                if constexpr (CPLX) {
-                    const double li = p2[P::OFF_LIM + low_index(c, k)];
-                    xr = d_fma(-ti[r][k], li, xr);
-                    xi = d_fma(tr[r][k], li, xi);
+                    xr = d_fma(-li[k], e.im[k][c], xr);
+                    xi = d_fma(li[k], e.re[k][c], xi);
                 }
             }
             e.re[r][c] = xr;
             e.im[r][c] = xi;
         }
+    }
+    // E = T A2^T (plain transpose):  E[r][c] = sum_{k <= c} T[r][k] A2[c][k], columns N-1 .. 0
+SYMPA_UNROLL
+    for (int cc = 0; cc < N; ++cc) {
+        const int c = N - 1 - cc;
+        const double dg = p2[P::OFF_DIAG + c];
+        double lr[N], li[N];
+SYMPA_UNROLL
+        for (int k = 0; k < c; ++k) {
+            lr[k] = p2[P::OFF_LRE + low_index(c, k)];
+            if constexpr (CPLX) li[k] = p2[P::OFF_LIM + low_index(c, k)];
+        }
+SYMPA_UNROLL
+        for (int r = 0; r < N; ++r) {
+            double xr = e.re[r][c] * dg, xi = e.im[r][c] * dg;
+SYMPA_UNROLL
+            for (int k = 0; k < c; ++k) {
+                xr = d_fma(e.re[r][k], lr[k], xr);
+                xi = d_fma(e.im[r][k], lr[k], xi);
+                if constexpr (CPLX) {
+                    xr = d_fma(-e.im[r][k], li[k], xr);
+                    xi = d_fma(e.re[r][k], li[k], xi);
+                }
+            }
+            e.re[r][c] = xr;
+            e.im[r][c] = xi;
+        }
+    }
 }
 
 // Same, reading the two points straight from memory (lane-per-row loads; used for n > 4 and on the host).

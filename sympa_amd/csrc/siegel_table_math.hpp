@@ -132,6 +132,36 @@ SYMPA_UNROLL
 template <int N, int MODEL>
 SYMPA_HD bool projx(CMat<N>& z, double eps, int& status) {
     symmetrise<N>(z);
+    // Cheap certificate first: the row is inside the eps-interior iff a Cholesky factorisation exists (upper: Im z - eps I
+    // positive definite <=> every eigenvalue > eps; bounded: I - Z Z^H / (1 - eps)^2 positive definite <=> every Takagi value
+    // < 1 - eps).  When it holds for all 64 rows of the wave -- every step of a converging run -- the eigendecomposition
+    // (~25 x the instructions) is skipped and the rows stay untouched, exactly what the reference's mask does
+    // (upper_half.py:42-66, bounded_domain.py:55-84).  The certificate is taken a hair (1e-9) inside the boundary, so a row
+    // within rounding of it still gets the exact path and the reference's own comparison.
+    {
+        constexpr double HAIR = 1e-9;
+        bool certain;
+        if (MODEL == MODEL_UPPER) {
+            double a[N][N];
+            const double shift = eps * (1.0 + HAIR);
+SYMPA_UNROLL
+            for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+                for (int j = 0; j < N; ++j) a[i][j] = (i == j) ? z.im[i][j] - shift : z.im[i][j];
+            Tri<N, false> l;
+            certain = chol_real<N>(a, l);
+        } else {
+            CMat<N> ws;
+            const double inv = 1.0 / ((1.0 - eps) * (1.0 - HAIR));
+SYMPA_UNROLL
+            for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+                for (int j = 0; j < N; ++j) { ws.re[i][j] = z.re[i][j] * inv; ws.im[i][j] = z.im[i][j] * inv; }
+            Tri<N, true> c;
+            certain = chol_id_minus_wwh<N>(ws, c);
+        }
+        if (wave_all(certain)) return false;
+    }
     if (MODEL == MODEL_UPPER) {
         double a[N][N], d[N], v[N][N];
 SYMPA_UNROLL

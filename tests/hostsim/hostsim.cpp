@@ -78,6 +78,7 @@ extern "C" int sympa_hostsim_dist_packed(const double* z1, const double* z2, int
         case 5: run_packed_n<5>(z1, z2, b, model, metric, w, eps, out, status); return 0;
         case 6: run_packed_n<6>(z1, z2, b, model, metric, w, eps, out, status); return 0;
         case 7: run_packed_n<7>(z1, z2, b, model, metric, w, eps, out, status); return 0;
+        case 8: run_packed_n<8>(z1, z2, b, model, metric, w, eps, out, status); return 0;
         default: return -2;
     }
 }

@@ -455,7 +455,7 @@ def test_integration_md_stub_runs_on_the_gpu(dev):
             assert torch.equal(z1.grad, y1.grad) and torch.equal(z2.grad, y2.grad)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_all_pairs_packed_kernel(dev, model, n):
     """sympa_all_pairs_dist_packed (every point factored once, inverted factor, wave-uniform row point, symmetric full

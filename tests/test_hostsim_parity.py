@@ -114,7 +114,7 @@ def test_nonfinite_input_generic_large_n(n):
             assert np.isnan(out[0]) and (st & 2)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_packed_point_path_of_the_all_pairs_kernel(model, n):
     """All-pairs matrix (runner.py:142-154): points are packed once with their INVERTED Cholesky factor and a pair costs
@@ -131,7 +131,7 @@ def test_packed_point_path_of_the_all_pairs_kernel(model, n):
             assert st == 0 and np.all(got[:5] == 0.0)
             assert rel_err(got, ref) < 1e-10, (model, n, s, metric)
             assert rel_err(got, so.manifold_dist(model, z1, z2, metric, w)) < TOL
-    if n in (2, 3, 4):
+    if n in (2, 3, 4, 8):
         gold = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
         for case in gold["case_names"]:
             got, st = hostsim_dist_packed(gold[f"{case}__z1"], gold[f"{case}__z2"], model, "riem")
