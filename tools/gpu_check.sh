@@ -1,19 +1,32 @@
 #!/bin/bash
-# One gpurun call: GPU tests, smoke, bench at the driver's K and at the default K, rocprofv3 kernel trace + PMC passes.
+# One gpurun call: GPU tests, smoke, the numerical self-check of every lanes-per-pair kernel instantiation, bench at the
+# driver's K and at the default K, rocprofv3 kernel trace + PMC passes, secondary workloads, training path.
 # usage: tools/gpu_check.sh <tag> [notests]
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+FAIL=0
 if [ "$2" != "notests" ]; then
 echo "== pytest -m gpu" | tee $OUT/pytest.log
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee -a $OUT/pytest.log
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee -a $OUT/pytest.log
+grep -q " passed" $OUT/pytest.log && ! grep -q "failed" $OUT/pytest.log || FAIL=1
 echo "== smoke" | tee $OUT/smoke.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $OUT/smoke.log
 fi
+echo "== self-check gate: every (family, model, n) of the lanes-per-pair kernels against the one-lane kernels" | tee $OUT/selfcheck.txt
+timeout 600 python -c "
+import torch, sys
+from sympa_amd import selfcheck
+f = selfcheck.check_all(torch.device('cuda:0'))
+print(len(selfcheck.CHECKED), 'instantiations checked,', len(f), 'routed to the one-lane kernels')
+for x in f: print('  FALLBACK', x)
+sys.exit(1 if f else 0)" 2>&1 | grep -v amdgpu.ids | tee -a $OUT/selfcheck.txt
+[ ${PIPESTATUS[0]} -eq 0 ] || FAIL=1
 echo "== bench (driver's command line, then defaults)"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_k20.err | tail -1 | tee $OUT/bench_k20.json | cut -c1-300
 timeout 600 python bench.py 2>$OUT/bench.err | tail -1 | tee $OUT/bench.json | cut -c1-300
+SYMPA_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>$OUT/bench_k20_dist.err | tail -1 | tee $OUT/bench_k20_forcedist.json | cut -c1-200
 echo "== rocprof kernel trace (same commands)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k20 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_k20.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline > $OUT/prof_bench.log 2>&1
@@ -29,18 +42,27 @@ for W in margulis-bounded-finf-n4-b65536 cartesian-upper-riem-n8-b262144 custom-
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --steps 64 --warmup 8 --launch graph --streams 1 > $OUT/prof_$W.log 2>&1
   find $OUT/prof_$W -name "*kernel_stats.csv" | head -1 | xargs -r head -2
 done
-echo "== training-path kernels (times, A/B against the one-lane kernels, whole graphed step, soak)"
+echo "== the graph workloads on their real (i < j, d) triplets (--pairs graph: evaluation order; graph-shuffled: training order)"
+for W in grid-upper-riem-n2-b512 tree-upper-riem-n4-b8192 margulis-bounded-finf-n4-b65536; do
+  for P in graph graph-shuffled; do
+    timeout 600 python bench.py --workload $W --pairs $P --steps 64 --warmup 8 --no-cpu-baseline 2>>$OUT/bench_graph.err | tail -1 | tee -a $OUT/bench_graph_pairs.json | cut -c1-200
+  done
+done
+echo "== evaluation epoch of the harness (Model.evaluate on configs[1]'s 596 778 triplets, batch 8192)"
+timeout 300 python3 tools/eval_time.py 2>&1 | grep -v amdgpu.ids | tee $OUT/eval_epoch.txt
+echo "== training-path kernels (times, A/Bs, whole graphed step, soak)"
 {
   timeout 300 python3 tools/bwd_time_dims.py 2>&1 | grep "fused"
-  timeout 300 python3 tools/bwd_coop_ab_small.py 262144 upper 2>&1 | grep "n="
-  timeout 300 python3 tools/bwd_coop_ab_small.py 262144 bounded 2>&1 | grep "n="
-  timeout 300 python3 tools/bwd_coop_ab.py upper 65536 9 10 12 16 2>&1 | grep backward
-  timeout 300 python3 tools/bwd_coop_ab.py bounded 65536 9 10 12 16 2>&1 | grep backward
-  timeout 300 python3 tools/spd_bwd_ab.py 65536 4 8 12 16 2>&1 | grep "spd backward"
+  timeout 300 python3 tools/det_ab.py upper 2>&1 | grep "n="
+  timeout 300 python3 tools/det_ab.py bounded 2>&1 | grep "n="
   timeout 300 python3 tools/spd_time.py 16 1048576 100000 --train 2>&1 | grep "spd n="
   timeout 300 python3 tools/table_time.py upper 45500 8 2>&1 | grep rows=
-  timeout 300 python3 tools/table_time.py upper 5041 10 16 2>&1 | grep rows=
-  timeout 300 python3 tools/train_step_time.py 20 2>&1 | grep "training step"
+  timeout 300 python3 tools/train_step_time.py 50 2>&1 | grep "training step"
   timeout 300 python3 tools/fuzz_coop_bwd.py 120 2>&1 | tail -1
   timeout 200 python3 tools/fuzz_coop.py 60 2>&1 | tail -1
 } | tee $OUT/training_path.txt
+echo "== rocprof kernel trace of the two-kernel training step (headline shape)"
+WORKLOADS=headline timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -- python3 tools/train_step_time.py 50 > $OUT/prof_train.log 2>&1
+find $OUT/prof_train -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | tee $OUT/train_kernel_stats_head.txt
+echo "== gpu_check status: FAIL=$FAIL"
+exit $FAIL
