@@ -81,5 +81,7 @@ int validate(const DistArgs& a, int model, int n);
 
 // siegel_coop.hip: 9 <= n <= 16, sixteen lanes per pair
 int launch_siegel_coop(const DistArgs& a, int n, int model, hipStream_t s);
+// siegel_coop_half.hip: dims 7, 8 with eight lanes per pair (SYMPA_FLAG_COOP; A/B only)
+int launch_siegel_coop_half(const DistArgs& a, int n, int model, hipStream_t s);
 
 }  // namespace sympa_hip

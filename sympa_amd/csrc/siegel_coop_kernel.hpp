@@ -15,15 +15,21 @@ namespace sympa_hip {
 // (upper: M <= 12 needs 230 registers; bounded, whose factors are complex: M <= 10 needs 254, M = 11 would spill)
 template <int MODEL, int M>
 constexpr bool coop_two_waves() { return M <= (MODEL == sympa::MODEL_UPPER ? 12 : 10); }
+// Pairs per wave and round / rounds per wave: 4 and 16 with sixteen lanes per pair; 8 and 8 in a unit that defines
+// SYMPA_COOP_HALF (eight lanes per pair, M <= 8; siegel_coop_half.hip: the A/B of the dims 7, 8 forward against the
+// one-pair-per-lane kernels).  Lane GROUP g + t owns pair GPW t + g of the wave in the one-pair-per-lane QL phase.
+constexpr int COOP_GPW = spd_coop::GROUPS_PER_WAVE;
+constexpr int COOP_ROUNDS = 64 / COOP_GPW;
 
 template <int MODEL, int M>
 __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void siegel_coop_kernel(const DistArgs a) {
     constexpr bool PREFETCH = !coop_two_waves<MODEL, M>();
     using namespace siegel_coop;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[COOP_GPW * N * N];
+    static_assert(M <= spd_coop::GROUP, "matrix rows per group");
     const int lane = threadIdx.x;
-    const int g = lane >> 4, r = lane & 15;
-    const int64_t i = (int64_t)blockIdx.x * 64 + 4 * r + g;
+    const int g = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
+    const int64_t i = (int64_t)blockIdx.x * 64 + COOP_GPW * r + g;
     const bool live = i < a.b;
     const int64_t ii = live ? i : a.b - 1;
     int st = 0;
@@ -47,8 +53,8 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
     // latency of the 4 M loads); a phantom lane reads element 0 of its pair's rows
     double fa[M], fb[M], fc[M], fd[M];
     auto fetch = [&](const int t) {
-        const int ra = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row1);     // the rows of my group's pair
-        const int rb = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row2);
+        const int ra = __builtin_amdgcn_ds_bpermute(4 * (spd_coop::GROUP * g + t), row1);     // the rows of my group's pair
+        const int rb = __builtin_amdgcn_ds_bpermute(4 * (spd_coop::GROUP * g + t), row2);
         const double* pa = a.base1 + (size_t)(unsigned)ra * (size_t)(2 * nn);
         const double* pb = a.base2 + (size_t)(unsigned)rb * (size_t)(2 * nn);
 #pragma unroll
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
         }
     };
     if constexpr (PREFETCH) fetch(0);
-    for (int t = 0; t < spd_coop::ROUNDS; ++t) {
+    for (int t = 0; t < COOP_ROUNDS; ++t) {
         double er[M], ei[M];
         bool pd1, pd2;
         if constexpr (!PREFETCH) fetch(t);
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
                 y1[j] = fb[j];
                 y2[j] = fd[j];
             }
-            if constexpr (PREFETCH) if (t + 1 < spd_coop::ROUNDS) fetch(t + 1);
+            if constexpr (PREFETCH) if (t + 1 < COOP_ROUNDS) fetch(t + 1);
             double rd1[M], rd2[M];
             pd1 = spd_coop::cholesky_rows(y1, rd1);
             pd2 = spd_coop::cholesky_rows(y2, rd2);
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
             double w1r[M], w1i[M], w2r[M], w2i[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) { w1r[j] = fa[j]; w1i[j] = fb[j]; w2r[j] = fc[j]; w2i[j] = fd[j]; }
-            if constexpr (PREFETCH) if (t + 1 < spd_coop::ROUNDS) fetch(t + 1);
+            if constexpr (PREFETCH) if (t + 1 < COOP_ROUNDS) fetch(t + 1);
             double dr[M], di[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) { dr[j] = w2r[j] - w1r[j]; di[j] = w2i[j] - w1i[j]; }

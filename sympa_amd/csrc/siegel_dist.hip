@@ -97,7 +97,8 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     if (n <= 4 && a.num_rows * 16 * n * n >= ((int64_t)1 << 32))
         return fail(SYMPA_ERR_BAD_ARG, "tables of dims <= 4 are limited to 4 GiB (32-bit row offsets in the gather)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if ((a.flags & SYMPA_FLAG_COOP) && (n == 6 || n == 8)) return launch_siegel_coop(a, n, model, s);   // A/B only
+    if ((a.flags & SYMPA_FLAG_COOP) && (n == 7 || n == 8)) return launch_siegel_coop_half(a, n, model, s);   // A/B only: eight lanes per pair
+    if ((a.flags & SYMPA_FLAG_COOP) && n == 6) return launch_siegel_coop(a, n, model, s);                 // A/B only: sixteen
     switch (n) {
         case 1: return launch_n<1>(a, model, s);
         case 2: return launch_n<2>(a, model, s);

@@ -655,3 +655,26 @@ def test_selfcheck_gate_passes_for_every_instantiation_and_falls_back_when_told(
     finally:
         lib.sympa_set_instance_fallback(selfcheck.SPD_BWD, 0, 7, 0)
     assert float((a - b_).abs().max()) < 1e-9 * float(a.abs().max()) and abs(float(la - lb)) < 1e-9 * float(la)
+
+
+@pytest.mark.parametrize("n", [7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_eight_lanes_per_pair_forward_ab_kernel(dev, model, n):
+    """SYMPA_FLAG_COOP at dims 7, 8: the forward with eight lanes per pair (two pairs per DPP row; csrc/siegel_coop_half.hip),
+    kept for the A/B against the one-pair-per-lane register kernels: same distances, ragged batches, the gathered form."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(1700 + n)
+    for b, s in ((1, 0.3), (67, 1e-3), (1000, 0.3), (4099, 0.6)):
+        z1, z2 = points(model, b, n, s, g), points(model, b, n, s, g)
+        for metric in ("riem", "fmin"):
+            a = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), model, metric, flags=ops.FLAG_COOP).cpu()
+            c = ops.siegel_dist_forward(z1.to(dev), z2.to(dev), model, metric).cpu()
+            ops.check_status(dev)
+            assert rel_err(a, c) < 1e-10, (model, n, b, metric)
+            assert rel_err(a, so.manifold_dist(model, z1, z2, metric)) < 1e-8
+    table = points(model, 300, n, 0.3, g).to(dev)
+    trip = torch.randint(0, 300, (2500, 3), generator=g).to(dev)
+    sc = torch.tensor([1.3], device=dev)
+    a = ops.model_forward(table, trip, model, "riem", None, sc, 2.0, flags=ops.FLAG_COOP)
+    c = ops.model_forward(table, trip, model, "riem", None, sc, 2.0)
+    assert rel_err(a.cpu(), c.cpu()) < 1e-10
