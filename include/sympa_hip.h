@@ -294,11 +294,14 @@ int sympa_model_train_backward(const double* table, int64_t num_rows, int n, con
  * step_counter c (device int64, may be NULL) the lists of batch c are used: order + c * order_stride, rowptr + c *
  * (num_rows + 1) (sympa_amd/train_step.py builds them for a whole epoch with one sort).  wave_partials (may be NULL): see
  * sympa_model_train_backward; partial_stride = 2 + n (doubles per wavefront), num_weights = n for the wsum metric, else 0
- * (then grad_w may be NULL); grad_scale may be NULL. */
+ * (then grad_w may be NULL); grad_scale may be NULL.  sq_partials (may be NULL; needs wave_partials): [sympa_segment_sum_
+ * partials(num_rows, row_doubles)] fp64, WRITTEN: one sum of squares of the finished gradient per block in a fixed tree, the
+ * last one for the scale / weight gradients -- sympa_rsgd_step_fused adds them in index order instead of making its own pass. */
+int64_t sympa_segment_sum_partials(int64_t num_rows, int row_doubles);
 int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32_t* rowptr, int64_t num_rows, int row_doubles,
                            int64_t order_stride, const int64_t* step_counter, double alpha, int accumulate, double* grad_table,
                            const double* wave_partials, int64_t num_waves, int partial_stride, int num_weights, double* loss,
-                           double* grad_scale, double* grad_w, void* stream);
+                           double* grad_scale, double* grad_w, double* sq_partials, void* stream);
 
 /* The optimiser side of one training step as ONE launch (sympa/runner.py:113-118: clip_grad_norm_(parameters, max_norm),
  * optimizer.step(), zero_grad()), dims 1..6, tables of at most (CUs x 256) rows (a grid barrier inside: every block must be
@@ -310,14 +313,16 @@ int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32
  *   zero_grads != 0: grad and extra_grad[k] are zeroed (the next step's backward accumulates into them);
  *   step_counter (device int64, may be NULL) += 1: the batch index the next sympa_model_loss_backward_indexed call reads.
  * extra_*: up to 2 parameters without a manifold (the model's scale, the wsum weights), 1..64 elements each.
+ * sq_partials (may be NULL): partial sums of squares that sympa_segment_sum_rows left -- then `total` is their sum in index
+ * order and the kernel makes no pass over the gradient and needs no barrier (the deterministic training step).
  * workspace: sympa_rsgd_step_fused_workspace_bytes(num_rows) bytes of device memory, ZERO before the first call (the
  * kernel leaves it ready for the next one); one workspace per concurrently running step. */
 int64_t sympa_rsgd_step_fused_workspace_bytes(int64_t num_rows);
 int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
                           double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
                           const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
-                          void* workspace, int64_t workspace_bytes, int64_t* step_counter, int32_t* projected_count,
-                          int32_t* status, void* stream);
+                          void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
+                          int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream);
 
 /* ---- SPD model (manifold "spd": geoopt.manifolds.SymmetricPositiveDefinite, sympa/embeddings.py:6,70-72,142) ----
  * Points are [n, n] fp64 symmetric positive definite matrices (upper triangle read), n <= 16.

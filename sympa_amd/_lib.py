@@ -39,6 +39,7 @@ SYMBOLS = (
     "sympa_rsgd_step_clipped",
     "sympa_model_train_backward",
     "sympa_segment_sum_rows",
+    "sympa_segment_sum_partials",
     "sympa_rsgd_step_fused_workspace_bytes",
     "sympa_rsgd_step_fused",
     "sympa_spd_dist_fwd",
@@ -161,15 +162,18 @@ def load():
     lib.sympa_segment_sum_rows.argtypes = [
         _c_double_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_double, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p,
-        _c_double_p, _c_double_p, ctypes.c_void_p,
+        _c_double_p, _c_double_p, _c_double_p, ctypes.c_void_p,
     ]
+    lib.sympa_segment_sum_partials.restype = ctypes.c_int64
+    lib.sympa_segment_sum_partials.argtypes = [ctypes.c_int64, ctypes.c_int]
     lib.sympa_rsgd_step_fused_workspace_bytes.restype = ctypes.c_int64
     lib.sympa_rsgd_step_fused_workspace_bytes.argtypes = [ctypes.c_int64]
     lib.sympa_rsgd_step_fused.restype = ctypes.c_int
     lib.sympa_rsgd_step_fused.argtypes = [
         _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
         ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _c_i32_p, _c_i32_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, ctypes.c_void_p, _c_i32_p,
+        _c_i32_p, ctypes.c_void_p,
     ]
     lib.sympa_rsgd_step.restype = ctypes.c_int
     lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,

@@ -71,9 +71,10 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
                                                                  double alpha, int accumulate, double* __restrict__ grad,
                                                                  const double* __restrict__ wave_partials, int64_t num_waves,
                                                                  int quantities, int partial_stride, double* loss, double* gscale,
-                                                                 double* gw, unsigned row_blocks) {
+                                                                 double* gw, unsigned row_blocks, double* sq_partials) {
     __shared__ double red[BLOCK];
     if (blockIdx.x >= row_blocks) {
+        double extra_sq = 0.0;
         // fixed-order sums of the per-wave partials: thread t takes waves t, t + 256, ...; then a tree over the block
         for (int k = 0; k < quantities; ++k) {
             double s = 0.0;
@@ -86,17 +87,33 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
             }
             if (threadIdx.x == 0) {
                 double* dst = (k == 0) ? loss : (k == 1 ? gscale : (gw != nullptr ? gw + (k - 2) : nullptr));
-                if (dst != nullptr) dst[0] += red[0];
+                if (dst != nullptr) {
+                    const double v = dst[0] + red[0];
+                    dst[0] = v;
+                    if (k >= 1) extra_sq = fma(v, v, extra_sq);      // the scale's and the weights' gradients enter the clip norm
+                }
             }
             __syncthreads();
         }
+        if (sq_partials != nullptr && threadIdx.x == 0) sq_partials[row_blocks] = extra_sq;
         return;
     }
     const int64_t c = counter != nullptr ? counter[0] : 0;
     order += c * order_stride;
     rowptr += c * (num_rows + 1);
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= num_rows * rowd) return;
+    if (t >= num_rows * rowd) {
+        if (sq_partials != nullptr) {        // the block's tree below needs every thread
+            red[threadIdx.x] = 0.0;
+            __syncthreads();
+            for (int off = BLOCK / 2; off > 0; off >>= 1) {
+                if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) sq_partials[blockIdx.x] = red[0];
+        }
+        return;
+    }
     const int64_t r = t / rowd;
     const int e = (int)(t - r * rowd);
     const int p0 = rowptr[r], p1 = rowptr[r + 1];
@@ -109,7 +126,19 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
     }
     for (; p < p1; ++p) s += rows[(int64_t)order[p] * rowd + e];
     s *= alpha;
-    grad[t] = accumulate ? grad[t] + s : s;
+    const double v = accumulate ? grad[t] + s : s;
+    grad[t] = v;
+    if (sq_partials != nullptr) {
+        // squared norm of the finished gradient, one partial per block in a fixed tree: the optimiser kernel adds the
+        // partials in index order and needs neither its own pass over the gradient nor a grid barrier
+        red[threadIdx.x] = v * v;
+        __syncthreads();
+        for (int off = BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sq_partials[blockIdx.x] = red[0];
+    }
 }
 
 struct GateSlots {
@@ -271,10 +300,15 @@ int sympa_scatter_add_flat_rows(const double* rows, const int64_t* idx, int64_t 
     return 0;
 }
 
+int64_t sympa_segment_sum_partials(int64_t num_rows, int row_doubles) {
+    if (num_rows <= 0 || row_doubles < 1) return 0;
+    return (num_rows * row_doubles + BLOCK - 1) / BLOCK + 1;
+}
+
 int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32_t* rowptr, int64_t num_rows, int row_doubles,
                            int64_t order_stride, const int64_t* step_counter, double alpha, int accumulate, double* grad_table,
                            const double* wave_partials, int64_t num_waves, int partial_stride, int num_weights, double* loss,
-                           double* grad_scale, double* grad_w, void* stream) {
+                           double* grad_scale, double* grad_w, double* sq_partials, void* stream) {
     if (num_rows <= 0 || row_doubles < 1 || row_doubles > 2 * SYMPA_MAX_DIMS_GENERIC * SYMPA_MAX_DIMS_GENERIC)
         return fail(SYMPA_ERR_BAD_ARG, "bad table shape");
     if (rows == nullptr || order == nullptr || rowptr == nullptr || grad_table == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
@@ -282,11 +316,13 @@ int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32
     if (wave_partials != nullptr && (num_waves < 0 || num_weights < 0 || partial_stride < 2 + num_weights || loss == nullptr ||
                                      (num_weights > 0 && grad_w == nullptr)))
         return fail(SYMPA_ERR_BAD_ARG, "bad partial-sum arguments");
+    if (sq_partials != nullptr && wave_partials == nullptr)
+        return fail(SYMPA_ERR_BAD_ARG, "sq_partials needs wave_partials (the scalar gradients enter the clip norm)");
     const unsigned row_blocks = (unsigned)((num_rows * row_doubles + BLOCK - 1) / BLOCK);
     const unsigned grid = row_blocks + (wave_partials != nullptr ? 1u : 0u);
     hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows, order,
                        rowptr, num_rows, row_doubles, order_stride, step_counter, alpha, accumulate, grad_table, wave_partials,
-                       num_waves, 2 + num_weights, partial_stride, loss, grad_scale, grad_w, row_blocks);
+                       num_waves, 2 + num_weights, partial_stride, loss, grad_scale, grad_w, row_blocks, sq_partials);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
@@ -295,9 +331,10 @@ int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32
 int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
                           double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
                           const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
-                          void* workspace, int64_t workspace_bytes, int64_t* step_counter, int32_t* projected_count,
-                          int32_t* status, void* stream) {
+                          void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
+                          int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream) {
     if (num_rows <= 0 || table == nullptr || grad == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer / empty table");
+    if (sq_partials != nullptr && num_sq_partials < 1) return fail(SYMPA_ERR_BAD_ARG, "empty partial list");
     if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
     if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (num_extra < 0 || num_extra > FUSED_MAX_EXTRA) return fail(SYMPA_ERR_BAD_ARG, "at most 2 plain parameters");
@@ -325,6 +362,7 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
         a.xlr[k] = extra_lr[k]; a.xwd[k] = extra_weight_decay[k];
     }
     a.counter = step_counter; a.projected = projected_count; a.status = status; a.zero_grads = zero_grads;
+    a.sq_in = sq_partials; a.sq_in_count = num_sq_partials;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
         case 1: return launch_fused_step<1>(a, model, s);

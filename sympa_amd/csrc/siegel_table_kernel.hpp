@@ -106,6 +106,8 @@ struct FusedStepArgs {
     int32_t* projected;
     int32_t* status;
     int zero_grads;
+    const double* sq_in;               // squared-norm partials already computed by sympa_segment_sum_rows (deterministic
+    int sq_in_count;                   // mode): phase 1 and the barrier are skipped, the partials are summed in index order
 };
 
 template <int N, int MODEL>
@@ -122,7 +124,21 @@ __global__ __launch_bounds__(BLOCK) void fused_step_kernel(const FusedStepArgs a
     sympa::load_full<N>(a.grad + ii * ROW, g);
     int st = 0;
     double coef = 1.0;
-    if (a.max_norm > 0.0) {
+    if (a.max_norm > 0.0 && a.sq_in != nullptr) {
+        if (wave == 0) {
+            double t = 0.0;
+            for (int k = lane; k < a.sq_in_count; k += 64) t += a.sq_in[k];
+SYMPA_UNROLL
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if (lane == 0) total_s = t;
+        }
+        __syncthreads();
+        coef = fmin(1.0, a.max_norm / (sqrt(total_s) + 1e-6));
+SYMPA_UNROLL
+        for (int r = 0; r < N; ++r)
+SYMPA_UNROLL
+            for (int c = 0; c < N; ++c) { g.re[r][c] *= coef; g.im[r][c] *= coef; }
+    } else if (a.max_norm > 0.0) {
         double s = 0.0;
 SYMPA_UNROLL
         for (int r = 0; r < N; ++r)
@@ -199,7 +215,7 @@ SYMPA_UNROLL
             if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(f));
         }
     }
-    if (a.max_norm > 0.0 || a.counter != nullptr) {
+    if ((a.max_norm > 0.0 && a.sq_in == nullptr) || a.counter != nullptr) {
         __syncthreads();       // every wave of the block has read total_s / the partials
         if (threadIdx.x == 0) {
             const unsigned done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

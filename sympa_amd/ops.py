@@ -605,7 +605,8 @@ def sorted_slots(row_index_lists, num_rows):
 
 
 def segment_sum_rows_(grad_table, rows, order, rowptr, alpha=1.0, accumulate=False, step_counter=None,
-                      wave_partials=None, num_waves=0, partial_stride=0, loss=None, grad_scale=None, grad_weights=None):
+                      wave_partials=None, num_waves=0, partial_stride=0, loss=None, grad_scale=None, grad_weights=None,
+                      sq_partials=None):
     """grad_table[r] (= | +=) alpha * sum of rows[order[p]], p in [rowptr[r], rowptr[r + 1]), added in list order: the
     deterministic counterpart of scatter_add_rows_ (C-ABI sympa_segment_sum_rows).  order / rowptr from sorted_slots();
     with step_counter the lists of batch step_counter[0] are used.  wave_partials: the per-wave sums model_train_backward
@@ -630,9 +631,15 @@ def segment_sum_rows_(grad_table, rows, order, rowptr, alpha=1.0, accumulate=Fal
             grad_table.data_ptr(), None if wave_partials is None else wave_partials.data_ptr(), int(num_waves),
             int(partial_stride), nw,
             None if loss is None else loss.data_ptr(), None if grad_scale is None else grad_scale.data_ptr(),
-            None if grad_weights is None else grad_weights.data_ptr(), _stream())
+            None if grad_weights is None else grad_weights.data_ptr(),
+            None if sq_partials is None else sq_partials.data_ptr(), _stream())
     _lib.check(rc)
     return grad_table
+
+
+def segment_sum_partials(grad_table):
+    """Length of the sq_partials buffer segment_sum_rows_ fills for this gradient table."""
+    return int(_lib.load().sympa_segment_sum_partials(grad_table.shape[0], grad_table[0].numel()))
 
 
 class FusedStep:
@@ -649,7 +656,7 @@ class FusedStep:
         cus = torch.cuda.get_device_properties(table.device).multi_processor_count
         return (table.shape[0] + 255) // 256 <= cus
 
-    def __init__(self, table, grad, model, extras=(), counter=None, projected=None, zero_grads=True):
+    def __init__(self, table, grad, model, extras=(), counter=None, projected=None, zero_grads=True, sq_partials=None):
         self.lib = _lib.load()
         _need_gpu(table, "table"); _need_gpu(grad, "grad")
         if table.dtype != torch.float64 or grad.dtype != torch.float64 or table.shape != grad.shape \
@@ -674,6 +681,10 @@ class FusedStep:
         self.ws = torch.zeros(need // 8, dtype=torch.float64, device=self.dev)
         self.zero_grads = 1 if zero_grads else 0
         self.status = _status_buf(self.dev)
+        # squared-norm partials left by segment_sum_rows_ (deterministic step): no pass over the gradient, no grid barrier
+        self.sq_partials = sq_partials
+        if sq_partials is not None and (sq_partials.dtype != torch.float64 or not sq_partials.is_cuda or not sq_partials.is_contiguous()):
+            raise ValueError("sq_partials must be a contiguous float64 device tensor")
 
     def run(self, lr, weight_decay=0.0, max_norm=None, extra_lr=(), extra_weight_decay=(), eps=None):
         table, grad, extras, counter, projected = self.keep
@@ -686,7 +697,9 @@ class FusedStep:
                 table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], self.model, float(lr),
                 float(weight_decay), EPS[torch.float64] if eps is None else float(eps),
                 float(max_norm) if max_norm is not None else 0.0, self.zero_grads, self.xp, self.xg, self.xn, xlr, xwd, self.k,
-                self.ws.data_ptr(), self.ws.numel() * 8, None if counter is None else counter.data_ptr(),
+                self.ws.data_ptr(), self.ws.numel() * 8,
+                None if (self.sq_partials is None or max_norm is None) else self.sq_partials.data_ptr(),
+                0 if self.sq_partials is None else self.sq_partials.numel(), None if counter is None else counter.data_ptr(),
                 None if projected is None else projected.data_ptr(), self.status.data_ptr(), _stream())
         _lib.check(rc)
 

@@ -111,7 +111,7 @@ class GraphedTrainStep:
                                  grad_rows=self.rows, step_counter=counter, wave_partials=self.partials)
         ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=counter,
                               wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
-                              loss=self.loss, grad_scale=gs, grad_weights=gw)
+                              loss=self.loss, grad_scale=gs, grad_weights=gw, sq_partials=self.sq_partials)
 
     def _body(self):
         if self.mode == "two_kernels":
@@ -157,8 +157,12 @@ class GraphedTrainStep:
         self._extra_params = [p for p in self.params if p is not table]
         extras = [(p.data, p.grad) for p in self._extra_params]
         # zero_grads: the scatter accumulates into the table gradient, the scalar sums into the scale / weight gradients
+        self.sq_partials = None
+        if self.deterministic:      # the segmented sum leaves the squared-norm partials: the optimiser kernel needs no barrier
+            self.sq_partials = torch.zeros(ops.segment_sum_partials(table.grad), dtype=torch.float64, device=self.device)
         self._fused = ops.FusedStep(table.data, table.grad, man.model_name, extras, counter=self.counter,
-                                    projected=man.projected_counter(table.device), zero_grads=True)
+                                    projected=man.projected_counter(table.device), zero_grads=True,
+                                    sq_partials=self.sq_partials)
         if self.deterministic:
             n = table.shape[2]
             self.rows = torch.empty(2 * self.batch_size, 2, n, n, dtype=torch.float64, device=self.device)
@@ -206,7 +210,8 @@ class GraphedTrainStep:
                                      grad_rows=rows, wave_partials=partials)
             order, rowptr = ops.sorted_slots(torch.cat((ids[:, 0], ids[:, 1])), table.shape[0])
             ops.segment_sum_rows_(table.grad, rows, order, rowptr, wave_partials=partials, num_waves=(b + 63) // 64,
-                                  partial_stride=2 + n, loss=loss, grad_scale=gs, grad_weights=gw)
+                                  partial_stride=2 + n, loss=loss, grad_scale=gs, grad_weights=gw,
+                                  sq_partials=self.sq_partials)
         self._fused_step()
         return loss
 

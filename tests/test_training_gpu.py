@@ -171,6 +171,16 @@ def test_fused_optimiser_kernel_equals_the_separate_kernels(model, n, nodes):
         assert int(c1) == int(c2)
         assert float(g2.abs().max()) == 0.0 and float(gs2.abs().max()) == 0.0 and float(gw2.abs().max()) == 0.0
         assert int(fs.ws.view(torch.int32)[:2].abs().sum()) == 0          # barrier words reset
+        if max_norm is not None:
+            # the same step with the squared-norm partials handed in (what the deterministic graph does: no pass over the
+            # gradient, no grid barrier): identical coefficient up to the order of the sum
+            t4, s4, w4 = table0.clone(), scale0.clone(), w0.clone()
+            g4, gs4, gw4 = grad0.clone(), gs0.clone(), gw0.clone()
+            parts = torch.stack(((grad0 * grad0).sum(), (gs0 * gs0).sum() + (gw0 * gw0).sum(),
+                                 torch.zeros((), dtype=torch.float64, device=dev)))
+            ops.FusedStep(t4, g4, model, [(s4, gs4), (w4, gw4)], sq_partials=parts).run(lr, 1e-3, max_norm, [0.5 * lr, lr], [0.0, 1e-2])
+            assert float((t4 - t1).abs().max()) < 1e-11 * scale_t and abs(float(s4 - s1)) < 1e-13
+            assert float(g4.abs().max()) == 0.0
         # a second step with the same object: the workspace needs no host-side reset
         g2.copy_(grad0); gs2.copy_(gs0); gw2.copy_(gw0)
         t3 = t2.clone()
@@ -220,6 +230,20 @@ def test_deterministic_gradient_accumulation(model, n):
             a1, a2 = det(), det()
             for x, y in zip(a1[:4], a2[:4]):
                 assert torch.equal(x, y)
+            # squared-norm partials of the finished gradient (+ the scalar gradients), bitwise reproducible
+            sq = [torch.zeros(ops.segment_sum_partials(table), dtype=torch.float64, device=dev) for _ in range(2)]
+            for q in sq:
+                part = torch.empty((b + 63) // 64, 2 + n, dtype=torch.float64, device=dev)
+                loss_, gs_, gw_ = (torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev),
+                                   torch.zeros(n, dtype=torch.float64, device=dev))
+                ops.model_train_backward(table, trip, gd, b, loss_, model, metric, w, gw_, sc, gs_, 2.0, 1.0, grad_rows=a1[4],
+                                         step_counter=counter, wave_partials=part)
+                ops.segment_sum_rows_(torch.empty_like(table), a1[4], order, rowptr, step_counter=counter, wave_partials=part,
+                                      num_waves=(b + 63) // 64, partial_stride=2 + n, loss=loss_, grad_scale=gs_,
+                                      grad_weights=gw_ if metric == "wsum" else None, sq_partials=q)
+            assert torch.equal(sq[0], sq[1])
+            want_sq = float((a1[0] ** 2).sum() + a1[2] ** 2 + ((a1[3] ** 2).sum() if metric == "wsum" else 0.0))
+            assert abs(float(sq[0].sum()) - want_sq) < 1e-12 * want_sq
             # the atomic form of the same batch
             grad = torch.zeros_like(table)
             loss, gs = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
