@@ -102,32 +102,24 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
     order += c * order_stride;
     rowptr += c * (num_rows + 1);
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= num_rows * rowd) {
-        if (sq_partials != nullptr) {        // the block's tree below needs every thread
-            red[threadIdx.x] = 0.0;
-            __syncthreads();
-            for (int off = BLOCK / 2; off > 0; off >>= 1) {
-                if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) sq_partials[blockIdx.x] = red[0];
+    const bool in_range = t < num_rows * rowd;      // no early return: the block's tree below needs every thread at its barriers
+    double v = 0.0;
+    if (in_range) {
+        const int64_t r = t / rowd;
+        const int e = (int)(t - r * rowd);
+        const int p0 = rowptr[r], p1 = rowptr[r + 1];
+        double s = 0.0;
+        int p = p0;
+        for (; p + 4 <= p1; p += 4) {       // four loads in flight, added in list order
+            const double v0 = rows[(int64_t)order[p] * rowd + e], v1 = rows[(int64_t)order[p + 1] * rowd + e];
+            const double v2 = rows[(int64_t)order[p + 2] * rowd + e], v3 = rows[(int64_t)order[p + 3] * rowd + e];
+            s = ((s + v0) + v1) + v2 + v3;
         }
-        return;
+        for (; p < p1; ++p) s += rows[(int64_t)order[p] * rowd + e];
+        s *= alpha;
+        v = accumulate ? grad[t] + s : s;
+        grad[t] = v;
     }
-    const int64_t r = t / rowd;
-    const int e = (int)(t - r * rowd);
-    const int p0 = rowptr[r], p1 = rowptr[r + 1];
-    double s = 0.0;
-    int p = p0;
-    for (; p + 4 <= p1; p += 4) {       // four loads in flight, added in list order
-        const double v0 = rows[(int64_t)order[p] * rowd + e], v1 = rows[(int64_t)order[p + 1] * rowd + e];
-        const double v2 = rows[(int64_t)order[p + 2] * rowd + e], v3 = rows[(int64_t)order[p + 3] * rowd + e];
-        s = ((s + v0) + v1) + v2 + v3;
-    }
-    for (; p < p1; ++p) s += rows[(int64_t)order[p] * rowd + e];
-    s *= alpha;
-    const double v = accumulate ? grad[t] + s : s;
-    grad[t] = v;
     if (sq_partials != nullptr) {
         // squared norm of the finished gradient, one partial per block in a fixed tree: the optimiser kernel adds the
         // partials in index order and needs neither its own pass over the gradient nor a grid barrier
@@ -339,11 +331,13 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
     if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
     if (num_extra < 0 || num_extra > FUSED_MAX_EXTRA) return fail(SYMPA_ERR_BAD_ARG, "at most 2 plain parameters");
     if (n < 1 || n > 6) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "fused step: dims 1..6 (one row per lane)");
-    const int64_t grid = (num_rows + BLOCK - 1) / BLOCK;
-    // the grid barrier needs every block resident at once: one block per CU is always possible
+    // the grid barrier needs every block resident at once: one block per CU is always possible.  One-wave blocks while
+    // they fit (a wave per CU instead of four on a quarter of the CUs), 256-thread blocks above
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return fail(SYMPA_ERR_BAD_ARG, "no device");
+    const int block = (num_rows + 63) / 64 <= cus ? 64 : BLOCK;
+    const int64_t grid = (num_rows + block - 1) / block;
     if (grid > cus) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "fused step: more row blocks than CUs (use sympa_rsgd_step_clipped)");
     const int64_t need = sympa_rsgd_step_fused_workspace_bytes(num_rows);
     if (workspace == nullptr || workspace_bytes < need) return fail(SYMPA_ERR_BAD_ARG, "workspace too small");
@@ -365,17 +359,17 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
     a.sq_in = sq_partials; a.sq_in_count = num_sq_partials;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
-        case 1: return launch_fused_step<1>(a, model, s);
-        case 2: return launch_fused_step<2>(a, model, s);
-        case 3: return launch_fused_step<3>(a, model, s);
-        case 4: return launch_fused_step<4>(a, model, s);
-        case 5: return launch_fused_step<5>(a, model, s);
-        default: return launch_fused_step<6>(a, model, s);
+        case 1: return launch_fused_step<1>(a, model, block, s);
+        case 2: return launch_fused_step<2>(a, model, block, s);
+        case 3: return launch_fused_step<3>(a, model, block, s);
+        case 4: return launch_fused_step<4>(a, model, block, s);
+        case 5: return launch_fused_step<5>(a, model, block, s);
+        default: return launch_fused_step<6>(a, model, block, s);
     }
 }
 
 int64_t sympa_rsgd_step_fused_workspace_bytes(int64_t num_rows) {
-    const int64_t grid = (num_rows + BLOCK - 1) / BLOCK;
+    const int64_t grid = (num_rows + 63) / 64;                 // the largest grid any block size gives
     return 8 * (grid + 2);          // one 8-byte slot for the two barrier words, grid + 1 partial sums
 }
 

@@ -110,8 +110,12 @@ struct FusedStepArgs {
     int sq_in_count;                   // mode): phase 1 and the barrier are skipped, the partials are summed in index order
 };
 
-template <int N, int MODEL>
-__global__ __launch_bounds__(BLOCK) void fused_step_kernel(const FusedStepArgs a) {
+// FB = threads per block: 64 while the table has at most as many 64-row groups as the chip has CUs (one wave per CU: a
+// lane-per-row load or store touches 64 cache lines per instruction, so four waves on one CU queue behind one texture
+// addresser -- 5 041 rows at n = 4: 15.5 us with 20 blocks of 256, measured), 256 above that (the barrier needs grid <= CUs).
+template <int N, int MODEL, int FB>
+__global__ __launch_bounds__(FB) void fused_step_kernel(const FusedStepArgs a) {
+    constexpr int BLOCK = FB;
     __shared__ double red[BLOCK / 64];
     __shared__ double total_s;
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -229,10 +233,16 @@ SYMPA_UNROLL
 }
 
 template <int N>
-int launch_fused_step(const FusedStepArgs& a, int model, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.rows + BLOCK - 1) / BLOCK);
-    if (model == SYMPA_MODEL_UPPER) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, a);
+int launch_fused_step(const FusedStepArgs& a, int model, int block, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.rows + block - 1) / block);
+    const bool up = model == SYMPA_MODEL_UPPER;
+    if (block == 64) {
+        if (up) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER, 64>), dim3(grid), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED, 64>), dim3(grid), dim3(64), 0, s, a);
+    } else {
+        if (up) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, a);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
