@@ -119,8 +119,15 @@ __device__ __attribute__((noinline)) void scatter_add_rows_outlined(const sympa:
     scatter_add_rows<N>(g, row, grad, tile, live);
 }
 
+// A/B hook: -DSYMPA_BWD_ROWS_MIN_BLOCKS=2 asks for two blocks per CU (two 256-register waves per SIMD) in the rows-out form at n <= 4
+#ifndef SYMPA_BWD_ROWS_MIN_BLOCKS
+#define SYMPA_BWD_ROWS_MIN_BLOCKS 1
+#endif
+template <int N, bool SCATTER>
+constexpr int bwd_min_blocks() { return (N <= 4 && !SCATTER) ? SYMPA_BWD_ROWS_MIN_BLOCKS : 1; }
+
 template <int N, int MODEL, bool SCATTER>
-__global__ __launch_bounds__(bwd_block<N>()) void siegel_bwd_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, SCATTER>())) void siegel_bwd_kernel(const BwdArgs a) {
     constexpr int BLOCK = bwd_block<N>();
     constexpr int GATHER_SLOTS = DmaTile<N>::ENABLED ? DmaTile<N>::WAVE_SLOTS_LOW : Tile<N>::WAVE_SLOTS;
     constexpr bool ROWS_TILE = !SCATTER && !ScatterTile<N>::BY_PLANE;      // per-pair rows leave through the tile too (n <= 6)

@@ -12,12 +12,17 @@ namespace sympa_hip {
 // Body of one 256-thread block: pairs [first, first + 256) of the batch described by `a`.
 // EXPERIMENT: a spare instantiation selected by flags bit 0x100 for in-process A/B timing (tools/ab_bench.py);
 // identical to the product kernel unless a variant is being measured.
+// dims 5..8: the bounded model gathers only the chunks that hold upper-triangle elements through three ring buffers, the
+// upper model whole rows through two (siegel_gather.hpp: measured per model)
+template <int MODEL>
+constexpr bool pass_masked() { return MODEL != sympa::MODEL_UPPER; }
+
 template <int N, int MODEL, bool LOWLDS>
 struct BlockLds {
     static constexpr bool PASS4 = (N == 4) && LOWLDS;   // minimum-LDS gather: three blocks of different launches per CU
     static constexpr int WAVE_SLOTS = PASS4 ? PASS4_WAVE_SLOTS
                                       : DmaTile<N>::ENABLED ? (LOWLDS ? DmaTile<N>::WAVE_SLOTS_LOW : DmaTile<N>::WAVE_SLOTS)
-                                      : (PassTile<N>::ENABLED ? PassTile<N>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
+                                      : (PassTile<N>::ENABLED ? PassTile<N, pass_masked<MODEL>()>::WAVE_SLOTS : Tile<N>::WAVE_SLOTS);
 };
 
 template <int N, int MODEL, bool LOWLDS>
@@ -48,7 +53,7 @@ __device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t firs
     if constexpr (PassTile<N>::ENABLED) {
         sympa::CMat<N> z1, z2;
         v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
-        gather_pair_passes<N>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
+        gather_pair_passes<N, pass_masked<MODEL>()>(a.base1, (int)r1, a.base2, (int)r2, tile, z1, z2);
         d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);
     } else if constexpr (Tile<N>::STAGED) {
         sympa::CMat<N> z1, z2;
@@ -111,8 +116,16 @@ struct MultiArgs {
     int num_batches;
 };
 
+// Blocks per CU the compiler must make room for in the fused multi-batch kernel (A/B hook: -DSYMPA_MULTI_MIN_BLOCKS_BOUNDED4=4
+// caps the bounded n = 4 instantiation, 146 registers = three waves per SIMD, at 128 = four like the upper one).
+#ifndef SYMPA_MULTI_MIN_BLOCKS_BOUNDED4
+#define SYMPA_MULTI_MIN_BLOCKS_BOUNDED4 1
+#endif
 template <int N, int MODEL>
-__global__ __launch_bounds__(BLOCK) void siegel_dist_multi_kernel(const MultiArgs m) {
+constexpr int multi_min_blocks() { return (N == 4 && MODEL != sympa::MODEL_UPPER) ? SYMPA_MULTI_MIN_BLOCKS_BOUNDED4 : 1; }
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK, (multi_min_blocks<N, MODEL>())) void siegel_dist_multi_kernel(const MultiArgs m) {
     constexpr bool LOW = DmaTile<N>::ENABLED;
     __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOW>::WAVE_SLOTS];
     // batch of this block: binary search over <= 32 prefix ends (block-uniform, scalar)

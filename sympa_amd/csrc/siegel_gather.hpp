@@ -284,86 +284,151 @@ __device__ __forceinline__ void gather_pair_staged(const double* __restrict__ ba
 }
 
 // ---------------------------------------------------------------------------------------------
-// n = 5..8: rows are 400 B .. 1 KiB, a whole wave's tile would not fit in LDS.  The 64 rows of an endpoint
-// are gathered in 4 passes of 16 rows through two ping-pong buffers: one LDS-DMA instruction fetches one row
-// (lane l < C fetches chunk l: a fully coalesced 16 C-byte segment), pass p+1 is in flight while the 16 lanes
-// of pass p read their rows back (row pitch C or C+1 slots, odd, conflict-free).  Measured need: with
-// lane-per-row loads the n = 8 kernel was bound by L1/TA line thrashing (257 us per 262 144 pairs against
-// ~75 us of arithmetic).
+// n = 5..8: rows are 400 B .. 1 KiB, a whole wave's tile would not fit in LDS.  The 64 rows of an endpoint are gathered in 4
+// passes of 16 rows through a ring of LDS buffers: one LDS-DMA instruction fetches one row, later passes are in flight while
+// the 16 lanes of pass p read their rows back (odd row pitch, conflict-free).  Measured need: with lane-per-row loads the
+// n = 8 kernel was bound by L1/TA line thrashing (257 us per 262 144 pairs against ~75 us of arithmetic).
+//
+// Round 3 (profiles/r03_n8_forward_ab.txt): with one wave per SIMD nothing but the ring hides the latency of these loads --
+// the upper n = 8 forward takes 125 us per 262 144 pairs on a table that fits the L2s and 154 us on configs[3]'s 46.6 MB
+// table.  MASKED form: only the upper triangles are read afterwards, so a lane fetches only a 16-byte chunk that CONTAINS an
+// upper-triangle element (40 of the 64 chunks of an 8 x 8 row; lane k fetches the k-th needed chunk, the DMA packs the
+// active lanes' chunks back to back): a row is 640 B in LDS instead of 1 KiB, THREE buffers fit where two did, two passes
+// are in flight behind the one being read, 37 % fewer bytes leave memory.  Measured A/B against the two-buffer full-row
+// form: bounded n = 8 248 -> 238 us, upper n = 8 152.8 -> 157.5 us (and 123 -> 130 us on an L2-resident table: the select
+// chain, the exec-masked DMA and the different register allocation cost more than the deeper ring hides), dims 5..7 equal.
+// So the latency that shows is not the ring's steady state but the head of every wave (index load, then the first pass,
+// nothing to overlap with) -- MASKED is used for the bounded model, the upper model keeps full rows and two buffers.
 // ---------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool MASKED>
+struct PassChunks {
+    static constexpr int C = N * N;                       // 16-byte chunks per row ([2, N, N] doubles)
+    struct Map {
+        int count;
+        int src[C];          // k-th needed chunk
+        int slot[C];         // packed position of chunk c, -1 when not fetched
+    };
+    static constexpr Map make() {
+        Map m{};
+        bool need[C] = {};
+        if (MASKED) {
+            for (int pl = 0; pl < 2; ++pl)
+                for (int i = 0; i < N; ++i)
+                    for (int j = i; j < N; ++j) need[(pl * N * N + i * N + j) / 2] = true;
+        } else {
+            for (int c = 0; c < C; ++c) need[c] = true;
+        }
+        int k = 0;
+        for (int c = 0; c < C; ++c) {
+            m.slot[c] = -1;
+            if (need[c]) { m.src[k] = c; m.slot[c] = k; ++k; }
+        }
+        for (int c = k; c < C; ++c) m.src[c] = 0;
+        m.count = k;
+        return m;
+    }
+    static constexpr Map MAP = make();
+    static constexpr int K = MAP.count;
+};
+
+template <int N, bool MASKED = false>
 struct PassTile {
     static constexpr int C = N * N;
     static constexpr bool ENABLED = (N >= 5 && N <= 8);
-    static constexpr int PITCH = (C % 2 == 1) ? C : C + 1;
+    static constexpr int K = PassChunks<N, MASKED>::K;                   // chunks of a row that are fetched
+    static constexpr int PITCH = (K % 2 == 1) ? K : K + 1;
     static constexpr int ROWS = 16;
     static constexpr int BUF_SLOTS = ENABLED ? ROWS * PITCH : 1;
-    static constexpr int WAVE_SLOTS = 2 * BUF_SLOTS;
+    static constexpr int NBUF = MASKED ? 3 : 2;
+    static constexpr int WAVE_SLOTS = NBUF * BUF_SLOTS;
 };
 
-template <int N>
+// the chunk lane `lane` fetches (a select chain over the constexpr map: once per wave)
+template <int N, bool MASKED>
+__device__ __forceinline__ int pass_my_chunk(const int lane) {
+    if constexpr (!MASKED) return lane < N * N ? lane : 0;
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < PassChunks<N, MASKED>::K; ++k) mine = (lane == k) ? PassChunks<N, MASKED>::MAP.src[k] : mine;
+    return mine;
+}
+
+template <int N, bool MASKED>
 __device__ __forceinline__ void pass_issue(const double* __restrict__ base, const int row, const int pass,
-                                           v2d* __restrict__ buf) {
-    constexpr int C = PassTile<N>::C;
+                                           v2d* __restrict__ buf, const int my_chunk) {
+    constexpr int K = PassTile<N, MASKED>::K;
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < PassTile<N>::ROWS; ++j) {
         const int rr = __shfl(row, 16 * pass + j);
-        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * (lane < C ? lane : 0);
-        if (C == 64 || lane < C)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PassTile<N>::PITCH), 16, 0, 0);
+        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * my_chunk;
+        if (K == 64 || lane < K)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
     }
 }
 
-template <int N>
+template <int N, bool MASKED>
 __device__ __forceinline__ void pass_read(const v2d* __restrict__ buf, const int pass, sympa::CMat<N>& z) {
-    constexpr int C = PassTile<N>::C;
+    constexpr int K = PassTile<N, MASKED>::K;
     const int lane = threadIdx.x & 63;
     if ((lane >> 4) == pass) {
-        const v2d* mine = buf + (lane & 15) * PassTile<N>::PITCH;
-        v2d q[C];
+        const v2d* mine = buf + (lane & 15) * PassTile<N, MASKED>::PITCH;
+        v2d q[K];
 #pragma unroll
-        for (int c = 0; c < C; ++c) q[c] = mine[c];
+        for (int c = 0; c < K; ++c) q[c] = mine[c];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const int fr = (i <= j) ? i * N + j : j * N + i;
                 const int fi = N * N + fr;
-                z.re[i][j] = (fr & 1) ? q[fr >> 1].y : q[fr >> 1].x;
-                z.im[i][j] = (fi & 1) ? q[fi >> 1].y : q[fi >> 1].x;
+                z.re[i][j] = (fr & 1) ? q[PassChunks<N, MASKED>::MAP.slot[fr >> 1]].y : q[PassChunks<N, MASKED>::MAP.slot[fr >> 1]].x;
+                z.im[i][j] = (fi & 1) ? q[PassChunks<N, MASKED>::MAP.slot[fi >> 1]].y : q[PassChunks<N, MASKED>::MAP.slot[fi >> 1]].x;
             }
         }
     }
 }
 
-template <int N>
+// s_waitcnt vmcnt(V) only (lgkmcnt / expcnt untouched): V in [0, 63]
+template <int V>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (V & 15) | ((V >> 4) << 14));
+}
+
+template <int N, bool MASKED>
 __device__ __forceinline__ void gather_pair_passes(const double* __restrict__ base1, const int row1,
                                                    const double* __restrict__ base2, const int row2,
                                                    v2d* __restrict__ tile, sympa::CMat<N>& z1, sympa::CMat<N>& z2) {
+    constexpr int NBUF = PassTile<N, MASKED>::NBUF;
+    constexpr int LOOK = NBUF - 1;                  // passes in flight behind the one being read
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) { z1.re[i][j] = 0.0; z1.im[i][j] = 0.0; z2.re[i][j] = 0.0; z2.im[i][j] = 0.0; }
-    v2d* buf0 = tile;
-    v2d* buf1 = tile + PassTile<N>::BUF_SLOTS;
-    pass_issue<N>(base1, row1, 0, buf0);
+    const int my_chunk = pass_my_chunk<N, MASKED>(threadIdx.x & 63);
+    auto issue = [&](const int p) {
+        v2d* buf = tile + (p % NBUF) * PassTile<N, MASKED>::BUF_SLOTS;
+        if (p < 4) pass_issue<N, MASKED>(base1, row1, p, buf, my_chunk);
+        else pass_issue<N, MASKED>(base2, row2, p - 4, buf, my_chunk);
+    };
+#pragma unroll
+    for (int p = 0; p < NBUF; ++p) issue(p);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        v2d* cur = (s & 1) ? buf1 : buf0;
-        v2d* nxt = (s & 1) ? buf0 : buf1;
-        if (s + 1 < 8) {
-            // the buffer being refilled was read two steps ago: make sure those reads have completed
+        // passes s+1 .. s+LOOK (those that exist) stay in flight; pass s has landed
+        const int behind = (8 - 1 - s) < LOOK ? (8 - 1 - s) : LOOK;
+        if (behind == 2) wait_vmcnt<32>();
+        else if (behind == 1) wait_vmcnt<16>();
+        else wait_vmcnt<0>();
+        wave_lds_fence();
+        const v2d* cur = tile + (s % NBUF) * PassTile<N, MASKED>::BUF_SLOTS;
+        if (s < 4) pass_read<N, MASKED>(cur, s, z1);
+        else pass_read<N, MASKED>(cur, s - 4, z2);
+        if (s + NBUF < 8) {
+            // the buffer just read is refilled: make sure those reads have completed
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
             wave_lds_fence();
-            if (s + 1 < 4) pass_issue<N>(base1, row1, s + 1, nxt);
-            else pass_issue<N>(base2, row2, s + 1 - 4, nxt);
-            __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): the DMAs of step s have landed
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+            issue(s + NBUF);
         }
-        wave_lds_fence();
-        if (s < 4) pass_read<N>(cur, s, z1);
-        else pass_read<N>(cur, s - 4, z2);
     }
 }

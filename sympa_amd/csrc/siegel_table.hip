@@ -110,7 +110,14 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
         const int p0 = rowptr[r], p1 = rowptr[r + 1];
         double s = 0.0;
         int p = p0;
-        for (; p + 4 <= p1; p += 4) {       // four loads in flight, added in list order
+        for (; p + 8 <= p1; p += 8) {       // eight loads in flight, added in list order
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = rows[(int64_t)order[p + k] * rowd + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += x[k];
+        }
+        for (; p + 4 <= p1; p += 4) {
             const double v0 = rows[(int64_t)order[p] * rowd + e], v1 = rows[(int64_t)order[p + 1] * rowd + e];
             const double v2 = rows[(int64_t)order[p + 2] * rowd + e], v3 = rows[(int64_t)order[p + 3] * rowd + e];
             s = ((s + v0) + v1) + v2 + v3;

@@ -8,9 +8,11 @@ from sympa_amd import data
 
 paths = [a for a in sys.argv[1:] if not a.startswith("--") and a.endswith(".so")]
 K = int(sys.argv[sys.argv.index("--k") + 1]) if "--k" in sys.argv else 20
+model = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else "upper"
+mid = {"upper": 0, "bounded": 1}[model]
 dev = torch.device("cuda:0")
 nodes, n, batch, nb = 5041, 4, 65536, 16
-table = data.trained_like_table(nodes, n).to(dev)
+table = data.trained_like_table(nodes, n, model=model).to(dev)
 scale = torch.ones(1, dtype=torch.float64, device=dev)
 batches = [data.sample_pairs(nodes, batch, j).to(dev) for j in range(nb)]
 status = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -28,7 +30,7 @@ for p in paths:
     st = (V * 1)(torch.cuda.current_stream().cuda_stream)
 
     def run(fn=fn, trip=trip, bb=bb, oo=oo, st=st):
-        rc = fn(table.data_ptr(), nodes, n, trip, 2, bb, K, 0, 0, None, 1e-5, scale.data_ptr(), 1.0, oo, status.data_ptr(), 8, st, 1)
+        rc = fn(table.data_ptr(), nodes, n, trip, 2, bb, K, mid, 0, None, 1e-5, scale.data_ptr(), 1.0, oo, status.data_ptr(), 8, st, 1)
         assert rc == 0, rc
     for _ in range(20):
         run()
@@ -49,5 +51,5 @@ for (p, _, outs), t in zip(variants, times):
     t.sort()
     same = all(torch.equal(o, r_) for o, r_ in zip(outs, variants[0][2]))
     med = t[len(t) // 2]
-    print(f"{os.path.basename(p):24s} K={K}: median {med:.3f} us/step  min {t[0]:.3f}  p90 {t[int(len(t) * 0.9)]:.3f}  "
+    print(f"{os.path.basename(p):24s} {model} K={K}: median {med:.3f} us/step  min {t[0]:.3f}  p90 {t[int(len(t) * 0.9)]:.3f}  "
           f"{batch / med / 1e3:.2f} G pairs/s  bit-identical to first: {same}")
