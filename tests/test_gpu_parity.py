@@ -30,7 +30,7 @@ def gpu_dist(z1, z2, model, metric, w=None, dev="cuda:0", vvd=False):
     return (r[0].cpu(), r[1].cpu()) if vvd else r.cpu()
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 12, 16])     # every kernel family: Jacobi, QL in registers, sixteen lanes
 @pytest.mark.parametrize("model", MODELS)
 def test_golden_vectors_of_the_reference(dev, model, n):
     g = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
@@ -39,7 +39,9 @@ def test_golden_vectors_of_the_reference(dev, model, n):
         for metric in METRICS:
             got = gpu_dist(z1, z2, model, metric, g["wsum_weights"])
             tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
-            assert rel_err(got, g[f"{case}__{metric}"]) < tol, (model, n, case, metric)
+            # d(x, x): exactly 0 here, ~1e-15 per component in the reference (up to 2(n-1) n of them under fmin)
+            atol = 1e-10 if (case == "same" and n > 8) else 1e-12
+            assert rel_err(got, g[f"{case}__{metric}"], atol=atol) < tol, (model, n, case, metric)
         if f"{case}__vvd_exact50" in g:
             _, vvd = gpu_dist(z1, z2, model, "riem", vvd=True)
             assert rel_err(vvd, g[f"{case}__vvd_exact50"]) < (1e-12 if model == "upper" else 1e-9)

@@ -226,3 +226,25 @@ def test_dpp_hazard_checker_flags_a_copy_in_front_of_a_dpp_read():
     half_b = "v_fmac_f64_dpp v[8:9], -v[2:3], v[4:5] row_newbcast:11 row_mask:0xf bank_mask:0xc"
     assert len(scan(["s_nop 1", half_a, half_b])[1]) == 1
     assert scan(["s_nop 1", half_a, "s_nop 1", half_b])[1] == []
+
+
+def test_sorted_slots_lists_of_the_deterministic_gradient_accumulation():
+    """ops.sorted_slots (pure torch, runs on any device): for every batch the slots 0 .. 2b-1 sorted by table row --
+    stable, so inside a table row the slots keep batch order -- and CSR pointers of the table rows into that list."""
+    import torch
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(3)
+    steps, b, rows = 3, 50, 17
+    src = torch.randint(0, rows, (steps, b), generator=g)
+    dst = torch.randint(0, rows, (steps, b), generator=g)
+    keys = torch.cat((src, dst), dim=1)
+    order, rowptr = ops.sorted_slots(keys, rows)
+    assert order.dtype == torch.int32 and rowptr.dtype == torch.int32
+    assert order.shape == (steps, 2 * b) and rowptr.shape == (steps, rows + 1)
+    for s in range(steps):
+        assert int(rowptr[s, 0]) == 0 and int(rowptr[s, -1]) == 2 * b
+        for r in range(rows):
+            seg = order[s, int(rowptr[s, r]):int(rowptr[s, r + 1])].tolist()
+            assert seg == [k for k in range(2 * b) if int(keys[s, k]) == r]      # exactly the slots of row r, in batch order
+    o1, p1 = ops.sorted_slots(keys[0], rows)                                      # a single batch as a 1-d list
+    assert torch.equal(o1[0], order[0]) and torch.equal(p1[0], rowptr[0])

@@ -14,7 +14,7 @@ TOL = 1e-9
 TOL_FAR_VS_REFERENCE = 1e-6
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_golden(model, n):
     g = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
@@ -137,3 +137,20 @@ def test_packed_point_path_of_the_all_pairs_kernel(model, n):
             got, st = hostsim_dist_packed(gold[f"{case}__z1"], gold[f"{case}__z2"], model, "riem")
             tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
             assert st == 0 and rel_err(got, gold[f"{case}__riem"]) < tol, (model, n, case)
+
+
+@pytest.mark.parametrize("n", [12, 16])
+@pytest.mark.parametrize("model", MODELS)
+def test_generic_arithmetic_against_reference_goldens(model, n):
+    """The runtime-n arithmetic (the one-lane kernels behind SYMPA_FLAG_GENERIC, which the sixteen-lanes kernels are checked
+    against on the GPU) against outputs of the imported reference at dims 12 and 16."""
+    g = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
+    for case in g["case_names"]:
+        z1, z2 = g[f"{case}__z1"], g[f"{case}__z2"]
+        for metric in METRICS:
+            out, vvd, st = hostsim_dist(z1, z2, model, metric, g["wsum_weights"], generic=True)
+            assert st == 0
+            tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
+            # d(x, x): exactly 0 here, ~1e-15 per component in the reference (up to 2(n-1) n of them under fmin)
+            atol = 1e-10 if case == "same" else 1e-12
+            assert rel_err(out, g[f"{case}__{metric}"], atol=atol) < tol, (model, n, case, metric)

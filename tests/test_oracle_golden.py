@@ -25,7 +25,7 @@ def close(a, b, rtol=1e-12, atol=1e-13):
     return torch.allclose(a, b, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 12, 16])
 @pytest.mark.parametrize("model", ["upper", "bounded"])
 def test_dist_matches_reference(golden_dir, model, n):
     g = np.load(os.path.join(golden_dir, f"dist_{model}_n{n}.npz"))

@@ -308,8 +308,45 @@ def autograd_goldens_large(dims=(6, 8)):
             print(f"  {os.path.basename(path)}  {os.path.getsize(path)} B")
 
 
+def dist_goldens_more(dims=(5, 6, 7, 12, 16)):
+    """Round 3: `dist` of the imported reference at the dims whose kernels differ in KIND from those of n = 2, 3, 4, 8 --
+    5..7 (Householder + lockstep QL in registers, the ring gather) and 12, 16 (sixteen lanes per pair) -- so that every
+    kernel family is pinned by reference outputs directly, not only through the oracle.  Own RNG stream: the existing
+    fixtures stay byte-identical.  Smaller batches at 12 / 16 keep the files small."""
+    torch.set_default_dtype(torch.float64)
+    sm, cay, tak, UH, BD, met = ref_shim.import_reference()
+    g = torch.Generator().manual_seed(20261003)
+    for n in dims:
+        wsum_w = torch.linspace(-0.5, 1.5, n).reshape(1, n)
+        cases = build_cases(n, g, b=24 if n <= 8 else 8)
+        for model in ("upper", "bounded"):
+            blob = {"wsum_weights": wsum_w.numpy(), "case_names": np.array(sorted(cases))}
+            for name in sorted(cases):
+                z1, z2 = cases[name]
+                if model == "bounded":
+                    z1, z2 = cay.cayley_transform(z1), cay.cayley_transform(z2)
+                    z1, z2 = sm.to_symmetric(z1), sm.to_symmetric(z2)
+                blob[f"{name}__z1"] = z1.numpy()
+                blob[f"{name}__z2"] = z2.numpy()
+                for metric in METRICS:
+                    man = (UH if model == "upper" else BD)(dims=n, metric=met.MetricType.from_str(metric))
+                    if metric == "wsum":
+                        with torch.no_grad():
+                            man.metric.weights.copy_(wsum_w)
+                    with torch.no_grad():
+                        d = man.dist(z1, z2)
+                    blob[f"{name}__{metric}"] = d.detach().numpy()
+            path = os.path.join(OUT, f"dist_{model}_n{n}.npz")
+            np.savez_compressed(path, **blob)
+            print(f"  {os.path.basename(path)}  {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
-    if "--autograd-large" in sys.argv:
+    if "--dist-more" in sys.argv:
+        dist_goldens_more()
+    elif "--autograd-more" in sys.argv:          # round 3: dims 7 (eight lanes per pair) and 12 (sixteen lanes per pair)
+        autograd_goldens_large(dims=(7, 12))
+    elif "--autograd-large" in sys.argv:
         autograd_goldens_large()
     else:
         main()
