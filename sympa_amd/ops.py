@@ -234,12 +234,43 @@ class BatchedForward:
 
     def set_streams(self, streams):
         if not streams:
-            streams = [torch.cuda.current_stream(self.dev)]
+            cur = torch.cuda.current_stream(self.dev)
+            handle = cur.cuda_stream
+            if getattr(self, "_one_stream", None) == handle:
+                return                                  # the usual case: same stream as last time, nothing to rebuild
+            self._one_stream = handle
+            self.streams = [cur]
+            self.stream_arr = (ctypes.c_void_p * 1)(handle)
+            self._full = None
+            return
+        self._one_stream = None
         self.streams = list(streams)
         self.stream_arr = (ctypes.c_void_p * len(self.streams))(*[s.cuda_stream for s in self.streams])
+        self._full = None
 
     def run(self, first=0, count=None):
         """Enqueues launches first .. first+count-1 (default: all)."""
+        if first == 0 and count is None:
+            # the whole list: the argument tuple is converted to C types once (a 20-step timed region is ~100 us; the
+            # conversion of 18 Python arguments per call was ~5 us of it)
+            full = getattr(self, "_full", None)
+            if full is None:
+                if self.k == 0:
+                    return
+                C = ctypes
+                full = self._full = (
+                    C.c_void_p(self.keep[0].data_ptr()), C.c_int64(self.num_rows), C.c_int(self.n),
+                    C.c_void_p(C.addressof(self.trip)), C.c_int64(self.stride), C.c_void_p(C.addressof(self.b)),
+                    C.c_int(self.k), C.c_int(self.args[0]), C.c_int(self.args[1]),
+                    C.c_void_p(self.args[2]), C.c_double(self.args[3]), C.c_void_p(self.args[4]),
+                    C.c_double(self.args[5]), C.c_void_p(C.addressof(self.out)), C.c_void_p(self.status.data_ptr()),
+                    C.c_int(self.flags), C.cast(self.stream_arr, C.c_void_p), C.c_int(len(self.streams)))
+            rc = self.lib.sympa_model_forward_batches(*full)
+            if rc != 0:
+                _lib.check(rc)
+            if _debug:
+                check_status(self.dev)
+            return
         count = self.k - first if count is None else count
         if count <= 0:
             return
