@@ -101,89 +101,6 @@ __global__ __launch_bounds__(BLOCK, fwd_min_blocks<N>()) void siegel_dist_kernel
     dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * BLOCK, lds);
 }
 
-// dims 5..8, batches deeper than one block per CU: PERSISTENT blocks (grid = number of CUs) that walk the batch in strides
-// of the grid.  One 480-register wave per SIMD means nothing hides the head of a block -- the index load, then the first
-// gather passes (29 of 154 us at n = 8 on configs[3]'s table are a lone wave waiting on memory, profiles/r03_n8_forward_ab.txt)
-// -- so the NEXT block's indices are loaded while the current block's rows stream in, and its first two (three) gather
-// passes are issued into the ring's buffers right before the current block's arithmetic, which takes ten times longer than
-// they need to land.  Wait counts: the next block's two index loads are always the youngest vector-memory operations when
-// the tail of the gather begins, so `vmcnt(2)` there covers everything older (prefetched passes, the previous block's
-// stores and rare status atomics) whatever their number.
-template <int N, int MODEL>
-__global__ __launch_bounds__(BLOCK, (fwd_min_blocks<N>())) void siegel_dist_persist_kernel(const DistArgs a) {
-    constexpr bool MASKED = pass_masked<MODEL>();
-    using PT = PassTile<N, MASKED>;
-    __shared__ v2d lds[(BLOCK / 64) * PT::WAVE_SLOTS];
-    v2d* tile = lds + (threadIdx.x >> 6) * PT::WAVE_SLOTS;
-    const int my_chunk = pass_my_chunk<N, MASKED>(threadIdx.x & 63);
-    const int64_t nblocks = (a.b + BLOCK - 1) / BLOCK;
-    const bool idx_mode = a.ap_cols == 0 && a.idx1 != nullptr;      // the rows of a pair come from index loads
-    int64_t blk = blockIdx.x;
-    int64_t i = blk * BLOCK + threadIdx.x;
-    bool live = i < a.b;
-    int st = 0;
-    int64_t r1, r2;
-    {
-        const int64_t ii = live ? i : a.b - 1;
-        r1 = ii; r2 = ii;
-        if (a.ap_cols > 0) {
-            ap_pair(a, ii, r1, r2);
-        } else if (idx_mode) {
-            r1 = __builtin_nontemporal_load(a.idx1 + ii * a.idx1_stride);
-            r2 = __builtin_nontemporal_load(a.idx2 + ii * a.idx2_stride);
-            if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { st |= sympa::ST_BAD_INDEX; r1 = 0; r2 = 0; }
-        }
-    }
-    gather_head<N, MASKED>(a.base1, (int)r1, a.base2, (int)r2, tile, my_chunk);
-    for (;;) {
-        const int64_t nblk = blk + gridDim.x;
-        const bool has_next = nblk < nblocks;                       // block-uniform
-        const int64_t in = (has_next ? nblk : blk) * BLOCK + threadIdx.x;
-        const bool liven = in < a.b;
-        const int64_t iin = liven ? in : a.b - 1;
-        int64_t r1n = iin, r2n = iin;
-        if (idx_mode) {
-            // the last block re-reads its own indices: the count of operations younger than the prefetched passes stays two
-            r1n = __builtin_nontemporal_load(a.idx1 + iin * a.idx1_stride);
-            r2n = __builtin_nontemporal_load(a.idx2 + iin * a.idx2_stride);
-            wait_vmcnt<2>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        sympa::CMat<N> z1, z2;
-        gather_tail<N, MASKED>(a.base1, (int)r1, a.base2, (int)r2, tile, my_chunk, z1, z2);   // ends with vmcnt(0)
-        int stn = 0;
-        if (a.ap_cols > 0) {
-            ap_pair(a, iin, r1n, r2n);
-        } else if (idx_mode) {
-            if (r1n < 0 || r1n >= a.num_rows || r2n < 0 || r2n >= a.num_rows) { stn |= sympa::ST_BAD_INDEX; r1n = 0; r2n = 0; }
-        }
-        if (has_next) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the last passes have been read out of the ring
-            wave_lds_fence();
-            gather_head<N, MASKED>(a.base1, (int)r1n, a.base2, (int)r2n, tile, my_chunk);
-        }
-        double* vv = (a.vvd != nullptr && live) ? a.vvd + i * N : nullptr;
-        double d = sympa::pair_distance_mats<N, MODEL>(z1, z2, a.metric, a.metric_w, a.inv_eps, vv, st);
-        if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
-        if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
-        if (live) {
-            if (a.ap_cols > 0) ap_store(a, i, r1, r2, d);
-            else __builtin_nontemporal_store(d, a.out + i);
-        }
-        if (a.status != nullptr) {
-            const int flagged = (live && st != 0) ? 1 : 0;
-            const unsigned long long m = __ballot(flagged);
-            if (m != 0ull) {   // rare path
-                if (flagged) atomicOr(&a.status[0], st);
-                if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
-            }
-        }
-        if (!has_next) break;
-        blk = nblk; i = in; live = liven; r1 = r1n; r2 = r2n; st = stn;
-    }
-}
-
 // Several batches in ONE launch (C-ABI sympa_model_forward_batches with SYMPA_FLAG_FUSE): block x belongs to the
 // batch k with blk_end[k-1] <= x < blk_end[k]; the batches share table, metric and scale and differ in their index
 // list, size and output.  The grid is several blocks per CU deep, so the minimum-LDS gather form is used: three
@@ -244,38 +161,12 @@ hipError_t launch_kernel(K kern, unsigned grid, const DistArgs& a, hipStream_t s
     return hipGetLastError();
 }
 
-// number of CUs of the current device (cached per device): the grid of the persistent kernel
-inline int persist_grid() {
-    static int cached[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached[dev] = cus;
-    }
-    return cached[dev];
-}
-
 template <int N>
 int launch_n(const DistArgs& a, int model, hipStream_t s) {
     const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
     // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
     const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256);
     hipError_t e;
-    if constexpr (PassTile<N>::ENABLED) {
-        // deeper than one block per CU: persistent blocks with the next block's head prefetched (flags bit 0x200: the
-        // one-block-per-workgroup form, for A/B)
-        const int cus = persist_grid();
-        if ((int64_t)grid > cus && !(a.flags & 0x200)) {
-            if (model == SYMPA_MODEL_UPPER)
-                e = launch_kernel(siegel_dist_persist_kernel<N, sympa::MODEL_UPPER>, (unsigned)cus, a, s);
-            else
-                e = launch_kernel(siegel_dist_persist_kernel<N, sympa::MODEL_BOUNDED>, (unsigned)cus, a, s);
-            if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-            return 0;
-        }
-    }
     if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
         e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, a, s);
     } else if (model == SYMPA_MODEL_UPPER) {

@@ -432,55 +432,3 @@ __device__ __forceinline__ void gather_pair_passes(const double* __restrict__ ba
         }
     }
 }
-
-// ---------------------------------------------------------------------------------------------
-// The same ring in two halves, for the persistent forward kernel of dims 5..8 (siegel_dist_kernel.hpp): `gather_head` issues
-// the first NBUF passes of a batch -- it is called BEFORE the arithmetic of the previous batch, so these passes (and the next
-// batch's index loads) fly while the wave computes --, `gather_tail` assumes they have landed (the caller has waited for
-// everything older than its two index loads), reads them and streams the remaining passes as above.
-// ---------------------------------------------------------------------------------------------
-template <int N, bool MASKED>
-__device__ __forceinline__ void gather_head(const double* __restrict__ base1, const int row1, const double* __restrict__ base2,
-                                            const int row2, v2d* __restrict__ tile, const int my_chunk) {
-    constexpr int NBUF = PassTile<N, MASKED>::NBUF;
-#pragma unroll
-    for (int p = 0; p < NBUF; ++p) {
-        v2d* buf = tile + (p % NBUF) * PassTile<N, MASKED>::BUF_SLOTS;
-        if (p < 4) pass_issue<N, MASKED>(base1, row1, p, buf, my_chunk);
-        else pass_issue<N, MASKED>(base2, row2, p - 4, buf, my_chunk);
-    }
-}
-
-template <int N, bool MASKED>
-__device__ __forceinline__ void gather_tail(const double* __restrict__ base1, const int row1, const double* __restrict__ base2,
-                                            const int row2, v2d* __restrict__ tile, const int my_chunk, sympa::CMat<N>& z1,
-                                            sympa::CMat<N>& z2) {
-    constexpr int NBUF = PassTile<N, MASKED>::NBUF;
-    constexpr int LOOK = NBUF - 1;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) { z1.re[i][j] = 0.0; z1.im[i][j] = 0.0; z2.re[i][j] = 0.0; z2.im[i][j] = 0.0; }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (s >= NBUF) {
-            // issued so far: passes 0 .. s + LOOK; those behind pass s stay in flight
-            const int behind = (8 - 1 - s) < LOOK ? (8 - 1 - s) : LOOK;
-            if (behind == 2) wait_vmcnt<32>();
-            else if (behind == 1) wait_vmcnt<16>();
-            else wait_vmcnt<0>();
-        }
-        wave_lds_fence();
-        const v2d* cur = tile + (s % NBUF) * PassTile<N, MASKED>::BUF_SLOTS;
-        if (s < 4) pass_read<N, MASKED>(cur, s, z1);
-        else pass_read<N, MASKED>(cur, s - 4, z2);
-        if (s + NBUF < 8) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the buffer just read is refilled
-            wave_lds_fence();
-            const int p = s + NBUF;
-            v2d* buf = tile + (p % NBUF) * PassTile<N, MASKED>::BUF_SLOTS;
-            if (p < 4) pass_issue<N, MASKED>(base1, row1, p, buf, my_chunk);
-            else pass_issue<N, MASKED>(base2, row2, p - 4, buf, my_chunk);
-        }
-    }
-}

@@ -70,7 +70,7 @@ def test_integration_md_stub_compiles_and_matches_the_binding():
     import re
     from abc import ABC
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    sec = text[text.index("## 3."):text.index("## 4.")]
+    sec = text[text.index("## 3."):text.index("### 3b.")]      # 3b shows the loops around the path, not the ctypes stub
     blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
     assert len(blocks) == 1
     src = blocks[0]
