@@ -62,6 +62,15 @@ def train(args, log=print):
                               mode="auto" if args.grad_exchange == "none" else args.grad_exchange)
         if rank == 0:
             log(f"gradient exchange: {ex.mode}, {ex.message_bytes / 1e6:.3f} MB sent per rank per step")
+    # steps with an exchange in the middle run eagerly, but the optimiser side is still ONE launch where the fused kernel
+    # applies (clip norm + RiemannianSGD + scale step + zero_grad on the exchanged gradient, which lives in ex's flat buffer)
+    stepper = None
+    if ex is not None and args.optim == "rsgd":
+        stepper = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev)
+        if stepper.mode == "two_kernels":
+            stepper._ensure_fused()          # after GradientExchange: p.grad are views of its flat buffer
+        else:
+            stepper = None
     for epoch in range(1, args.epochs + 1):
         mine = shard_triplets(trip, rank, world, epoch=epoch, seed=0).to(dev)
         t0 = time.perf_counter()
@@ -94,8 +103,11 @@ def train(args, log=print):
                 else:                                   # dense mode, or the ragged last batch of an epoch
                     loss_sum += model.fused_loss_backward(ids, gd)
                     ex.allreduce()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)      # runner.py:115
-            opt.step()
+            if stepper is not None:
+                stepper._fused_step()                                                       # runner.py:115-118 in one launch
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), args.max_grad_norm)      # runner.py:115
+                opt.step()
         # the reference asserts inside every dist() call (siegel_manifold.py:64-66) and checks all points once per epoch
         # (runner.py:180-184); here the status word of the kernels is read once per epoch (one host sync)
         ops.check_status(dev)
