@@ -601,6 +601,16 @@ def main():
         # 1024 SIMDs at the 2.4 GHz peak clock)
         if valu_per_wave:
             rec["valu_issue_fraction"] = (value / world) / 64.0 * valu_per_wave * 4.0 / (1024 * 2.4e9)
+        # SURVEY 8d, flop form of the same roof: pairs/s x flops per pair / the fp64 vector peak (78.6 TFLOP/s = 256 CUs x 4
+        # SIMDs x 32 FLOP/clk x 2.4 GHz).  Own flops: VALU instructions per pair (the PMC figure: one lane executes the wave's
+        # stream for its pair) x the static flops-per-VALU-instruction ratio of the headline kernel's ISA (3 034 flops in
+        # 2 300 VALU instructions: FMA = 2, mul / add / max / rsq = 1, moves and integer work = 0; tools/asm_stats.py); the
+        # reference executes ~121 n^3 flops for the same pair (17 matmuls, 3 inverses, eigh(n), eigh(2n))
+        if valu_per_wave and args.workload == "upper-riem-n4-b65536":
+            own = valu_per_wave * 3034.0 / 2300.0
+            rec["fp64_flops"] = {"peak_tflops": 78.6, "own_flops_per_pair": own, "reference_flops_per_pair": 121.0 * n ** 3,
+                                 "frac_own": (value / world) * own / 78.6e12,
+                                 "reference_equivalent_tflops": (value / world) * 121.0 * n ** 3 / 1e12}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(model, metric, n, nodes, my_pairs, args.seed,
                                                pairs=None if args.pairs == "sampled" else batches[0][:, :2].cpu())
