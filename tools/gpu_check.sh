@@ -26,10 +26,10 @@ sys.exit(1 if f else 0)" 2>&1 | grep -v amdgpu.ids | tee -a $OUT/selfcheck.txt
 echo "== bench (driver's command line, then defaults)"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_k20.err | tail -1 | tee $OUT/bench_k20.json | cut -c1-300
 timeout 600 python bench.py 2>$OUT/bench.err | tail -1 | tee $OUT/bench.json | cut -c1-300
-SYMPA_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>$OUT/bench_k20_dist.err | tail -1 | tee $OUT/bench_k20_forcedist.json | cut -c1-200
+SYMPA_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic 2>$OUT/bench_k20_dist.err | tail -1 | tee $OUT/bench_k20_forcedist.json | cut -c1-200
 echo "== rocprof kernel trace (same commands)"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k20 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_k20.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline > $OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k20 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $OUT/prof_k20.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --no-cpu-baseline --no-live-traffic > $OUT/prof_bench.log 2>&1
 for d in prof_k20 prof; do find $OUT/$d -name "*kernel_stats.csv" | head -1 | xargs -r head -4; done | tee $OUT/kernel_stats_head.txt
 bash tools/pmc_collect.sh $TAG > $OUT/pmc.log 2>&1
 tail -30 $OUT/pmc.log
@@ -39,13 +39,13 @@ echo "== secondary workloads (bench line, then rocprof kernel trace of each, one
 for W in margulis-bounded-finf-n4-b65536 cartesian-upper-riem-n8-b262144 custom-spd-n16-b1048576 tree-upper-riem-n4-b8192 grid-upper-riem-n2-b512; do
   timeout 600 python bench.py --workload $W --steps 64 --warmup 8 2>$OUT/bench_$W.err | tail -1 > $OUT/bench_$W.json
   cut -c1-300 $OUT/bench_$W.json
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --steps 64 --warmup 8 --launch graph --streams 1 > $OUT/prof_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -- python3 bench.py --workload $W --no-cpu-baseline --no-live-traffic --steps 64 --warmup 8 --launch graph --streams 1 > $OUT/prof_$W.log 2>&1
   find $OUT/prof_$W -name "*kernel_stats.csv" | head -1 | xargs -r head -2
 done
 echo "== the graph workloads on their real (i < j, d) triplets (--pairs graph: evaluation order; graph-shuffled: training order)"
 for W in grid-upper-riem-n2-b512 tree-upper-riem-n4-b8192 margulis-bounded-finf-n4-b65536; do
   for P in graph graph-shuffled; do
-    timeout 600 python bench.py --workload $W --pairs $P --steps 64 --warmup 8 --no-cpu-baseline 2>>$OUT/bench_graph.err | tail -1 | tee -a $OUT/bench_graph_pairs.json | cut -c1-200
+    timeout 600 python bench.py --workload $W --pairs $P --steps 64 --warmup 8 --no-cpu-baseline --no-live-traffic 2>>$OUT/bench_graph.err | tail -1 | tee -a $OUT/bench_graph_pairs.json | cut -c1-200
   done
 done
 echo "== evaluation epoch of the harness (Model.evaluate on configs[1]'s 596 778 triplets, batch 8192)"

@@ -10,7 +10,7 @@ EXTRA=${5:-}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WORKLOAD --steps 128 --warmup 32 --no-cpu-baseline $EXTRA"
+ARGS="bench.py --workload $WORKLOAD --steps 128 --warmup 32 --no-cpu-baseline --no-live-traffic $EXTRA"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 $ARGS > $OUT/tcc.log 2>&1
