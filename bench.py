@@ -144,7 +144,7 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0, pairs=None
                       f"{el:.1f} s"}
 
 
-def live_traffic(argv_base, kernel_substring, pairs_per_launch, timeout_s=150):
+def live_traffic(argv_base, kernel_substring, pairs_per_launch, timeout_s=60):
     """HBM-side bytes per launch of the timed kernel, measured NOW: two child runs of this file under `rocprofv3 --pmc`
     (FETCH_SIZE, then WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes), every sample
     normalised by the work-items of its dispatch (one pair per lane).  2 x FETCH_SIZE + WRITE_SIZE KiB: the guide's gfx950
