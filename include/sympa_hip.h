@@ -75,16 +75,20 @@ extern "C" {
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
-#define SYMPA_MAX_DIMS_BACKWARD 16 /* largest n with a backward kernel in this build (n = 7, 8 spill to scratch; n = 9..16 run
-                                      sixteen lanes per pair, csrc/siegel_coop_bwd.hpp; SYMPA_FLAG_GENERIC selects the same
-                                      adjoint as rolled loops over per-lane scratch arrays; SYMPA_FLAG_COOP at n = 7, 8 runs
-                                      the sixteen-lanes kernel for A/B) */
+#define SYMPA_MAX_DIMS_BACKWARD 16 /* largest n with a backward kernel in this build: n <= 6 one pair per lane in registers;
+                                      n = 7, 8 one pair per lane or eight lanes per pair (the default where measured faster;
+                                      SYMPA_FLAG_COOP forces the eight-lanes kernels at n = 5..8, SYMPA_FLAG_GENERIC the
+                                      one-pair-per-lane ones); n = 9..16 sixteen lanes per pair (csrc/siegel_coop_bwd.hpp),
+                                      SYMPA_FLAG_GENERIC selects the same adjoint as rolled loops over per-lane scratch */
 #define SYMPA_MAX_DIMS_ALL_PAIRS_PACKED 8 /* sympa_all_pairs_dist_packed: per-point factor reuse, dims 1..8 (dims 8: the 64
                                              packed column points of a block live in an LDS tile, 55 / 70 KB) */
 #define SYMPA_MAX_DIMS_GENERIC 16 /* n in (SYMPA_MAX_DIMS, 16]: the forward runs sixteen lanes per pair (csrc/siegel_coop.hpp;
-                                     SYMPA_FLAG_GENERIC selects the runtime-n fallback over scratch); the table operations
-                                     (sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step* / sympa_tangent_sqnorm) run the
-                                     row arithmetic of dims <= 8 with rolled loops over scratch (siegel_table_rolled.hip) */
+                                     SYMPA_FLAG_GENERIC selects the runtime-n fallback over scratch).  The table operations
+                                     (sympa_egrad2rgrad / sympa_projx / sympa_rsgd_step* / sympa_tangent_sqnorm) run one row
+                                     per lane for n <= 6, eight lanes per row at n = 7, 8 and sixteen at n = 9..16
+                                     (csrc/siegel_coop_table.hpp); the rolled one-row-per-lane kernels over scratch
+                                     (siegel_table_rolled.hip) remain for the gated exact projection and behind
+                                     SYMPA_TABLE_GENERIC=1 / an instance fallback */
 
 /* Library / build identification. */
 const char* sympa_version(void);
@@ -329,8 +333,8 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
  * dist = || log(x^-1/2 y x^-1/2) ||_F  (geoopt's default affine-invariant metric; geoopt is absent from the
  * reference tree: parity unpinned).  sympa_spd_model_forward is Model.forward for that model
  * (sympa/model.py:16-41) with a [num_rows, n, n] table.  flags: 0 or SYMPA_FLAG_GENERIC.
- * 6 <= n <= 16 run the sixteen-lanes-per-pair kernel (csrc/spd_coop.hpp; n < 16 padded with the identity),
- * n <= 5 the runtime-n one-lane-per-pair kernel. */
+ * 6 <= n <= 16 run the sixteen-lanes-per-pair kernel (csrc/spd_coop.hpp: one instantiation per n, lanes r >= n of a group
+ * are phantoms), n <= 5 the runtime-n one-lane-per-pair kernel. */
 int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status, int flags,
                        void* stream);
 int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
