@@ -41,14 +41,21 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
 // M < 16 (6 <= n < 16, one instantiation per n): the row-per-lane routines are templates over the matrix size, lanes
 // r >= M of a group are phantoms (spd_coop.hpp), the time goes with M^2.  Rows are n*n*8 bytes then, not the 2 KB image
 // the DMA tile is made for, so each lane loads the elements of its row itself (upper triangle: (min, max)).
+// two waves per SIMD (256 registers) up to this size of the handed-over block, one beyond
+#ifndef SYMPA_SPD_TB_TWO_WAVES
+#define SYMPA_SPD_TB_TWO_WAVES 10
+#endif
 template <int M>
-__global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
+__global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_TWO_WAVES ? 2 : 1)) void spd16_coop_kernel(const DistArgs a) {
     using namespace spd_coop;
     constexpr bool PADDED = M < N;      // historical name: "not the 2 KB image of n = 16"
     constexpr int n = M;
+    constexpr int TB = trailing_block<M>();
     __shared__ __attribute__((aligned(16))) char tile[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) double hand_all[GROUPS_PER_WAVE * (TB >= 3 ? TB * TB : 2)];
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
+    double* const hand = hand_all + g * (TB >= 3 ? TB * TB : 2);
     const int64_t i = (int64_t)blockIdx.x * 64 + 4 * r + g;
     const bool live = i < a.b;
     const int64_t ii = live ? i : a.b - 1;
@@ -74,11 +81,14 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
         voff[h] = (unsigned)(rr * 128 + c * 16);
     }
     // byte offset of element (r, j) of my pair's X image (upper triangle only: (min, max))
-    int eoff[M];
+    // (two 14-bit offsets per register: the sixteen of them would otherwise hold sixteen registers through the kernel)
+    unsigned eoff2[(M + 1) / 2];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int lo = r < j ? r : j, hi = r < j ? j : r;
-        eoff[j] = g * 4096 + tile_slot(lo, hi >> 1) * 16 + (hi & 1) * 8;
+        const unsigned e = (unsigned)(g * 4096 + tile_slot(lo, hi >> 1) * 16 + (hi & 1) * 8);
+        if (j & 1) eoff2[j / 2] |= e << 16;
+        else eoff2[j / 2] = e;
     }
     auto issue = [&](const int t) {
 #pragma unroll
@@ -89,9 +99,11 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 1024), 16, 0, 0);
         }
     };
-    double d[M], e2[M];
+    double d[M], e2[M], blk[packed_len<TB>()];
 #pragma unroll
     for (int k = 0; k < M; ++k) { d[k] = 0.0; e2[k] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < packed_len<TB>(); ++k) blk[k] = 0.0;
     bool ok = true;
     if constexpr (!PADDED) issue(0);
     for (int t = 0; t < ROUNDS; ++t) {
@@ -113,21 +125,35 @@ __global__ __launch_bounds__(64) void spd16_coop_kernel(const DistArgs a) {
             wave_lds_fence();
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                x[j] = *reinterpret_cast<const double*>(tile + eoff[j]);
-                y[j] = *reinterpret_cast<const double*>(tile + 2048 + eoff[j]);
+                unsigned pk = eoff2[j / 2];
+                asm volatile("" : "+v"(pk));        // unpack here, every round: hoisted out of the loop it is sixteen registers again
+                const unsigned e = (j & 1) ? (pk >> 16) : (pk & 0xffffu);
+                x[j] = *reinterpret_cast<const double*>(tile + e);
+                y[j] = *reinterpret_cast<const double*>(tile + 2048 + e);
             }
         }
-        double rd[M], m[M];
-        const bool pd = reduce_pair_front(x, y, rd, m, reinterpret_cast<double*>(tile + g * 2048), r);
+        if constexpr (TB >= 3) {
+            // the trailing block of the previous round's pair, behind this round's loads
+            wave_lds_fence();
+            if (t > 0 && r == t - 1) take_block<TB>(blk, hand);
+        }
+        double rdl, m[M];
+        const bool pd = reduce_pair_front(x, y, rdl, m, reinterpret_cast<double*>(tile) + g * (N * TPAD), r);
         // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
         __builtin_amdgcn_s_waitcnt(0xC07F);
         wave_lds_fence();
         if constexpr (!PADDED) if (t + 1 < ROUNDS) issue(t + 1);
         const bool keep = (r == t);
         ok = keep ? pd : ok;
-        reduce_pair_back(m, x, rd, r, keep, d, e2);
+        reduce_pair_back<M, TB>(m, x, rdl, r, keep, 0x0001000100010001ull << t, d, e2, hand);
     }
-    // one pair per lane: QL on the tridiagonal forms, then the norm of the logarithms
+    if constexpr (TB >= 3) {
+        wave_lds_fence();
+        if (r == ROUNDS - 1) take_block<TB>(blk, hand);
+    }
+    // one pair per lane from here: the rest of the tridiagonalisation (the trailing TB x TB block of my pair), ...
+    if constexpr (TB >= 3) sympa::tridiag_packed<TB>(blk, d + (M - TB), e2 + (M - TB));
+    // ... QL on the tridiagonal forms, then the norm of the logarithms
     const bool conv = sympa::tridiag_ql_lockstep<M>(d, e2);
     double acc = 0.0;
 #pragma unroll

@@ -248,13 +248,63 @@ __device__ __forceinline__ void cholesky_rows2(double (&x)[M], double (&rdx)[M],
     });
 }
 
-// m <- y^T for the rows held one per lane, through 2 KB of LDS private to my group
+// dst <- src in the lanes of `mask` only (a wave-uniform 64-bit lane mask), one VALU instruction: the select
+// `dst = cond ? src : dst` costs two v_cndmask_b32 for a double.  The wave runs with all 64 lanes enabled wherever this
+// is used (one wave per block, no divergent exit before), so EXEC is restored to all ones.
+__device__ __forceinline__ void mov_in_lanes(double& dst, const double src, const unsigned long long mask) {
+    asm volatile("s_mov_b64 exec, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "s"(mask));
+}
+
+// X = Lh D Lh^T with Lh UNIT lower triangular, right-looking, in place: after step j, register j of lane i > j holds
+// Lh[i][j] = L[i][j] / L[j][j].  No array of reciprocal diagonals (32 registers): lane j captures its own pivot D_j and
+// `rdl` = 1 / sqrt(D_j) = 1 / L[j][j] is ONE value per lane, computed for all sixteen pivots at once after the loop; the
+// triangular solves against a unit factor need no scaling, and  L^-1 A L^-T = D^-1/2 (Lh^-1 A Lh^-T) D^-1/2  puts the
+// scaling into one per-lane multiply of the transposed intermediate and one broadcast multiply at the end.
 template <int M>
+__device__ __forceinline__ bool ldl_rows(double (&x)[M], double& rdl) {
+    double mine = 1.0;
+    sfor<0, M>([&](auto J) {
+        constexpr int j = J;
+        const double t = settle(x[j]);
+        const double piv = bcast<j>(t);
+        mov_in_lanes(mine, t, 0x0001000100010001ull << j);
+        x[j] = settle(t * sympa::d_rcp(piv));
+        sfor<j + 1, M>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<k>(x[k], x[j], t);         // X[i][k] -= Lh[k][j] X[i][j]   (X[i][j] = Lh[i][j] D_j: the unscaled column)
+        });
+    });
+    rdl = sympa::d_rsqrt(mine);
+    // all pivots of my group positive (a NaN pivot compares false; the phantoms hold 1)
+    const unsigned long long pos = __ballot(mine > 0.0);
+    return ((pos >> (threadIdx.x & 48)) & 0xffffull) == 0xffffull;      // my group's sixteen bits
+}
+
+// a <- a Lh^-T for a unit lower factor:  a[j] -= sum_{k<j} a[k] Lh[j][k]
+template <int M>
+__device__ __forceinline__ void solve_right_unit(double (&a)[M], const double (&l)[M]) {
+    sfor<0, M>([&](auto J) {
+        constexpr int j = J;
+        sfor<0, j>([&](auto K) {
+            constexpr int k = K;
+            fnmac_bc<j>(a[j], l[k], a[k]);
+        });
+    });
+}
+
+// m <- y^T for the rows held one per lane, through 2 KB of LDS private to my group
+// STRIDE = doubles per row of the buffer.  With N = 16 (128 bytes) the sixteen lanes of a group write their 16-byte chunk c
+// to addresses 128 bytes apart: two sets of banks for the whole wave, a 32-way conflict on every ds_write_b128
+// (SQ_LDS_BANK_CONFLICT: 58 % of the LDS-busy cycles of the spd forward kernel).  STRIDE = TPAD = 18 (144 bytes, still
+// 16-byte aligned) puts the sixteen rows of a group on sixteen different sets of four banks; the transposed read
+// (sixteen consecutive doubles of one row) is conflict-free either way.  A group's buffer is then N * TPAD doubles.
+constexpr int TPAD = 18;
+template <int M, int STRIDE = N>
 __device__ __forceinline__ void transpose_rows(const double (&y)[M], double (&m)[M], double* __restrict__ tbuf, const int r) {
     wave_lds_fence();
-    sfor<0, M>([&](auto J) { tbuf[r * N + J] = y[J]; });
+    sfor<0, M>([&](auto J) { tbuf[r * STRIDE + J] = y[J]; });
     wave_lds_fence();
-    sfor<0, M>([&](auto J) { m[J] = tbuf[J * N + r]; });
+    sfor<0, M>([&](auto J) { m[J] = tbuf[J * STRIDE + r]; });
 }
 
 // dst[0 .. M*M) += the M x M block whose row r is `v` in lane r (fp64 atomics), through the group's LDS tile so that
@@ -275,28 +325,64 @@ __device__ __forceinline__ void scatter_plane(const double (&v)[M], double* __re
 }
 
 // First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
-// W^T = L^-1 (Y - X) out.  `tbuf` = 2 KB of LDS private to my group for the transpose.  Returns "X is PD".
+// W^T = L^-1 (Y - X) out.  `tbuf` = N * TPAD doubles of LDS private to my group for the transpose.  Returns "X is PD".
 template <int M>
-__device__ __forceinline__ bool reduce_pair_front(double (&x)[M], double (&y)[M], double (&rd)[M], double (&m)[M],
+__device__ __forceinline__ bool reduce_pair_front(double (&x)[M], double (&y)[M], double& rdl, double (&m)[M],
                                                   double* __restrict__ tbuf, const int r) {
-    sfor<0, M>([&](auto J) { y[J] -= x[J]; });      // D = Y - X
-    const bool pd = cholesky_rows(x, rd);
-    solve_right_lt(y, x, rd);                        // W = D L^-T
-    transpose_rows(y, m, tbuf, r);
+    sfor<0, M>([&](auto J) { y[J] -= x[J]; });      // A = Y - X
+    const bool pd = ldl_rows(x, rdl);
+    solve_right_unit(y, x);                          // B = A Lh^-T     (W = B D^-1/2)
+    transpose_rows<M, TPAD>(y, m, tbuf, r);
+    sfor<0, M>([&](auto J) { m[J] *= rdl; });        // row j of W^T = column j of B / L[j][j]
     return pd;
 }
 
-// Second half: M = W^T L^-T = L^-1 (Y - X) L^-T, then its tridiagonal form (d, e2), kept by the lane with keep = true.
+// Trailing block handed to the one-pair-per-lane phase (spd_math.hpp tridiag_packed).  A Householder step in the
+// row-per-lane layout costs ~75 wave instructions of group-uniform scalar work and reductions next to its 3 (M - k - 1)
+// useful DPP FMAs, and serves FOUR pairs; the same step one pair per lane serves 64.  So only the first M - TB steps
+// run here; the TB x TB block that is left goes through the LDS to the lane that keeps the pair (36 doubles for
+// TB = 8 -- what the register budget of two waves per SIMD allows), which finishes the tridiagonalisation after the
+// last round together with the 63 other pairs of the wave.
 template <int M>
-__device__ __forceinline__ void reduce_pair_back(double (&m)[M], const double (&x)[M], const double (&rd)[M],
-                                                 const int r, const bool keep, double (&d)[M], double (&e2)[M]) {
-    solve_right_lt(m, x, rd);
+constexpr int trailing_block() {
+#ifdef SYMPA_SPD_TB
+    return (SYMPA_SPD_TB > M) ? M : SYMPA_SPD_TB;
+#else
+    return M < 10 ? M : 10;
+#endif
+}
+template <int TB>
+constexpr int packed_len() { return TB >= 3 ? TB * (TB + 1) / 2 : 1; }
+
+// The packed lower triangle of the block my group left in `hand`.  Call it under `if (lane keeps that pair)`: a real
+// branch (55 loads under the EXEC mask for TB = 10), the other lanes keep the blocks of their own pairs.
+template <int TB>
+__device__ __forceinline__ void take_block(double (&blk)[packed_len<TB>()], const double* __restrict__ hand) {
+    sfor<0, TB>([&](auto I) {
+        constexpr int i = I;
+        sfor<0, i + 1>([&](auto J) { blk[i * (i + 1) / 2 + J] = hand[i * TB + J]; });
+    });
+}
+
+// Second half: M = W^T L^-T = L^-1 (Y - X) L^-T, then the first M - TB steps of its tridiagonalisation: (d, e2)[0 .. M - TB)
+// kept by the lane with keep = true (`keepmask`: those lanes as a wave mask), and the trailing block into `hand`
+// (TB * TB doubles of LDS private to my group).  TB < 3: all of it here.
+template <int M, int TB>
+__device__ __forceinline__ void reduce_pair_back(double (&m)[M], const double (&x)[M], const double rdl,
+                                                 const int r, const bool keep, const unsigned long long keepmask,
+                                                 double (&d)[M], double (&e2)[M], double* __restrict__ hand) {
+    solve_right_unit(m, x);
+    {
+        const double rs = settle(rdl);
+        sfor<0, M>([&](auto J) { m[J] *= bcast<J>(rs); });      // column j / L[j][j]
+    }
+    constexpr int KS = (TB >= 3) ? M - TB : M - 2;      // steps taken here
 
     // Householder tridiagonalisation.  The reflector of step k is taken from COLUMN k, one element per lane (my
     // own register k), and broadcast from there for every use: with a single source for v the update is an exact
     // similarity whatever rounding-level asymmetry M carries.  (Mixing row k of lane k with my own column element
     // is inconsistent by that asymmetry RELATIVE TO |v|, which is large when the eliminated column is small.)
-    sfor<0, M - 2>([&](auto K) {
+    sfor<0, KS>([&](auto K) {
         constexpr int k = K;
         const double col = settle(m[k]);
         const double x0 = bcast<k + 1>(col);
@@ -304,34 +390,48 @@ __device__ __forceinline__ void reduce_pair_back(double (&m)[M], const double (&
         const double tail = (r > k + 1 && r < M) ? col : 0.0;
         const double s2 = group_sum(tail * tail);
         const double n2 = sympa::d_fma(x0, x0, s2);
-        d[k] = keep ? dk : d[k];
-        e2[k] = keep ? n2 : e2[k];
+        mov_in_lanes(d[k], dk, keepmask);
+        mov_in_lanes(e2[k], n2, keepmask);
         const double nx = sympa::d_sqrt(n2);
         const double v0 = x0 + copysign(nx, x0);
         const double den = sympa::d_fma(v0, v0, s2);
-        const double beta = (den > 0.0) ? 2.0 * sympa::d_rcp(den) : 0.0;
-        const double vi = settle((r <= k || r >= M) ? 0.0 : ((r == k + 1) ? v0 : col));
-        // p_i = sum_j M[i][j] v_j, four partial sums: the chain is the latency of the step
-        double ps[4] = {0.0, 0.0, 0.0, 0.0};
-        sfor<k + 1, M>([&](auto J) { fmac_bc<J>(ps[J % 4], vi, m[J]); });
-        double p = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        p = (r <= k || r >= M) ? 0.0 : beta * p;
-        const double kk = 0.5 * beta * group_sum(vi * p);
+        // a zero column (den = 0): v = 0, so p = q = 0 whatever the (finite) beta
+        const double hb = sympa::d_rcp(fmax(den, 1e-300));         // beta / 2
+        const double beta = hb + hb;
+        const double vi = settle((r == k + 1) ? v0 : tail);        // 0 in the finished rows (r <= k) and the phantoms
+        // p_i = beta sum_j M[i][j] v_j
+        double ps[2] = {0.0, 0.0};
+        sfor<k + 1, M>([&](auto J) { fmac_bc<J>(ps[J % 2], vi, m[J]); });
+        double p = beta * (ps[0] + ps[1]);
+        // a phantom row (r >= M) holds whatever the LDS held where nobody wrote (its transposed read): possibly NaN, and
+        // 0 * NaN would poison the sum below
+        if constexpr (M < N) p = (r < M) ? p : 0.0;
+        const double kk = hb * group_sum(vi * p);
         const double q = settle(sympa::d_fma(-kk, vi, p));
-        // M <- M - q v^T - v q^T on the trailing block (lanes <= k have v = q = 0 and keep their rows)
+        // M <- M - q v^T - v q^T.  Not masked to the trailing block: a finished row r <= k (v_r = 0) receives -v_j q_r,
+        // which is what the two-sided reflection does to it (its eliminated entries); a phantom row (p = q = 0) keeps
+        // whatever it holds.  Neither is read again.
         sfor<k + 1, M>([&](auto J) {
             constexpr int j = J;
             fnmac_bc<j>(m[j], vi, q);       // - v_j q_i
             fnmac_bc<j>(m[j], q, vi);       // - q_j v_i
         });
     });
-    const double last = settle(m[M - 1]);
-    const double dm = bcast<M - 2>(settle(m[M - 2]));
-    const double dn = bcast<M - 1>(last);
-    const double en = bcast<M - 2>(last);
-    d[M - 2] = keep ? dm : d[M - 2];
-    d[M - 1] = keep ? dn : d[M - 1];
-    e2[M - 2] = keep ? en * en : e2[M - 2];
+    if constexpr (TB >= 3) {
+        // rows KS .. M-1 of the trailing block, one per lane -> the LDS -> packed lower triangle in the keeping lane.
+        // The keeping lane collects it (take_block) at the start of the NEXT round, behind that round's loads, so that
+        // nobody waits for these 55 loads here.
+        wave_lds_fence();       // the previous round's block has been collected
+        if (r >= KS && r < M) sfor<KS, M>([&](auto J) { hand[(r - KS) * TB + (J - KS)] = m[J]; });
+    } else {
+        const double last = settle(m[M - 1]);
+        const double dm = bcast<M - 2>(settle(m[M - 2]));
+        const double dn = bcast<M - 1>(last);
+        const double en = bcast<M - 2>(last);
+        mov_in_lanes(d[M - 2], dm, keepmask);
+        mov_in_lanes(d[M - 1], dn, keepmask);
+        mov_in_lanes(e2[M - 2], en * en, keepmask);
+    }
 }
 
 }  // namespace spd_coop

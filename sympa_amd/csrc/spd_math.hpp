@@ -93,6 +93,57 @@ SYMPA_HD bool tridiag_ql_runtime(double* d, double* e2, int n) {
     return done;
 }
 
+// Householder tridiagonalisation of a real symmetric S x S matrix held PACKED by one lane: element (i, j), i >= j, is
+// a[i (i + 1) / 2 + j]; fully unrolled, every index a constant, so the 36 doubles of an 8 x 8 block live in registers.
+// Out: d[0 .. S), e2[0 .. S - 1) (squares of the off-diagonal).  The lanes-per-pair kernels (spd_coop.hpp) hand the
+// trailing block of every pair to this routine: a step here serves 64 pairs per wave instruction, a step in the
+// row-per-lane layout four.
+template <int S>
+SYMPA_HD void tridiag_packed(double (&a)[S * (S + 1) / 2], double* __restrict__ d, double* __restrict__ e2) {
+#define SYMPA_AP(i, j) a[((i) >= (j)) ? ((i) * ((i) + 1) / 2 + (j)) : ((j) * ((j) + 1) / 2 + (i))]
+SYMPA_UNROLL
+    for (int k = 0; k < S - 2; ++k) {
+        double s2 = 0.0;
+SYMPA_UNROLL
+        for (int i = k + 2; i < S; ++i) s2 = d_fma(SYMPA_AP(i, k), SYMPA_AP(i, k), s2);
+        const double x0 = SYMPA_AP(k + 1, k);
+        const double n2 = d_fma(x0, x0, s2);
+        d[k] = SYMPA_AP(k, k);
+        e2[k] = n2;
+        const double nx = d_sqrt(n2);
+        const double v0 = x0 + copysign(nx, x0);
+        const double den = d_fma(v0, v0, s2);
+        const double beta = (den > 0.0) ? 2.0 * d_rcp(den) : 0.0;
+        double v[S], p[S];
+        v[k + 1] = v0;
+SYMPA_UNROLL
+        for (int i = k + 2; i < S; ++i) v[i] = SYMPA_AP(i, k);
+        double kk = 0.0;
+SYMPA_UNROLL
+        for (int i = k + 1; i < S; ++i) {
+            double t = 0.0;
+SYMPA_UNROLL
+            for (int j = k + 1; j < S; ++j) t = d_fma(SYMPA_AP(i, j), v[j], t);
+            p[i] = beta * t;
+            kk = d_fma(v[i], p[i], kk);
+        }
+        kk *= 0.5 * beta;
+SYMPA_UNROLL
+        for (int i = k + 1; i < S; ++i) p[i] = d_fma(-kk, v[i], p[i]);
+SYMPA_UNROLL
+        for (int i = k + 1; i < S; ++i) {
+SYMPA_UNROLL
+            for (int j = k + 1; j <= i; ++j) SYMPA_AP(i, j) = d_fma(-v[i], p[j], d_fma(-p[i], v[j], SYMPA_AP(i, j)));
+        }
+    }
+    if (S >= 2) {
+        d[S - 2] = SYMPA_AP(S - 2, S - 2);
+        e2[S - 2] = SYMPA_AP(S - 1, S - 2) * SYMPA_AP(S - 1, S - 2);
+    }
+    d[S - 1] = SYMPA_AP(S - 1, S - 1);
+#undef SYMPA_AP
+}
+
 // px, py: [n, n] fp64 row-major symmetric (upper triangle read).  Returns the AIM distance.
 SYMPA_HD double spd_pair_distance(SpdWork& w, const double* __restrict__ px, const double* __restrict__ py, int n,
                                   int& status) {

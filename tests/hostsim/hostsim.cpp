@@ -215,3 +215,34 @@ extern "C" int sympa_hostsim_spd_table(int op, int n, const double* x, const dou
     if (moved) *moved = mv;
     return st;
 }
+
+// Eigenvalues of b symmetric s x s matrices (full row-major in): packed one-lane Householder (spd_math.hpp
+// tridiag_packed, the trailing-block routine of the lanes-per-pair kernels) + the runtime QL.
+template <int S>
+static void run_tridiag_packed(const double* a, int64_t b, double* eig) {
+    for (int64_t q = 0; q < b; ++q) {
+        double pk[S * (S + 1) / 2], d[S], e2[S];
+        for (int i = 0; i < S; ++i)
+            for (int j = 0; j <= i; ++j) pk[i * (i + 1) / 2 + j] = a[q * S * S + i * S + j];
+        for (int i = 0; i < S; ++i) e2[i] = 0.0;
+        sympa::tridiag_packed<S>(pk, d, e2);
+        sympa::tridiag_ql_runtime(d, e2, S);
+        for (int i = 0; i < S; ++i) eig[q * S + i] = d[i];
+    }
+}
+extern "C" int sympa_hostsim_tridiag_packed(const double* a, int64_t b, int s, double* eig) {
+    switch (s) {
+        case 2: run_tridiag_packed<2>(a, b, eig); return 0;
+        case 3: run_tridiag_packed<3>(a, b, eig); return 0;
+        case 4: run_tridiag_packed<4>(a, b, eig); return 0;
+        case 5: run_tridiag_packed<5>(a, b, eig); return 0;
+        case 6: run_tridiag_packed<6>(a, b, eig); return 0;
+        case 7: run_tridiag_packed<7>(a, b, eig); return 0;
+        case 8: run_tridiag_packed<8>(a, b, eig); return 0;
+        case 9: run_tridiag_packed<9>(a, b, eig); return 0;
+        case 10: run_tridiag_packed<10>(a, b, eig); return 0;
+        case 12: run_tridiag_packed<12>(a, b, eig); return 0;
+        case 16: run_tridiag_packed<16>(a, b, eig); return 0;
+        default: return -2;
+    }
+}
