@@ -30,11 +30,11 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
     using spd_coop::solve_right_l;
     using spd_coop::solve_right_lt;
     using spd_coop::transpose_rows;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[spd_coop::GROUPS_PER_WAVE * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[spd_coop::GROUPS_PER_WAVE * spd_coop::TBUF];
     const DistArgs& f = a.f;
     const int lane = threadIdx.x;
     const int g = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
-    double* const tbuf = tbuf_all + g * N * N;
+    double* const tbuf = tbuf_all + g * spd_coop::TBUF;
     constexpr int nn = M * M;
     constexpr int64_t ROW = 2 * nn;
     double sc = 1.0;

@@ -25,7 +25,7 @@ template <int MODEL, int M>
 __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void siegel_coop_kernel(const DistArgs a) {
     constexpr bool PREFETCH = !coop_two_waves<MODEL, M>();
     using namespace siegel_coop;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[COOP_GPW * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[COOP_GPW * spd_coop::TBUF];
     static_assert(M <= spd_coop::GROUP, "matrix rows per group");
     const int lane = threadIdx.x;
     const int g = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
         if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { st |= sympa::ST_BAD_INDEX; r1 = 0; r2 = 0; }
     }
     const int row1 = (int)r1, row2 = (int)r2;      // num_rows < 2^31 (checked on the host)
-    double* const tbuf = tbuf_all + g * N * N;
+    double* const tbuf = tbuf_all + g * spd_coop::TBUF;
     constexpr int nn = M * M;
 
     double d[M], e2[M];

@@ -29,10 +29,10 @@ __global__ __launch_bounds__(64) void siegel_coop_table_kernel(double* __restric
     constexpr bool UPPER = (MODEL == sympa::MODEL_UPPER);
     using spd_coop::matmul_rows;
     using spd_coop::transpose_rows;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[spd_coop::GROUPS_PER_WAVE * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[spd_coop::GROUPS_PER_WAVE * spd_coop::TBUF];
     const int lane = threadIdx.x;
     const int grp = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
-    double* const tbuf = tbuf_all + grp * N * N;
+    double* const tbuf = tbuf_all + grp * spd_coop::TBUF;
     constexpr int nn = M * M;
     constexpr int64_t ROW = 2 * nn;
     const double coef = (clip != nullptr) ? fmin(1.0, max_norm / (sqrt(clip[0]) + 1e-6)) : 1.0;

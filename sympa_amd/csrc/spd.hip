@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_
             if (t > 0 && r == t - 1) take_block<TB>(blk, hand);
         }
         double rdl, m[M];
-        const bool pd = reduce_pair_front(x, y, rdl, m, reinterpret_cast<double*>(tile) + g * (N * TPAD), r);
+        const bool pd = reduce_pair_front(x, y, rdl, m, reinterpret_cast<double*>(tile) + g * TBUF, r);
         // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
         __builtin_amdgcn_s_waitcnt(0xC07F);
         wave_lds_fence();

@@ -297,9 +297,12 @@ __device__ __forceinline__ void solve_right_unit(double (&a)[M], const double (&
 // to addresses 128 bytes apart: two sets of banks for the whole wave, a 32-way conflict on every ds_write_b128
 // (SQ_LDS_BANK_CONFLICT: 58 % of the LDS-busy cycles of the spd forward kernel).  STRIDE = TPAD = 18 (144 bytes, still
 // 16-byte aligned) puts the sixteen rows of a group on sixteen different sets of four banks; the transposed read
-// (sixteen consecutive doubles of one row) is conflict-free either way.  A group's buffer is then N * TPAD doubles.
+// (sixteen consecutive doubles of one row) is conflict-free either way.  A group's buffer is TBUF doubles.
 constexpr int TPAD = 18;
-template <int M, int STRIDE = N>
+// doubles of LDS per group for transpose_rows.  The extra 128 (sixteen lanes per pair) / 16 (eight) bytes shift neighbouring
+// groups onto complementary banks for the transposed read / the chunk write.
+constexpr int TBUF = N * TPAD + (GROUP == 16 ? 16 : 2);
+template <int M, int STRIDE = TPAD>
 __device__ __forceinline__ void transpose_rows(const double (&y)[M], double (&m)[M], double* __restrict__ tbuf, const int r) {
     wave_lds_fence();
     sfor<0, M>([&](auto J) { tbuf[r * STRIDE + J] = y[J]; });
@@ -325,14 +328,14 @@ __device__ __forceinline__ void scatter_plane(const double (&v)[M], double* __re
 }
 
 // First half of a round: rows x (of X) and y (of Y) of my pair in; Cholesky factor (x, rd) and the rows m of
-// W^T = L^-1 (Y - X) out.  `tbuf` = N * TPAD doubles of LDS private to my group for the transpose.  Returns "X is PD".
+// W^T = L^-1 (Y - X) out.  `tbuf` = TBUF doubles of LDS private to my group for the transpose.  Returns "X is PD".
 template <int M>
 __device__ __forceinline__ bool reduce_pair_front(double (&x)[M], double (&y)[M], double& rdl, double (&m)[M],
                                                   double* __restrict__ tbuf, const int r) {
     sfor<0, M>([&](auto J) { y[J] -= x[J]; });      // A = Y - X
     const bool pd = ldl_rows(x, rdl);
     solve_right_unit(y, x);                          // B = A Lh^-T     (W = B D^-1/2)
-    transpose_rows<M, TPAD>(y, m, tbuf, r);
+    transpose_rows(y, m, tbuf, r);
     sfor<0, M>([&](auto J) { m[J] *= rdl; });        // row j of W^T = column j of B / L[j][j]
     return pd;
 }

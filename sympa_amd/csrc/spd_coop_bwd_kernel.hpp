@@ -55,10 +55,10 @@ void launch_spd_coop_bwd_lo(const SpdBwdArgs& a, int n, dim3 grid, hipStream_t s
 template <int M>
 __global__ __launch_bounds__(64, spd_coop_bwd_waves<M>()) void spd_coop_bwd_kernel(const SpdBwdArgs a, const int rounds) {
     using namespace spd_coop;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * TBUF];
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
-    double* const tbuf = tbuf_all + g * N * N;
+    double* const tbuf = tbuf_all + g * TBUF;
     constexpr int nn = M * M;
     double sc = 1.0;
     bool sc_active = false;
@@ -195,12 +195,12 @@ __global__ __launch_bounds__(64, spd_coop_bwd_waves<M>()) void spd_coop_bwd_kern
 template <int M>
 __global__ __launch_bounds__(64) void spd_coop_bwd2_kernel(const SpdBwdArgs a, const int rounds) {
     using namespace spd_coop;
-    __shared__ __attribute__((aligned(16))) double tbuf_all[3 * 4 * N * N];     // per group: transposes, Z of A, Z of B
+    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * TBUF + 2 * 4 * N * N];     // per group: transposes, Z of A, Z of B
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
-    double* const tbuf = tbuf_all + g * N * N;
-    double* const zt_a = tbuf_all + (4 + g) * N * N;
-    double* const zt_b = tbuf_all + (8 + g) * N * N;
+    double* const tbuf = tbuf_all + g * TBUF;
+    double* const zt_a = tbuf_all + 4 * TBUF + g * N * N;
+    double* const zt_b = tbuf_all + 4 * TBUF + (4 + g) * N * N;
     constexpr int nn = M * M;
     double sc = 1.0;
     bool sc_active = false;

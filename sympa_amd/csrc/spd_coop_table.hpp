@@ -36,10 +36,10 @@ __global__ __launch_bounds__(64) void spd_coop_table_kernel(double* __restrict__
                                                             double* __restrict__ out, const int64_t b, const double lr,
                                                             const double wd, const double* __restrict__ clip,
                                                             const double max_norm, int32_t* __restrict__ status, const int rounds) {
-    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * N * N];
+    __shared__ __attribute__((aligned(16))) double tbuf_all[4 * TBUF];
     const int lane = threadIdx.x;
     const int grp = lane >> 4, r = lane & 15;
-    double* const tbuf = tbuf_all + grp * N * N;
+    double* const tbuf = tbuf_all + grp * TBUF;
     constexpr int nn = M * M;
     const double coef = (clip != nullptr) ? fmin(1.0, max_norm / (sqrt(clip[0]) + 1e-6)) : 1.0;
     int st = 0, nbad = 0;
