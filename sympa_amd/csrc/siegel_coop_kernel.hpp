@@ -12,9 +12,11 @@ namespace sympa_hip {
 // Small M: the working set fits 256 registers once the next round's rows are not prefetched, so two waves
 // share a SIMD and hide each other's load latency (measured per M, profiles/r02_dims_sweep.txt); larger M: one
 // 512-register wave per SIMD that prefetches the rows of round t + 1 while round t computes.
-// (upper: M <= 12 needs 230 registers; bounded, whose factors are complex: M <= 10 needs 254, M = 11 would spill)
+// (upper: M <= 12 needs 230 registers, M = 13 exactly 256, M = 14 spills 20 and is still 10 % faster than one wave per
+// SIMD, M = 15 breaks even, M = 16 loses 3 %; bounded, whose factors are complex: M <= 10 needs 254, M = 11 spills 27
+// and gains 6 %, M = 12 spills 66 and loses 9 % -- profiles/r03_coop_two_waves.txt)
 template <int MODEL, int M>
-constexpr bool coop_two_waves() { return M <= (MODEL == sympa::MODEL_UPPER ? 12 : 10); }
+constexpr bool coop_two_waves() { return M <= (MODEL == sympa::MODEL_UPPER ? 14 : 11); }
 // Pairs per wave and round / rounds per wave: 4 and 16 with sixteen lanes per pair; 8 and 8 in a unit that defines
 // SYMPA_COOP_HALF (eight lanes per pair, M <= 8; siegel_coop_half.hip: the A/B of the dims 7, 8 forward against the
 // one-pair-per-lane kernels).  Lane GROUP g + t owns pair GPW t + g of the wave in the one-pair-per-lane QL phase.

@@ -93,10 +93,18 @@ __device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t firs
 #ifndef SYMPA_FWD_BIG_BLOCKS
 #define SYMPA_FWD_BIG_BLOCKS 1
 #endif
-template <int N> constexpr int fwd_min_blocks() { return N >= 5 ? SYMPA_FWD_BIG_BLOCKS : 1; }
+// dims 6, upper: 286 registers by itself; held to 256 (two waves per SIMD, 35 registers in scratch) it measures 88.4 -> 83.7 us per
+// 262 144 pairs on the 46.6 MB table and 84.4 -> 74.4 us on an L2-resident one (profiles/r03_n6_two_waves.txt).  bounded would
+// spill 163 registers, dims 7 and 8 several hundred.
+#ifndef SYMPA_FWD_N6_WAVES
+#define SYMPA_FWD_N6_WAVES 2
+#endif
+template <int N, int MODEL> constexpr int fwd_min_blocks() {
+    return (N == 6 && MODEL == sympa::MODEL_UPPER) ? SYMPA_FWD_N6_WAVES : (N >= 5 ? SYMPA_FWD_BIG_BLOCKS : 1);
+}
 
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
-__global__ __launch_bounds__(BLOCK, fwd_min_blocks<N>()) void siegel_dist_kernel(const DistArgs a) {
+__global__ __launch_bounds__(BLOCK, (fwd_min_blocks<N, MODEL>())) void siegel_dist_kernel(const DistArgs a) {
     __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
     dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * BLOCK, lds);
 }
@@ -122,7 +130,10 @@ struct MultiArgs {
 #define SYMPA_MULTI_MIN_BLOCKS_BOUNDED4 1
 #endif
 template <int N, int MODEL>
-constexpr int multi_min_blocks() { return (N == 4 && MODEL != sympa::MODEL_UPPER) ? SYMPA_MULTI_MIN_BLOCKS_BOUNDED4 : 1; }
+constexpr int multi_min_blocks() {
+    return (N == 4 && MODEL != sympa::MODEL_UPPER) ? SYMPA_MULTI_MIN_BLOCKS_BOUNDED4
+                                                    : ((N == 6 && MODEL == sympa::MODEL_UPPER) ? SYMPA_FWD_N6_WAVES : 1);
+}
 
 template <int N, int MODEL>
 __global__ __launch_bounds__(BLOCK, (multi_min_blocks<N, MODEL>())) void siegel_dist_multi_kernel(const MultiArgs m) {
