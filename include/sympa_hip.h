@@ -334,7 +334,8 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
  * reference tree: parity unpinned).  sympa_spd_model_forward is Model.forward for that model
  * (sympa/model.py:16-41) with a [num_rows, n, n] table.  flags: 0 or SYMPA_FLAG_GENERIC.
  * 6 <= n <= 16 run the sixteen-lanes-per-pair kernel (csrc/spd_coop.hpp: one instantiation per n, lanes r >= n of a group
- * are phantoms), n <= 5 the runtime-n one-lane-per-pair kernel. */
+ * are phantoms; factorisation, solves and the first n - 10 Householder steps sixteen lanes per pair, the trailing block of at
+ * most 10 x 10 and the QL iteration one pair per lane), n <= 5 the runtime-n one-lane-per-pair kernel. */
 int sympa_spd_dist_fwd(const double* x, const double* y, int64_t b, int n, double* out, int32_t* status, int flags,
                        void* stream);
 int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
