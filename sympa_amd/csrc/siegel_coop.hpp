@@ -115,10 +115,26 @@ __device__ __forceinline__ void csolve_right_lt(double (&ar)[M], double (&ai)[M]
 
 // Complex Householder tridiagonalisation of the Hermitian H held one row per lane (hr[j] + i hi[j] = H[me][j]).
 // d_k and |b_k|^2 are group-uniform; the lane with keep = true stores them.
-template <int M>
+//
+// TB >= 2: only the first M - TB steps run here.  The TB x TB Hermitian block that is left is PARKED in the LDS, in the
+// column of the lane that keeps the pair (`park` points at that lane's column: element e of the block at park[64 e]),
+// and tridiagonalised one pair per lane after the last round (siegel_math.hpp herm_tridiagonalize): a step in this layout
+// costs ~110 wave instructions of group-uniform work next to its 12 (M - k - 1) DPP FMAs and serves four pairs, the
+// same step one pair per lane serves 64 (the hybrid of the spd forward kernel, spd_coop.hpp; there the block travels in
+// registers, here the registers are taken and the LDS is not).  Block layout: the upper triangle of Re H row by row
+// (element (i, j), i <= j, at park_slot(i, j)), then the same of Im H.
+template <int TB>
+constexpr int park_base(const int i) { return i * TB - i * (i + 1) / 2; }      // park_slot(i, j) = park_base(i) + j
+template <int TB>
+constexpr int park_slot(const int i, const int j) { return park_base<TB>(i) + j; }
+template <int TB>
+constexpr int park_doubles() { return TB * (TB + 1); }                          // per pair, both planes
+
+template <int M, int TB = 0>
 __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[M], double (&hi)[M], const int r, const bool keep,
-                                                    double (&d)[M], double (&e2)[M]) {
-    sfor<0, M - 2>([&](auto K) {
+                                                    double (&d)[M], double (&e2)[M], double* __restrict__ park = nullptr) {
+    constexpr int KS = (TB >= 2) ? M - TB : M - 2;
+    sfor<0, KS>([&](auto K) {
         constexpr int k = K;
         // my element of column k: H[me][k]; every use of the reflector broadcasts from these registers
         const double cr = settle(hr[k]), ci = settle(hi[k]);
@@ -166,13 +182,50 @@ __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[M], double (&hi
             fmac_bc<j>(hi[j], vi, qr);
         });
     });
-    const double lr = settle(hr[M - 1]), li = settle(hi[M - 1]);
-    const double dm = bcast<M - 2>(settle(hr[M - 2]));
-    const double dn = bcast<M - 1>(lr);
-    const double br = bcast<M - 2>(lr), bi = bcast<M - 2>(li);
-    d[M - 2] = keep ? dm : d[M - 2];
-    d[M - 1] = keep ? dn : d[M - 1];
-    e2[M - 2] = keep ? sympa::d_fma(br, br, bi * bi) : e2[M - 2];
+    if constexpr (TB >= 2) {
+        // Row i of the block (lane KS + i) owns slots park_base(i) + j, j >= i.  No branch per row: every lane of the block
+        // stores ALL its TB columns from its own base; what lane i writes for j < i lands in slots of the rows above it,
+        // whose owners write them with a LATER instruction (their column index is larger by park_base(i) - park_base(i') > 0),
+        // and the LDS executes a wave's stores in program order.
+        if (r >= KS && r < M) {
+            const int i = r - KS;
+            double* const row = park + 64 * (i * TB - i * (i + 1) / 2);
+            sfor<0, TB>([&](auto J) {
+                row[64 * J] = hr[KS + J];
+                row[64 * (TB * (TB + 1) / 2 + J)] = hi[KS + J];
+                // column J before column J + 1, as separate instructions: to the compiler a lane's stores go to different
+                // addresses and may be reordered or paired into one ds_write2 (measured: TB = 7 wrong without this)
+                asm volatile("" ::: "memory");
+            });
+        }
+    } else {
+        const double lr = settle(hr[M - 1]), li = settle(hi[M - 1]);
+        const double dm = bcast<M - 2>(settle(hr[M - 2]));
+        const double dn = bcast<M - 1>(lr);
+        const double br = bcast<M - 2>(lr), bi = bcast<M - 2>(li);
+        d[M - 2] = keep ? dm : d[M - 2];
+        d[M - 1] = keep ? dn : d[M - 1];
+        e2[M - 2] = keep ? sympa::d_fma(br, br, bi * bi) : e2[M - 2];
+    }
+}
+
+// The parked block of MY pair (column `lane` of the park) tridiagonalised: d[KS ..], e2[KS ..] of the pair's form.
+template <int M, int TB>
+__device__ __forceinline__ void finish_parked(const double* __restrict__ park_all, const int lane, double (&d)[M], double (&e2)[M]) {
+    sympa::Herm<TB> hb;
+    constexpr int IM = TB * (TB + 1) / 2;
+    sfor<0, TB>([&](auto I) {
+        constexpr int i = I;
+        hb.d[i] = park_all[64 * park_slot<TB>(i, i) + lane];
+        sfor<i + 1, TB>([&](auto J) {
+            constexpr int j = J;
+            hb.re[i][j] = park_all[64 * park_slot<TB>(i, j) + lane];
+            hb.im[i][j] = park_all[64 * (IM + park_slot<TB>(i, j)) + lane];
+        });
+    });
+    double aa[TB], bb[TB];
+    sympa::herm_tridiagonalize<TB>(hb, aa, bb);
+    sfor<0, TB>([&](auto I) { d[M - TB + I] = aa[I]; e2[M - TB + I] = bb[I]; });
 }
 
 }  // namespace siegel_coop

@@ -20,6 +20,23 @@ constexpr bool coop_two_waves() { return M <= (MODEL == sympa::MODEL_UPPER ? 14 
 // Pairs per wave and round / rounds per wave: 4 and 16 with sixteen lanes per pair; 8 and 8 in a unit that defines
 // SYMPA_COOP_HALF (eight lanes per pair, M <= 8; siegel_coop_half.hip: the A/B of the dims 7, 8 forward against the
 // one-pair-per-lane kernels).  Lane GROUP g + t owns pair GPW t + g of the wave in the one-pair-per-lane QL phase.
+// Size of the trailing block that is parked in the LDS and tridiagonalised one pair per lane (siegel_coop.hpp): what the
+// LDS of the occupancy allows -- 20 KB per wave at two waves per SIMD (4 x 4: 10 KB next to the 9.7 KB of the transposition
+// buffers), 40 KB at one (7 x 7: 28 KB).  Eight lanes per pair (A/B unit): none.
+#ifndef SYMPA_SIEGEL_TB_TWO_WAVES
+#define SYMPA_SIEGEL_TB_TWO_WAVES 4
+#endif
+#ifndef SYMPA_SIEGEL_TB_ONE_WAVE
+#define SYMPA_SIEGEL_TB_ONE_WAVE 7
+#endif
+// (two waves per SIMD, M = 12..14 upper: the variant with the parked block needs ~20 registers more than the one
+// without and spills 11 / 34 / 52; measured even / +11 % / +19 % slower, so those three keep all their steps in the
+// row-per-lane layout -- profiles/r03_siegel_parked_block.txt)
+template <int MODEL, int M>
+constexpr int coop_parked_block() {
+    return spd_coop::GROUP != 16 ? 0
+           : (coop_two_waves<MODEL, M>() ? (M <= 11 ? SYMPA_SIEGEL_TB_TWO_WAVES : 0) : SYMPA_SIEGEL_TB_ONE_WAVE);
+}
 constexpr int COOP_GPW = spd_coop::GROUPS_PER_WAVE;
 constexpr int COOP_ROUNDS = 64 / COOP_GPW;
 
@@ -27,7 +44,10 @@ template <int MODEL, int M>
 __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void siegel_coop_kernel(const DistArgs a) {
     constexpr bool PREFETCH = !coop_two_waves<MODEL, M>();
     using namespace siegel_coop;
+    constexpr int TB = coop_parked_block<MODEL, M>();
+    static_assert(TB == 0 || (TB >= 2 && TB <= M - 2), "parked block");
     __shared__ __attribute__((aligned(16))) double tbuf_all[COOP_GPW * spd_coop::TBUF];
+    __shared__ double park_all[TB >= 2 ? TB * (TB + 1) * 64 : 1];
     static_assert(M <= spd_coop::GROUP, "matrix rows per group");
     const int lane = threadIdx.x;
     const int g = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
@@ -116,7 +136,11 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
         gram_columns(er, ei, hr, hi);
         const bool keep = (r == t);
         ok = keep ? (pd1 && pd2) : ok;
-        tridiagonalize_rows(hr, hi, r, keep, d, e2);
+        tridiagonalize_rows<M, TB>(hr, hi, r, keep, d, e2, park_all + (spd_coop::GROUP * g + t));
+    }
+    if constexpr (TB >= 2) {
+        wave_lds_fence();
+        finish_parked<M, TB>(park_all, lane, d, e2);
     }
     // one pair per lane: eigenvalues of H = E^H E, vector-valued distance, metric
     const bool conv = sympa::tridiag_ql_lockstep<M>(d, e2);
