@@ -249,10 +249,12 @@ __device__ __forceinline__ void cholesky_rows2(double (&x)[M], double (&rdx)[M],
 }
 
 // dst <- src in the lanes of `mask` only (a wave-uniform 64-bit lane mask), one VALU instruction: the select
-// `dst = cond ? src : dst` costs two v_cndmask_b32 for a double.  The wave runs with all 64 lanes enabled wherever this
-// is used (one wave per block, no divergent exit before), so EXEC is restored to all ones.
+// `dst = cond ? src : dst` costs two v_cndmask_b32 for a double.  EXEC is narrowed to (EXEC & mask) for the one move and
+// restored from the saved copy, so the statement is correct under any EXEC it finds.
 __device__ __forceinline__ void mov_in_lanes(double& dst, const double src, const unsigned long long mask) {
-    asm volatile("s_mov_b64 exec, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "s"(mask));
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %1, %3\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(saved) : "v"(src), "s"(mask) : "scc");
 }
 
 // X = Lh D Lh^T with Lh UNIT lower triangular, right-looking, in place: after step j, register j of lane i > j holds
