@@ -94,14 +94,51 @@ class RiemannianAdam(torch.optim.Optimizer):
         x  <- retr(x, -lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps));   m is transported by the identity
     (SiegelManifold.transp returns the vector unchanged, siegel_manifold.py:142-154).  egrad2rgrad, inner and retr
     (= projx(x + u)) are HIP kernels over the table rows; the moment updates are elementwise torch ops on the device.
-    Parameters without a manifold get the ordinary Adam update.  amsgrad is not built."""
-    graph_capturable = False     # bias corrections and the step count live on the host and change every step
+    Parameters without a manifold get the ordinary Adam update.  amsgrad is not built.
+
+    The powers b1^t, b2^t live in two device words per parameter and are advanced by the step itself, so nothing the step
+    computes depends on host state that changes from call to call: the step can be captured in a hipGraph
+    (sympa_amd.train_step.GraphedTrainStep, classic mode) like RiemannianSGD's.  group["step"] still counts the host-side
+    calls, for information only."""
+    graph_capturable = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, stabilize=None):
         if amsgrad:
             raise NotImplementedError("amsgrad is not built")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, step=0))
         self._stabilize = stabilize
+
+    def _init_param_state(self, p):
+        state = self.state[p]
+        if state:
+            return state
+        manifold = getattr(p, "manifold", None)
+        siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
+        state["exp_avg"] = torch.zeros_like(p)
+        state["exp_avg_sq"] = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device) if siegel else torch.zeros_like(p)
+        state["b1_pow"] = torch.ones((), dtype=torch.float64, device=p.device)
+        state["b2_pow"] = torch.ones((), dtype=torch.float64, device=p.device)
+        return state
+
+    def init_state(self):
+        """Creates the moment buffers and the power words of every parameter (normally done by the first step)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.requires_grad:
+                    self._init_param_state(p)
+
+    def snapshot_state(self):
+        """Copies of every state tensor and step count: GraphedTrainStep's warm-up steps (lr = 0) must not count."""
+        return ([g["step"] for g in self.param_groups],
+                {p: {k: v.clone() for k, v in st.items()} for p, st in self.state.items()})
+
+    def restore_state(self, snap):
+        steps, states = snap
+        for g, n in zip(self.param_groups, steps):
+            g["step"] = n
+        for p, st in states.items():
+            for k, v in st.items():
+                self.state[p][k].copy_(v)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -113,24 +150,21 @@ class RiemannianAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
             group["step"] += 1
-            bc1 = 1.0 - b1 ** group["step"]
-            bc2 = 1.0 - b2 ** group["step"]
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                state = self.state[p]
                 manifold = getattr(p, "manifold", None)
                 siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
                 if isinstance(manifold, SymmetricPositiveDefinite):
                     raise NotImplementedError("RiemannianAdam on the spd model needs geoopt's parallel transport: use rsgd")
-                if not state:
-                    state["exp_avg"] = torch.zeros_like(p)
-                    state["exp_avg_sq"] = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device) if siegel \
-                        else torch.zeros_like(p)
+                state = self._init_param_state(p)
                 g = p.grad
                 if wd != 0:
                     g = g.add(p, alpha=wd)
                 m, v = state["exp_avg"], state["exp_avg_sq"]
+                # bias corrections 1 - b^t from the device words (t = number of steps this parameter has taken)
+                bc1 = state["b1_pow"].mul_(b1).neg().add_(1.0).to(p.dtype)
+                bc2 = state["b2_pow"].mul_(b2).neg().add_(1.0).to(p.dtype)
                 if siegel:
                     g = ops.egrad2rgrad(p.data, g, manifold.model_name)
                     m.mul_(b1).add_(g, alpha=1.0 - b1)

@@ -26,10 +26,12 @@ class GraphedTrainStep:
     def __init__(self, model, optimizer, batch_size, max_grad_norm, device, deterministic=False, accumulate_loss=False,
                  two_kernels=True):
         # the capture bakes every host-side scalar of the optimiser's step in as an immediate: only optimisers whose step has
-        # no host state that changes from step to step may be captured (RiemannianAdam's bias corrections and step count do)
+        # no host state that changes from step to step may be captured (sympa_amd.optim.RiemannianSGD; RiemannianAdam keeps
+        # its powers b^t in device words for this reason).  An optimiser with moments also provides init_state /
+        # snapshot_state / restore_state, so that the warm-up steps of the capture do not count.
         if not getattr(optimizer, "graph_capturable", False):
             raise TypeError(f"{type(optimizer).__name__} cannot be captured in a hipGraph (its step() changes host-side state "
-                            "every call); use sympa_amd.optim.RiemannianSGD or run the step eagerly")
+                            "every call); use sympa_amd.optim.RiemannianSGD / RiemannianAdam or run the step eagerly")
         self.model, self.opt = model, optimizer
         self.batch_size, self.max_grad_norm = int(batch_size), float(max_grad_norm)
         self.device = torch.device(device)
@@ -233,6 +235,10 @@ class GraphedTrainStep:
         # warm-up outside the capture with lr = 0: allocates the status words / workspaces and leaves the parameters where
         # they are (retr(x, 0) = projx(x), the identity for points on the manifold); every group gets its own lr back
         saved = [g["lr"] for g in self.opt.param_groups]
+        snap = None
+        if hasattr(self.opt, "snapshot_state"):         # moments and step counts: the warm-up steps must leave no trace
+            self.opt.init_state()
+            snap = self.opt.snapshot_state()
         saved_loss = self.loss.clone()
         saved_counter = self.counter.clone()
         for g in self.opt.param_groups:
@@ -246,6 +252,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         for g, lr in zip(self.opt.param_groups, saved):
             g["lr"] = lr
+        if snap is not None:
+            self.opt.restore_state(snap)
         self.loss.copy_(saved_loss)
         self.counter.copy_(saved_counter)
         # after the warm-up every buffer exists: from here on one foreach launch zeroes them all (classic mode)

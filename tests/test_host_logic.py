@@ -248,3 +248,34 @@ def test_sorted_slots_lists_of_the_deterministic_gradient_accumulation():
             assert seg == [k for k in range(2 * b) if int(keys[s, k]) == r]      # exactly the slots of row r, in batch order
     o1, p1 = ops.sorted_slots(keys[0], rows)                                      # a single batch as a 1-d list
     assert torch.equal(o1[0], order[0]) and torch.equal(p1[0], rowptr[0])
+
+
+def test_riemannian_adam_plain_parameters_match_torch_adam_and_state_snapshot():
+    """sympa_amd.optim.RiemannianAdam keeps b1^t, b2^t in tensors advanced by the step (so that the step can be captured in a
+    hipGraph); on parameters without a manifold it is the ordinary Adam: same trajectory as torch.optim.Adam.  snapshot_state /
+    restore_state undo steps exactly (GraphedTrainStep's warm-up)."""
+    import torch
+    from sympa_amd.optim import RiemannianAdam
+    g = torch.Generator().manual_seed(5)
+    w0 = torch.randn(7, 3, generator=g, dtype=torch.float64)
+    a = torch.nn.Parameter(w0.clone())
+    b = torch.nn.Parameter(w0.clone())
+    ours = RiemannianAdam([a], lr=0.05, eps=1e-7)
+    ref = torch.optim.Adam([b], lr=0.05, eps=1e-7)
+    ours.init_state()
+    snap = ours.snapshot_state()
+    a.grad = torch.ones_like(a)
+    ours.step()
+    ours.step()                         # two warm-up steps ...
+    with torch.no_grad():
+        a.copy_(w0)
+    ours.restore_state(snap)            # ... leave no trace
+    assert ours.param_groups[0]["step"] == 0 and float(ours.state[a]["b1_pow"]) == 1.0
+    for it in range(6):
+        grad = torch.randn(7, 3, generator=g, dtype=torch.float64)
+        a.grad = grad.clone()
+        b.grad = grad.clone()
+        ours.step()
+        ref.step()
+        assert torch.allclose(a.detach(), b.detach(), rtol=1e-12, atol=1e-14), it
+    assert abs(float(ours.state[a]["b1_pow"]) - 0.9 ** 6) < 1e-15

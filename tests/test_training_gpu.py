@@ -94,6 +94,38 @@ def test_riemannian_adam_trains():
     assert ok, reason
 
 
+@pytest.mark.parametrize("manifold", ["upper", "bounded"])
+def test_riemannian_adam_step_captured_in_a_graph(manifold):
+    """`--optim radam` under GraphedTrainStep (classic mode): the bias corrections come from device words the step itself
+    advances, the warm-up steps of the capture leave no trace in the moments, and K replays equal K eager steps."""
+    from sympa_amd import data
+    from sympa_amd.optim import RiemannianAdam
+    from sympa_amd.train_step import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    nodes, b = 300, 2048
+    ma = _toy_model(manifold, "riem", 3, nodes, dev)
+    mb = _toy_model(manifold, "riem", 3, nodes, dev)
+    oa = RiemannianAdam(ma.parameters(), lr=0.02, eps=1e-7, stabilize=None)
+    ob = RiemannianAdam(mb.parameters(), lr=0.02, eps=1e-7, stabilize=None)
+    stepper = GraphedTrainStep(ma, oa, b, 50.0, dev)
+    assert stepper.mode == "classic"
+    g = torch.Generator().manual_seed(9)
+    for it in range(5):
+        ids = data.sample_pairs(nodes, b, it, 1).to(dev)
+        gd = (torch.rand(b, generator=g, dtype=torch.float64) * 5 + 1).to(dev)
+        stepper(ids[:, :2], gd)
+        ob.zero_grad(set_to_none=False)
+        mb.fused_loss_backward(ids[:, :2].contiguous(), gd)
+        torch.nn.utils.clip_grad_norm_(mb.parameters(), 50.0)
+        ob.step()
+        ta, tb = ma.embeddings.embeds.detach(), mb.embeddings.embeds.detach()
+        assert float((ta - tb).abs().max()) < 1e-11 * float(tb.abs().max()), (manifold, it)
+        assert abs(float(ma.scale.detach()) - float(mb.scale.detach())) < 1e-12
+    sa, sb = oa.state[ma.embeddings.embeds], ob.state[mb.embeddings.embeds]
+    assert abs(float(sa["b1_pow"]) - 0.9 ** 5) < 1e-14 and abs(float(sb["b1_pow"]) - 0.9 ** 5) < 1e-14
+    assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) < 1e-12 * float(sb["exp_avg"].abs().max())
+
+
 @pytest.mark.parametrize("manifold,dims", [("upper", 10), ("bounded", 9), ("spd", 16)])
 def test_training_through_the_sixteen_lanes_kernels(manifold, dims):
     """dims 9..16 (Siegel) and spd n = 16 (configs[4]'s matrix size) end to end: the forward, the fused loss + backward with

@@ -52,8 +52,8 @@ def train(args, log=print):
     # single GPU: the whole step is one hipGraph replay; multi-GPU steps have an all-reduce in the middle and run eagerly
     graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev,
                                deterministic=True if args.deterministic else None, accumulate_loss=True) \
-        if (world == 1 and args.graph_step and args.grad_exchange == "none" and args.optim == "rsgd") else None
-    # (RiemannianAdam's bias corrections change every step on the host: its step is not captured)
+        if (world == 1 and args.graph_step and args.grad_exchange == "none") else None
+    # (RiemannianAdam keeps its powers b^t in device words, so its step is captured too: classic mode, one replay per step)
     # N > 1 (or --grad_exchange given): gradients live in one persistent flat buffer; the table gradient travels dense
     # (one in-place all-reduce) or as touched rows (all-gather of the 2 b per-pair rows), whichever message is smaller
     ex = None
