@@ -259,6 +259,18 @@ int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double
 int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
                     double weight_decay, double eps, int32_t* projected_count, int32_t* status, void* stream);
 
+/* One RiemannianAdam step over the whole table, in place, ONE launch (geoopt.optim.RiemannianAdam as train.py:69-70 builds it:
+ * `--optim radam`, eps = 1e-7, stabilize = None; geoopt is absent from the reference tree, the step is restated from
+ * geoopt/optim/radam.py):  g = egrad2rgrad(x, grad + weight_decay x);  exp_avg <- beta1 exp_avg + (1 - beta1) g;
+ * exp_avg_sq[row] <- beta2 exp_avg_sq[row] + (1 - beta2) inner(x, g, g);
+ * x <- projx(x - lr (exp_avg / (1 - beta1^t)) / (sqrt(exp_avg_sq / (1 - beta2^t)) + eps_adam)).
+ * exp_avg: [num_rows, 2, n, n], exp_avg_sq: [num_rows]; bias_pows: DEVICE words {beta1^t, beta2^t} of this step (the caller
+ * advances them on the device, so a captured launch never carries a step count).  dims 1..6 (one row per lane); larger
+ * tables use sympa_egrad2rgrad / sympa_tangent_sqnorm / sympa_projx. */
+int sympa_radam_step(double* table, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t num_rows, int n, int model,
+                     double lr, double beta1, double beta2, double eps_adam, double weight_decay, const double* bias_pows,
+                     double eps, int32_t* projected_count, int32_t* status, void* stream);
+
 /* The gradient clip of the reference's loop (torch.nn.utils.clip_grad_norm_, sympa/runner.py:115) folded into the step:
  * sympa_sqnorm_accum adds sum(x^2) to acc[0] (device; call it once per gradient tensor after zeroing acc), and
  * sympa_rsgd_step_clipped is sympa_rsgd_step with every gradient row scaled by

@@ -34,6 +34,7 @@ SYMBOLS = (
     "sympa_tangent_sqnorm",
     "sympa_projx",
     "sympa_rsgd_step",
+    "sympa_radam_step",
     "sympa_sqnorm_accum",
     "sympa_sgd_step_clipped",
     "sympa_rsgd_step_clipped",
@@ -175,6 +176,10 @@ def load():
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int, ctypes.c_void_p, _c_i32_p,
         _c_i32_p, ctypes.c_void_p,
     ]
+    lib.sympa_radam_step.restype = ctypes.c_int
+    lib.sympa_radam_step.argtypes = [_c_double_p, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     _c_double_p, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_rsgd_step.restype = ctypes.c_int
     lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]

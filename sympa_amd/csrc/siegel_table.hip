@@ -249,6 +249,28 @@ int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, 
                           stream);
 }
 
+int sympa_radam_step(double* table, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t num_rows, int n, int model,
+                     double lr, double beta1, double beta2, double eps_adam, double weight_decay, const double* bias_pows,
+                     double eps, int32_t* projected_count, int32_t* status, void* stream) {
+    if (num_rows < 0) return fail(SYMPA_ERR_BAD_ARG, "negative row count");
+    if (num_rows == 0) return 0;
+    if (table == nullptr || grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || bias_pows == nullptr)
+        return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
+    if (!(eps > 0.0) || !(eps_adam >= 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0, the Adam epsilon >= 0");
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0)) return fail(SYMPA_ERR_BAD_ARG, "betas must lie in [0, 1)");
+    if (num_rows > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "too many rows for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define SYMPA_RADAM_CASE(NN) case NN: return launch_radam<NN>(model, table, grad, exp_avg, exp_avg_sq, num_rows, lr, beta1, beta2, \
+                                                              eps_adam, weight_decay, bias_pows, eps, projected_count, status, s);
+    switch (n) {
+        SYMPA_RADAM_CASE(1) SYMPA_RADAM_CASE(2) SYMPA_RADAM_CASE(3) SYMPA_RADAM_CASE(4) SYMPA_RADAM_CASE(5) SYMPA_RADAM_CASE(6)
+        default: break;
+    }
+#undef SYMPA_RADAM_CASE
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "sympa_radam_step: dims 1..6 (larger tables: the separate row kernels)");
+}
+
 int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream) {
     if (count < 0) return fail(SYMPA_ERR_BAD_ARG, "negative count");
     if (count == 0) return 0;

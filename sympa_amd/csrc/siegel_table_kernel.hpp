@@ -78,6 +78,82 @@ SYMPA_UNROLL
     }
 }
 
+// One RiemannianAdam step over the rows of the table, one row per lane (geoopt.optim.RiemannianAdam as train.py:69-70 builds
+// it; restated, geoopt is absent from the reference tree):
+//     g <- egrad2rgrad(x, grad + wd x);  m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) inner(x, g, g)   (one v per row);
+//     x <- projx(x - lr (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps_adam))
+// pows: device words {b1^t, b2^t} (already advanced to this step by the caller): no host state in the kernel's arguments
+// changes from step to step, so the launch can sit in a replayed hipGraph.
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void radam_row_kernel(double* z, const double* grad, double* m, double* v, int64_t b,
+                                                          double lr, double b1, double b2, double eps_adam, double wd,
+                                                          const double* __restrict__ pows, double eps, int32_t* projected,
+                                                          int32_t* status) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < b;
+    const int64_t ii = live ? i : b - 1;      // tail lanes recompute the last row (the Jacobi loops ballot)
+    constexpr int64_t ROW = 2 * N * N;
+    sympa::CMat<N> x, g, r;
+    sympa::load_full<N>(z + ii * ROW, x);
+    sympa::load_full<N>(grad + ii * ROW, g);
+    if (wd != 0.0) {
+SYMPA_UNROLL
+        for (int a = 0; a < N; ++a)
+SYMPA_UNROLL
+            for (int c = 0; c < N; ++c) {
+                g.re[a][c] = sympa::d_fma(wd, x.re[a][c], g.re[a][c]);
+                g.im[a][c] = sympa::d_fma(wd, x.im[a][c], g.im[a][c]);
+            }
+    }
+    sympa::egrad2rgrad<N, MODEL>(x, g, r);
+    int st = 0;
+    const double s = sympa::tangent_sqnorm<N, MODEL>(x, r, st);
+    const double vn = sympa::d_fma(b2, v[ii], (1.0 - b2) * s);
+    const double bc1 = 1.0 - pows[0], bc2 = 1.0 - pows[1];
+    const double step = lr / (bc1 * (sqrt(vn / bc2) + eps_adam));
+    // m <- b1 m + (1 - b1) r (kept in g), x <- x - step m
+    sympa::load_full<N>(m + ii * ROW, g);
+SYMPA_UNROLL
+    for (int a = 0; a < N; ++a)
+SYMPA_UNROLL
+        for (int c = 0; c < N; ++c) {
+            g.re[a][c] = sympa::d_fma(b1, g.re[a][c], (1.0 - b1) * r.re[a][c]);
+            g.im[a][c] = sympa::d_fma(b1, g.im[a][c], (1.0 - b1) * r.im[a][c]);
+            x.re[a][c] = sympa::d_fma(-step, g.re[a][c], x.re[a][c]);
+            x.im[a][c] = sympa::d_fma(-step, g.im[a][c], x.im[a][c]);
+        }
+    const bool moved = sympa::projx<N, MODEL>(x, eps, st);
+    if (live) {
+        sympa::store_full<N>(m + i * ROW, g);
+        v[i] = vn;
+        sympa::store_full<N>(z + i * ROW, x);
+    }
+    const unsigned long long mm = __ballot(live && moved);
+    if (projected != nullptr && mm != 0ull && (threadIdx.x & 63) == 0) atomicAdd(projected, (int)__popcll(mm));
+    if (status != nullptr) {
+        const unsigned long long f = __ballot(live && st != 0);
+        if (f != 0ull) {
+            if (live && st != 0) atomicOr(&status[0], st);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&status[1], (int)__popcll(f));
+        }
+    }
+}
+
+template <int N>
+int launch_radam(int model, double* z, const double* grad, double* m, double* v, int64_t b, double lr, double b1, double b2,
+                 double eps_adam, double wd, const double* pows, double eps, int32_t* projected, int32_t* status, hipStream_t s) {
+    const unsigned grid = (unsigned)((b + BLOCK - 1) / BLOCK);
+    if (model == SYMPA_MODEL_UPPER)
+        hipLaunchKernelGGL((radam_row_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, z, grad, m, v, b, lr, b1, b2,
+                           eps_adam, wd, pows, eps, projected, status);
+    else
+        hipLaunchKernelGGL((radam_row_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, z, grad, m, v, b, lr, b1, b2,
+                           eps_adam, wd, pows, eps, projected, status);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The optimiser side of one training step as ONE kernel (runner.py:113-118: clip_grad_norm_, optimizer.step, zero_grad):
 //   phase 1  every block writes the sum of squares of its rows' gradients to partial[blockIdx]; block 0 adds the plain

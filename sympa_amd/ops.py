@@ -573,6 +573,32 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None,
     return table
 
 
+RADAM_FUSED_MAX_DIMS = 6
+
+
+def radam_step_(table, grad, exp_avg, exp_avg_sq, bias_pows, model, lr, betas=(0.9, 0.999), eps_adam=1e-8, weight_decay=0.0,
+                eps=None, counter=None):
+    """In-place RiemannianAdam step over the whole table as ONE kernel (C-ABI sympa_radam_step, dims <= 6): table / grad /
+    exp_avg [N,2,n,n], exp_avg_sq [N], bias_pows = device tensor (beta1^t, beta2^t) of this step."""
+    lib = _lib.load()
+    _need_gpu(table, "table")
+    grad = _rows(grad.detach(), "grad")
+    for name, t, shape in (("table", table, grad.shape), ("exp_avg", exp_avg, grad.shape), ("exp_avg_sq", exp_avg_sq, grad.shape[:1]),
+                           ("bias_pows", bias_pows, (2,))):
+        if t.dtype != torch.float64 or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != table.device:
+            raise ValueError(f"{name} must be a contiguous float64 tensor of shape {tuple(shape)} on {table.device}, got "
+                             f"{tuple(t.shape)} {t.dtype} on {t.device}")
+    eps = EPS[torch.float64] if eps is None else float(eps)
+    st = _status_buf(table.device)
+    with torch.cuda.device(table.device):
+        rc = lib.sympa_radam_step(table.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), table.shape[0],
+                                  table.shape[2], MODEL_IDS[model], float(lr), float(betas[0]), float(betas[1]), float(eps_adam),
+                                  float(weight_decay), bias_pows.data_ptr(), eps,
+                                  None if counter is None else counter.data_ptr(), st.data_ptr(), _stream())
+    _lib.check(rc)
+    return table
+
+
 def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper", metric="riem", weights=None,
                          grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, grad_table=None,
                          grad_rows=None, step_counter=None, wave_partials=None, eps=None, flags=0):

@@ -108,7 +108,7 @@ class RiemannianAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, step=0))
         self._stabilize = stabilize
 
-    def _init_param_state(self, p):
+    def _init_param_state(self, p, betas):
         state = self.state[p]
         if state:
             return state
@@ -116,8 +116,9 @@ class RiemannianAdam(torch.optim.Optimizer):
         siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
         state["exp_avg"] = torch.zeros_like(p)
         state["exp_avg_sq"] = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device) if siegel else torch.zeros_like(p)
-        state["b1_pow"] = torch.ones((), dtype=torch.float64, device=p.device)
-        state["b2_pow"] = torch.ones((), dtype=torch.float64, device=p.device)
+        state["bias_pows"] = torch.ones(2, dtype=torch.float64, device=p.device)      # (b1^t, b2^t), advanced by the step
+        state["b1_pow"], state["b2_pow"] = state["bias_pows"][0], state["bias_pows"][1]   # views
+        state["betas"] = torch.tensor([float(betas[0]), float(betas[1])], dtype=torch.float64, device=p.device)
         return state
 
     def init_state(self):
@@ -125,7 +126,7 @@ class RiemannianAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 if p.requires_grad:
-                    self._init_param_state(p)
+                    self._init_param_state(p, group["betas"])
 
     def snapshot_state(self):
         """Copies of every state tensor and step count: GraphedTrainStep's warm-up steps (lr = 0) must not count."""
@@ -157,14 +158,19 @@ class RiemannianAdam(torch.optim.Optimizer):
                 siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
                 if isinstance(manifold, SymmetricPositiveDefinite):
                     raise NotImplementedError("RiemannianAdam on the spd model needs geoopt's parallel transport: use rsgd")
-                state = self._init_param_state(p)
+                state = self._init_param_state(p, (b1, b2))
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                pows = state["bias_pows"].mul_(state["betas"])      # (b1^t, b2^t), t = steps this parameter has taken: one launch
+                if siegel and p.shape[2] <= ops.RADAM_FUSED_MAX_DIMS and p.data.is_contiguous() and p.dtype == torch.float64:
+                    # the whole row update in one kernel (C-ABI sympa_radam_step); the powers were advanced just above
+                    ops.radam_step_(p.data, p.grad, m, v, state["bias_pows"], manifold.model_name, lr, (b1, b2), eps, wd,
+                                    counter=manifold.projected_counter(p.device))
+                    continue
                 g = p.grad
                 if wd != 0:
                     g = g.add(p, alpha=wd)
-                m, v = state["exp_avg"], state["exp_avg_sq"]
-                # bias corrections 1 - b^t from the device words (t = number of steps this parameter has taken)
-                bc1 = state["b1_pow"].mul_(b1).neg().add_(1.0).to(p.dtype)
-                bc2 = state["b2_pow"].mul_(b2).neg().add_(1.0).to(p.dtype)
+                bc = pows.neg().add_(1.0).to(p.dtype)               # bias corrections 1 - b^t
+                bc1, bc2 = bc[0], bc[1]
                 if siegel:
                     g = ops.egrad2rgrad(p.data, g, manifold.model_name)
                     m.mul_(b1).add_(g, alpha=1.0 - b1)

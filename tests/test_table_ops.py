@@ -206,6 +206,38 @@ def test_gpu_tangent_norm_and_riemannian_adam(dev, model, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3, 5, 6])
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_fused_radam_row_kernel_against_the_separate_kernels(dev, model, n):
+    """C-ABI sympa_radam_step (one launch per table, dims <= 6) == egrad2rgrad, moment updates, inner, projx as separate
+    kernels / torch ops (what RiemannianAdam runs for dims >= 7), three steps, with weight decay and a step large enough to
+    send rows through the projection."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(60 + n)
+    rows = 700
+    x0 = points(model, rows, n, 0.3, g).to(dev)
+    xa, xb = x0.clone(), x0.clone()
+    ma, mb = torch.zeros_like(x0), torch.zeros_like(x0)
+    va, vb = torch.zeros(rows, dtype=torch.float64, device=dev), torch.zeros(rows, dtype=torch.float64, device=dev)
+    pows = torch.ones(2, dtype=torch.float64, device=dev)
+    b1, b2, eps, wd = 0.9, 0.999, 1e-7, 0.01
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    for it, lr in enumerate((0.01, 0.3, 0.05)):
+        grad = torch.randn(rows, 2, n, n, generator=g, dtype=torch.float64)
+        grad = (0.5 * (grad + grad.transpose(-1, -2))).to(dev)
+        pows.mul_(torch.tensor([b1, b2], dtype=torch.float64, device=dev))
+        ops.radam_step_(xa, grad, ma, va, pows, model, lr, (b1, b2), eps, wd, counter=counter)
+        r = ops.egrad2rgrad(xb, grad.add(xb, alpha=wd), model)
+        mb.mul_(b1).add_(r, alpha=1 - b1)
+        vb.mul_(b2).add_(ops.tangent_sqnorm(xb, r, model), alpha=1 - b2)
+        direction = (mb / (1 - b1 ** (it + 1))) / ((vb / (1 - b2 ** (it + 1))).sqrt() + eps).view(-1, 1, 1, 1)
+        xb = ops.projx(xb.add(direction, alpha=-lr), model)
+        assert relmax(xa.cpu(), xb.cpu()) < 1e-9, (model, n, it)
+        assert relmax(ma.cpu(), mb.cpu()) < 1e-11 and relmax(va.cpu(), vb.cpu()) < 1e-11
+    ops.check_status(dev)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", list(range(7, 17)))      # every instance of the eight- (7, 8) and sixteen-lanes (9..16) row kernels
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_table_operations_dims_9_to_16(dev, model, n):
