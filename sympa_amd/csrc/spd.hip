@@ -36,8 +36,9 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
     }
 }
 
-// n = 16: sixteen lanes per pair for the O(n^3) part, one lane per pair for the QL iteration (spd_coop.hpp).
-// One wave per block, 64 pairs per wave, 16 KB of LDS.  Lane 16 g + t owns pair 4 t + g of the wave's 64.
+// n = 16: sixteen lanes per pair for the factorisation, the solves and the first six Householder steps, one lane per pair
+// for the trailing 10 x 10 block and the QL iteration (spd_coop.hpp).  One wave per block, 64 pairs per wave, 19.2 KB of LDS
+// (the 16 KB tile + 3.2 KB for the hand-over), two waves per SIMD.  Lane 16 g + t owns pair 4 t + g of the wave's 64.
 // M < 16 (6 <= n < 16, one instantiation per n): the row-per-lane routines are templates over the matrix size, lanes
 // r >= M of a group are phantoms (spd_coop.hpp), the time goes with M^2.  Rows are n*n*8 bytes then, not the 2 KB image
 // the DMA tile is made for, so each lane loads the elements of its row itself (upper triangle: (min, max)).

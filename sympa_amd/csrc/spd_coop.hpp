@@ -2,20 +2,22 @@
 //
 // One lane per pair (spd_math.hpp) needs two 16 x 16 working matrices per lane: 4 KB of scratch per lane, and the
 // kernel runs at the speed of scratch memory.  Here lane r of a group of 16 lanes owns ROW r of every matrix of its
-// pair (16 doubles = 32 VGPRs per matrix), so everything up to the tridiagonal form stays in registers:
+// pair (16 doubles = 32 VGPRs per matrix), so the O(n^3) part with many operands stays in registers:
 //
 //   - elements of another row are read with the DPP modifier row_newbcast:j -- the only DPP mode the double-precision
 //     ALU has, and exactly "lane j of my group of 16" -- fused into the FMA:  v_fmac_f64_dpp acc, x(lane j), y
 //     is one instruction for  acc += X[j][.] * y;
 //   - the symmetric matrices are staged through the LDS by whole-row DMA (global_load_lds_dwordx4: 1 KB per
 //     instruction, 16 instructions per round of 4 pairs), one round ahead of the arithmetic;
-//   - Cholesky X = L L^T (right-looking), W = (Y - X) L^-T, a transpose through the LDS, M = W^T L^-T
-//     (= L^-1 (Y - X) L^-T), Householder tridiagonalisation with the reflector of step k taken from column k (one
-//     element per lane) and broadcast from there;
-//   - d_k and e_k^2 of the tridiagonal form come out of step k as group-uniform values (every lane of the group has
-//     them): in round t lane t of the group keeps them, so after 16 rounds EVERY lane holds one complete tridiagonal
-//     matrix in registers and the wave runs the sequential part -- PWK QL (dsterf), log1p, norm -- ONE PAIR PER
-//     LANE, all 64 lanes busy.  Lane 16 g + t therefore owns pair 4 t + g of the wave's 64.
+//   - X = Lh D Lh^T (unit lower factor, right-looking), B = (Y - X) Lh^-T, a transpose through the LDS,
+//     M = D^-1/2 (B^T Lh^-T) D^-1/2 (= L^-1 (Y - X) L^-T), then the FIRST M - TB Householder steps with the reflector of
+//     step k taken from column k (one element per lane) and broadcast from there;
+//   - d_k and e_k^2 of those steps come out as group-uniform values (every lane of the group has them): in round t lane
+//     t of the group keeps them, and the TB x TB block that is left travels through the LDS into that lane's registers
+//     (round 3: a step in this layout costs ~75 instructions of group-uniform work next to its useful FMAs and serves
+//     four pairs, the same step one pair per lane serves 64).  After 16 rounds EVERY lane holds one pair's partial
+//     tridiagonal form and trailing block, and the wave runs the rest -- the block's tridiagonalisation, PWK QL
+//     (dsterf), log1p, norm -- ONE PAIR PER LANE, all 64 lanes busy.  Lane 16 g + t owns pair 4 t + g of the wave's 64.
 //
 // Same arithmetic as spd_math.hpp (same formula, same QL, same log1p), different order of summation: the two kernels
 // agree to ~1e-14 and the tests check the one against the other and both against the oracle.
