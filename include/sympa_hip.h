@@ -340,6 +340,19 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
                           void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
                           int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream);
 
+/* The same launch for `--optim radam` (train.py:69-70: geoopt.optim.RiemannianAdam, eps = 1e-7): clip, one RiemannianAdam
+ * step of the table (sympa_radam_step's formula), the ordinary Adam step of the plain parameters, zero_grad, step counter.
+ * bias_pows / extra_bias_pows[k]: device words {beta1^t, beta2^t} as the PREVIOUS step left them (1, 1 before the first):
+ * the kernel uses beta * word as this step's power and stores it back, so a replayed launch carries no step count.
+ * Same limits and workspace as sympa_rsgd_step_fused. */
+int sympa_radam_step_fused(double* table, double* grad, double* exp_avg, double* exp_avg_sq, double* bias_pows, int64_t num_rows,
+                           int n, int model, double lr, double beta1, double beta2, double eps_adam, double weight_decay,
+                           double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
+                           double* const* extra_exp_avg, double* const* extra_exp_avg_sq, double* const* extra_bias_pows,
+                           const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
+                           void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
+                           int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream);
+
 /* ---- SPD model (manifold "spd": geoopt.manifolds.SymmetricPositiveDefinite, sympa/embeddings.py:6,70-72,142) ----
  * Points are [n, n] fp64 symmetric positive definite matrices (upper triangle read), n <= 16.
  * dist = || log(x^-1/2 y x^-1/2) ||_F  (geoopt's default affine-invariant metric; geoopt is absent from the

@@ -35,6 +35,7 @@ SYMBOLS = (
     "sympa_projx",
     "sympa_rsgd_step",
     "sympa_radam_step",
+    "sympa_radam_step_fused",
     "sympa_sqnorm_accum",
     "sympa_sgd_step_clipped",
     "sympa_rsgd_step_clipped",
@@ -169,6 +170,14 @@ def load():
     lib.sympa_segment_sum_partials.argtypes = [ctypes.c_int64, ctypes.c_int]
     lib.sympa_rsgd_step_fused_workspace_bytes.restype = ctypes.c_int64
     lib.sympa_rsgd_step_fused_workspace_bytes.argtypes = [ctypes.c_int64]
+    lib.sympa_radam_step_fused.restype = ctypes.c_int
+    lib.sympa_radam_step_fused.argtypes = [
+        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, _c_double_p, ctypes.c_int,
+        ctypes.c_void_p, _c_i32_p, _c_i32_p, ctypes.c_void_p,
+    ]
     lib.sympa_rsgd_step_fused.restype = ctypes.c_int
     lib.sympa_rsgd_step_fused.argtypes = [
         _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,

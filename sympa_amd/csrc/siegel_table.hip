@@ -349,12 +349,33 @@ int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32
     return 0;
 }
 
-int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
-                          double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
-                          const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
-                          void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
-                          int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream) {
+}  // extern "C"
+
+namespace {
+struct AdamSide {       // the RiemannianAdam state sympa_radam_step_fused adds to the fused step; null: RiemannianSGD
+    double* exp_avg;
+    double* exp_avg_sq;
+    double* bias_pows;
+    double* const* extra_exp_avg;
+    double* const* extra_exp_avg_sq;
+    double* const* extra_bias_pows;
+    double beta1, beta2, eps_adam;
+};
+
+int fused_step_impl(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
+                    double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
+                    const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
+                    void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
+                    int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream, const AdamSide* adam) {
     if (num_rows <= 0 || table == nullptr || grad == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer / empty table");
+    if (adam != nullptr) {
+        if (adam->exp_avg == nullptr || adam->exp_avg_sq == nullptr || adam->bias_pows == nullptr)
+            return fail(SYMPA_ERR_BAD_ARG, "null Adam state");
+        if (!(adam->beta1 >= 0.0 && adam->beta1 < 1.0 && adam->beta2 >= 0.0 && adam->beta2 < 1.0) || !(adam->eps_adam >= 0.0))
+            return fail(SYMPA_ERR_BAD_ARG, "betas must lie in [0, 1), the Adam epsilon must be >= 0");
+        if (num_extra > 0 && (adam->extra_exp_avg == nullptr || adam->extra_exp_avg_sq == nullptr || adam->extra_bias_pows == nullptr))
+            return fail(SYMPA_ERR_BAD_ARG, "null Adam state of the plain parameters");
+    }
     if (sq_partials != nullptr && num_sq_partials < 1) return fail(SYMPA_ERR_BAD_ARG, "empty partial list");
     if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
     if (!(eps > 0.0)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
@@ -386,6 +407,15 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
     }
     a.counter = step_counter; a.projected = projected_count; a.status = status; a.zero_grads = zero_grads;
     a.sq_in = sq_partials; a.sq_in_count = num_sq_partials;
+    if (adam != nullptr) {
+        a.am = adam->exp_avg; a.av = adam->exp_avg_sq; a.apows = adam->bias_pows;
+        a.b1 = adam->beta1; a.b2 = adam->beta2; a.aeps = adam->eps_adam;
+        for (int k = 0; k < num_extra; ++k) {
+            if (adam->extra_exp_avg[k] == nullptr || adam->extra_exp_avg_sq[k] == nullptr || adam->extra_bias_pows[k] == nullptr)
+                return fail(SYMPA_ERR_BAD_ARG, "null Adam state of a plain parameter");
+            a.xam[k] = adam->extra_exp_avg[k]; a.xav[k] = adam->extra_exp_avg_sq[k]; a.xapows[k] = adam->extra_bias_pows[k];
+        }
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (n) {
         case 1: return launch_fused_step<1>(a, model, block, s);
@@ -395,6 +425,32 @@ int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, 
         case 5: return launch_fused_step<5>(a, model, block, s);
         default: return launch_fused_step<6>(a, model, block, s);
     }
+}
+}  // namespace
+
+extern "C" {
+
+int sympa_rsgd_step_fused(double* table, double* grad, int64_t num_rows, int n, int model, double lr, double weight_decay,
+                          double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
+                          const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
+                          void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
+                          int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream) {
+    return fused_step_impl(table, grad, num_rows, n, model, lr, weight_decay, eps, max_norm, zero_grads, extra_param, extra_grad,
+                           extra_count, extra_lr, extra_weight_decay, num_extra, workspace, workspace_bytes, sq_partials,
+                           num_sq_partials, step_counter, projected_count, status, stream, nullptr);
+}
+
+int sympa_radam_step_fused(double* table, double* grad, double* exp_avg, double* exp_avg_sq, double* bias_pows, int64_t num_rows,
+                           int n, int model, double lr, double beta1, double beta2, double eps_adam, double weight_decay,
+                           double eps, double max_norm, int zero_grads, double* const* extra_param, double* const* extra_grad,
+                           double* const* extra_exp_avg, double* const* extra_exp_avg_sq, double* const* extra_bias_pows,
+                           const int* extra_count, const double* extra_lr, const double* extra_weight_decay, int num_extra,
+                           void* workspace, int64_t workspace_bytes, const double* sq_partials, int num_sq_partials,
+                           int64_t* step_counter, int32_t* projected_count, int32_t* status, void* stream) {
+    const AdamSide adam{exp_avg, exp_avg_sq, bias_pows, extra_exp_avg, extra_exp_avg_sq, extra_bias_pows, beta1, beta2, eps_adam};
+    return fused_step_impl(table, grad, num_rows, n, model, lr, weight_decay, eps, max_norm, zero_grads, extra_param, extra_grad,
+                           extra_count, extra_lr, extra_weight_decay, num_extra, workspace, workspace_bytes, sq_partials,
+                           num_sq_partials, step_counter, projected_count, status, stream, &adam);
 }
 
 int64_t sympa_rsgd_step_fused_workspace_bytes(int64_t num_rows) {

@@ -84,18 +84,13 @@ SYMPA_UNROLL
 //     x <- projx(x - lr (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps_adam))
 // pows: device words {b1^t, b2^t} (already advanced to this step by the caller): no host state in the kernel's arguments
 // changes from step to step, so the launch can sit in a replayed hipGraph.
+// The row update itself.  In: x = the point, g = the (clipped) Euclidean gradient row.  Out: x = the new point, g = the new
+// first moment, returns the new second moment through vn; `moved` = projx changed the point.
 template <int N, int MODEL>
-__global__ __launch_bounds__(BLOCK) void radam_row_kernel(double* z, const double* grad, double* m, double* v, int64_t b,
-                                                          double lr, double b1, double b2, double eps_adam, double wd,
-                                                          const double* __restrict__ pows, double eps, int32_t* projected,
-                                                          int32_t* status) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = i < b;
-    const int64_t ii = live ? i : b - 1;      // tail lanes recompute the last row (the Jacobi loops ballot)
-    constexpr int64_t ROW = 2 * N * N;
-    sympa::CMat<N> x, g, r;
-    sympa::load_full<N>(z + ii * ROW, x);
-    sympa::load_full<N>(grad + ii * ROW, g);
+__device__ __forceinline__ bool radam_row_update(sympa::CMat<N>& x, sympa::CMat<N>& g, const double* __restrict__ m_row,
+                                                 const double v_old, double& vn, double lr, double b1, double b2,
+                                                 double eps_adam, double wd, double pow1, double pow2, double eps, int& st) {
+    sympa::CMat<N> r;
     if (wd != 0.0) {
 SYMPA_UNROLL
         for (int a = 0; a < N; ++a)
@@ -106,13 +101,12 @@ SYMPA_UNROLL
             }
     }
     sympa::egrad2rgrad<N, MODEL>(x, g, r);
-    int st = 0;
     const double s = sympa::tangent_sqnorm<N, MODEL>(x, r, st);
-    const double vn = sympa::d_fma(b2, v[ii], (1.0 - b2) * s);
-    const double bc1 = 1.0 - pows[0], bc2 = 1.0 - pows[1];
+    vn = sympa::d_fma(b2, v_old, (1.0 - b2) * s);
+    const double bc1 = 1.0 - pow1, bc2 = 1.0 - pow2;
     const double step = lr / (bc1 * (sqrt(vn / bc2) + eps_adam));
     // m <- b1 m + (1 - b1) r (kept in g), x <- x - step m
-    sympa::load_full<N>(m + ii * ROW, g);
+    sympa::load_full<N>(m_row, g);
 SYMPA_UNROLL
     for (int a = 0; a < N; ++a)
 SYMPA_UNROLL
@@ -122,7 +116,24 @@ SYMPA_UNROLL
             x.re[a][c] = sympa::d_fma(-step, g.re[a][c], x.re[a][c]);
             x.im[a][c] = sympa::d_fma(-step, g.im[a][c], x.im[a][c]);
         }
-    const bool moved = sympa::projx<N, MODEL>(x, eps, st);
+    return sympa::projx<N, MODEL>(x, eps, st);
+}
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(BLOCK) void radam_row_kernel(double* z, const double* grad, double* m, double* v, int64_t b,
+                                                          double lr, double b1, double b2, double eps_adam, double wd,
+                                                          const double* __restrict__ pows, double eps, int32_t* projected,
+                                                          int32_t* status) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < b;
+    const int64_t ii = live ? i : b - 1;      // tail lanes recompute the last row (the Jacobi loops ballot)
+    constexpr int64_t ROW = 2 * N * N;
+    sympa::CMat<N> x, g;
+    sympa::load_full<N>(z + ii * ROW, x);
+    sympa::load_full<N>(grad + ii * ROW, g);
+    int st = 0;
+    double vn;
+    const bool moved = radam_row_update<N, MODEL>(x, g, m + ii * ROW, v[ii], vn, lr, b1, b2, eps_adam, wd, pows[0], pows[1], eps, st);
     if (live) {
         sympa::store_full<N>(m + i * ROW, g);
         v[i] = vn;
@@ -184,12 +195,21 @@ struct FusedStepArgs {
     int zero_grads;
     const double* sq_in;               // squared-norm partials already computed by sympa_segment_sum_rows (deterministic
     int sq_in_count;                   // mode): phase 1 and the barrier are skipped, the partials are summed in index order
+    // RiemannianAdam (fused_step_kernel<.., ADAM = true>): moments of the table and of the plain parameters, the device
+    // words {b1^t, b2^t} of each (read at the start, advanced by the last block to finish), hyper-parameters
+    double* am;                        // [rows, 2, n, n]
+    double* av;                        // [rows]
+    double* apows;                     // [2]
+    double* xam[FUSED_MAX_EXTRA];
+    double* xav[FUSED_MAX_EXTRA];
+    double* xapows[FUSED_MAX_EXTRA];
+    double b1, b2, aeps;
 };
 
 // FB = threads per block: 64 while the table has at most as many 64-row groups as the chip has CUs (one wave per CU: a
 // lane-per-row load or store touches 64 cache lines per instruction, so four waves on one CU queue behind one texture
 // addresser -- 5 041 rows at n = 4: 15.5 us with 20 blocks of 256, measured), 256 above that (the barrier needs grid <= CUs).
-template <int N, int MODEL, int FB>
+template <int N, int MODEL, int FB, bool ADAM = false>
 __global__ __launch_bounds__(FB) void fused_step_kernel(const FusedStepArgs a) {
     constexpr int BLOCK = FB;
     __shared__ double red[BLOCK / 64];
@@ -269,7 +289,21 @@ SYMPA_UNROLL
 SYMPA_UNROLL
             for (int c = 0; c < N; ++c) { g.re[r][c] *= coef; g.im[r][c] *= coef; }
     }
-    const bool moved = sympa::rsgd_row<N, MODEL>(z, g, a.lr, a.wd, a.eps, st);
+    bool moved;
+    double pow1 = 0.0, pow2 = 0.0;
+    if constexpr (ADAM) {
+        // this step's powers b^t: every block reads the old words here, the last block to finish stores the new ones
+        pow1 = a.apows[0] * a.b1;
+        pow2 = a.apows[1] * a.b2;
+        double vn;
+        moved = radam_row_update<N, MODEL>(z, g, a.am + ii * ROW, a.av[ii], vn, a.lr, a.b1, a.b2, a.aeps, a.wd, pow1, pow2, a.eps, st);
+        if (live) {
+            sympa::store_full<N>(a.am + i * ROW, g);
+            a.av[i] = vn;
+        }
+    } else {
+        moved = sympa::rsgd_row<N, MODEL>(z, g, a.lr, a.wd, a.eps, st);
+    }
     if (live) {
         sympa::store_full<N>(a.table + i * ROW, z);
         if (a.zero_grads) {
@@ -282,7 +316,17 @@ SYMPA_UNROLL
         for (int k = 0; k < FUSED_MAX_EXTRA; ++k)
             if (a.xp[k] != nullptr && lane < a.xn[k]) {
                 const double p = a.xp[k][lane];
-                a.xp[k][lane] = fma(-a.xlr[k], fma(a.xwd[k], p, coef * a.xg[k][lane]), p);
+                const double gk = fma(a.xwd[k], p, coef * a.xg[k][lane]);
+                if constexpr (ADAM) {       // the ordinary Adam update of a parameter without a manifold
+                    const double q1 = a.xapows[k][0] * a.b1, q2 = a.xapows[k][1] * a.b2;
+                    const double mk = fma(a.b1, a.xam[k][lane], (1.0 - a.b1) * gk);
+                    const double vk = fma(a.b2, a.xav[k][lane], (1.0 - a.b2) * gk * gk);
+                    a.xam[k][lane] = mk;
+                    a.xav[k][lane] = vk;
+                    a.xp[k][lane] = p - a.xlr[k] * (mk / (1.0 - q1)) / (sqrt(vk / (1.0 - q2)) + a.aeps);
+                } else {
+                    a.xp[k][lane] = fma(-a.xlr[k], gk, p);
+                }
                 if (a.zero_grads) a.xg[k][lane] = 0.0;
             }
     }
@@ -295,14 +339,21 @@ SYMPA_UNROLL
             if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(f));
         }
     }
-    if ((a.max_norm > 0.0 && a.sq_in == nullptr) || a.counter != nullptr) {
-        __syncthreads();       // every wave of the block has read total_s / the partials
+    if (ADAM || (a.max_norm > 0.0 && a.sq_in == nullptr) || a.counter != nullptr) {
+        __syncthreads();       // every wave of the block has read total_s / the partials / the powers
         if (threadIdx.x == 0) {
             const unsigned done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (done == gridDim.x - 1) {
                 __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a.counter != nullptr) a.counter[0] += 1;
+                if constexpr (ADAM) {       // everybody has read the old powers (a block reads them before it counts itself)
+                    a.apows[0] = pow1;
+                    a.apows[1] = pow2;
+SYMPA_UNROLL
+                    for (int k = 0; k < FUSED_MAX_EXTRA; ++k)
+                        if (a.xp[k] != nullptr) { a.xapows[k][0] *= a.b1; a.xapows[k][1] *= a.b2; }
+                }
             }
         }
     }
@@ -312,7 +363,15 @@ template <int N>
 int launch_fused_step(const FusedStepArgs& a, int model, int block, hipStream_t s) {
     const unsigned grid = (unsigned)((a.rows + block - 1) / block);
     const bool up = model == SYMPA_MODEL_UPPER;
-    if (block == 64) {
+    if (a.am != nullptr) {
+        if (block == 64) {
+            if (up) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER, 64, true>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED, 64, true>), dim3(grid), dim3(64), 0, s, a);
+        } else {
+            if (up) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+            else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+        }
+    } else if (block == 64) {
         if (up) hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_UPPER, 64>), dim3(grid), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((fused_step_kernel<N, sympa::MODEL_BOUNDED, 64>), dim3(grid), dim3(64), 0, s, a);
     } else {

@@ -701,7 +701,8 @@ def segment_sum_partials(grad_table):
 
 class FusedStep:
     """clip_grad_norm_ + RiemannianSGD step of the table + plain SGD step of up to two small parameters (the scale, the
-    wsum weights) + zero_grad as ONE launch (C-ABI sympa_rsgd_step_fused; runner.py:113-118).  Built once per (table,
+    wsum weights) + zero_grad as ONE launch (C-ABI sympa_rsgd_step_fused; runner.py:113-118); with `adam`: the same for
+    RiemannianAdam / Adam (sympa_radam_step_fused).  Built once per (table,
     gradient, parameters): the pointer arrays and the zeroed workspace live here, `run()` is one ctypes call.  Raises
     SympaHipError with code SYMPA_ERR_UNSUPPORTED_DIMS when the table does not qualify (dims > 6 or more row blocks than
     CUs): the caller then keeps the separate kernels.  `supported()` tells in advance."""
@@ -713,7 +714,10 @@ class FusedStep:
         cus = torch.cuda.get_device_properties(table.device).multi_processor_count
         return (table.shape[0] + 255) // 256 <= cus
 
-    def __init__(self, table, grad, model, extras=(), counter=None, projected=None, zero_grads=True, sq_partials=None):
+    def __init__(self, table, grad, model, extras=(), counter=None, projected=None, zero_grads=True, sq_partials=None,
+                 adam=None):
+        """adam: None (RiemannianSGD) or a dict(exp_avg, exp_avg_sq, bias_pows, betas, eps, extras=[(exp_avg, exp_avg_sq,
+        bias_pows), ...]) of the RiemannianAdam state tensors (C-ABI sympa_radam_step_fused): the kernel advances the powers."""
         self.lib = _lib.load()
         _need_gpu(table, "table"); _need_gpu(grad, "grad")
         if table.dtype != torch.float64 or grad.dtype != torch.float64 or table.shape != grad.shape \
@@ -727,6 +731,24 @@ class FusedStep:
                     or not p.is_contiguous() or not g.is_contiguous():
                 raise ValueError("plain parameters: contiguous float64, 1..64 elements, gradient of the same size")
         self.keep = (table, grad, list(extras), counter, projected)
+        self.adam = None
+        if adam is not None:
+            ax = list(adam.get("extras", ()))
+            if len(ax) != len(extras):
+                raise ValueError("one (exp_avg, exp_avg_sq, bias_pows) triple per plain parameter")
+            def _chk(t, shape, what):
+                if t.dtype != torch.float64 or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != table.device:
+                    raise ValueError(f"{what} must be a contiguous float64 tensor of shape {tuple(shape)} on {table.device}")
+            _chk(adam["exp_avg"], table.shape, "exp_avg")
+            _chk(adam["exp_avg_sq"], table.shape[:1], "exp_avg_sq")
+            _chk(adam["bias_pows"], (2,), "bias_pows")
+            for (p, _), (m_, v_, w_) in zip(extras, ax):
+                _chk(m_, p.shape, "plain exp_avg"); _chk(v_, p.shape, "plain exp_avg_sq"); _chk(w_, (2,), "plain bias_pows")
+            k_ = max(len(ax), 1)
+            self.adam = dict(adam, extras=ax,
+                             xm=(ctypes.c_void_p * k_)(*[t[0].data_ptr() for t in ax]),
+                             xv=(ctypes.c_void_p * k_)(*[t[1].data_ptr() for t in ax]),
+                             xw=(ctypes.c_void_p * k_)(*[t[2].data_ptr() for t in ax]))
         self.dev = table.device
         self.model = MODEL_IDS[model]
         k = len(extras)
@@ -749,6 +771,20 @@ class FusedStep:
         xwd = (ctypes.c_double * max(self.k, 1))(*[float(x) for x in extra_weight_decay])
         if len(extra_lr) != self.k or len(extra_weight_decay) != self.k:
             raise ValueError("one learning rate and weight decay per plain parameter")
+        if self.adam is not None:
+            ad = self.adam
+            with torch.cuda.device(self.dev):
+                rc = self.lib.sympa_radam_step_fused(
+                    table.data_ptr(), grad.data_ptr(), ad["exp_avg"].data_ptr(), ad["exp_avg_sq"].data_ptr(),
+                    ad["bias_pows"].data_ptr(), table.shape[0], table.shape[2], self.model, float(lr), float(ad["betas"][0]),
+                    float(ad["betas"][1]), float(ad["eps"]), float(weight_decay), EPS[torch.float64] if eps is None else float(eps),
+                    float(max_norm) if max_norm is not None else 0.0, self.zero_grads, self.xp, self.xg, ad["xm"], ad["xv"],
+                    ad["xw"], self.xn, xlr, xwd, self.k, self.ws.data_ptr(), self.ws.numel() * 8,
+                    None if (self.sq_partials is None or max_norm is None) else self.sq_partials.data_ptr(),
+                    0 if self.sq_partials is None else self.sq_partials.numel(), None if counter is None else counter.data_ptr(),
+                    None if projected is None else projected.data_ptr(), self.status.data_ptr(), _stream())
+            _lib.check(rc)
+            return
         with torch.cuda.device(self.dev):
             rc = self.lib.sympa_rsgd_step_fused(
                 table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], self.model, float(lr),

@@ -61,12 +61,14 @@ class GraphedTrainStep:
 
     # ------------------------------------------------------------------------------------------------------------
     def _two_kernels_possible(self):
-        from sympa_amd.optim import RiemannianSGD
+        from sympa_amd.optim import RiemannianAdam, RiemannianSGD
         m = self.model
         man = m.manifold
         table = m.embeddings.embeds
-        if not isinstance(self.opt, RiemannianSGD) or getattr(man, "model_name", None) not in ("upper", "bounded"):
+        if not isinstance(self.opt, (RiemannianSGD, RiemannianAdam)) or getattr(man, "model_name", None) not in ("upper", "bounded"):
             return False
+        if isinstance(self.opt, RiemannianAdam) and len({(tuple(g["betas"]), g["eps"]) for g in self.opt.param_groups}) != 1:
+            return False            # one set of Adam hyper-parameters per launch
         if not ops.FusedStep.supported(table.data):
             return False
         extras = [p for p in self.params if p is not table]
@@ -167,9 +169,17 @@ class GraphedTrainStep:
         self.sq_partials = None
         if self.deterministic:      # the segmented sum leaves the squared-norm partials: the optimiser kernel needs no barrier
             self.sq_partials = torch.zeros(ops.segment_sum_partials(table.grad), dtype=torch.float64, device=self.device)
+        adam = None
+        if hasattr(self.opt, "snapshot_state"):         # RiemannianAdam: its state tensors go into the kernel's plan
+            self.opt.init_state()
+            st = self.opt.state
+            g0 = self.opt.param_groups[0]
+            adam = dict(exp_avg=st[table]["exp_avg"], exp_avg_sq=st[table]["exp_avg_sq"], bias_pows=st[table]["bias_pows"],
+                        betas=g0["betas"], eps=g0["eps"],
+                        extras=[(st[p]["exp_avg"], st[p]["exp_avg_sq"], st[p]["bias_pows"]) for p in self._extra_params])
         self._fused = ops.FusedStep(table.data, table.grad, man.model_name, extras, counter=self.counter,
                                     projected=man.projected_counter(table.device), zero_grads=True,
-                                    sq_partials=self.sq_partials)
+                                    sq_partials=self.sq_partials, adam=adam)
         if self.deterministic:
             n = table.shape[2]
             self.rows = torch.empty(2 * self.batch_size, 2, n, n, dtype=torch.float64, device=self.device)

@@ -107,7 +107,7 @@ def test_riemannian_adam_step_captured_in_a_graph(manifold):
     mb = _toy_model(manifold, "riem", 3, nodes, dev)
     oa = RiemannianAdam(ma.parameters(), lr=0.02, eps=1e-7, stabilize=None)
     ob = RiemannianAdam(mb.parameters(), lr=0.02, eps=1e-7, stabilize=None)
-    stepper = GraphedTrainStep(ma, oa, b, 50.0, dev)
+    stepper = GraphedTrainStep(ma, oa, b, 50.0, dev, two_kernels=False)
     assert stepper.mode == "classic"
     g = torch.Generator().manual_seed(9)
     for it in range(5):
@@ -342,6 +342,54 @@ def test_two_kernel_epoch_trains_like_the_classic_graph_and_the_deterministic_fo
         assert float((other[0] - classic[0]).abs().max()) < 1e-9
         assert abs(float(other[1] - classic[1])) < 1e-9 and abs(float(other[2] - classic[2])) < 1e-8 * abs(float(classic[2]))
     assert float((classic[0] - _toy_model("upper", "riem", n, nodes, dev).embeddings.embeds.detach()).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize("model,metric", [("upper", "riem"), ("bounded", "wsum")])
+def test_two_kernel_radam_epoch_equals_the_optimiser_called_step_by_step(model, metric):
+    """`--optim radam` through the two-kernel step (C-ABI sympa_radam_step_fused: clip + RiemannianAdam of the table + Adam of
+    the scale / the wsum weights + zero_grad + step counter in one launch, the powers b^t advanced in the kernel) == backward,
+    clip_grad_norm_ and RiemannianAdam.step() called batch by batch; the deterministic form is bitwise reproducible."""
+    from sympa_amd import ops
+    from sympa_amd.optim import RiemannianAdam
+    from sympa_amd.train_step import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    nodes, n, batch, steps = 400, 3, 1024, 6
+    g = torch.Generator().manual_seed(19)
+    trip = torch.stack((torch.randint(0, nodes, (steps * batch + 200,), generator=g),
+                        torch.randint(0, nodes, (steps * batch + 200,), generator=g),
+                        torch.randint(1, 9, (steps * batch + 200,), generator=g)), 1).to(dev)
+
+    def run(form):
+        m = _toy_model(model, metric, n, nodes, dev)
+        opt = RiemannianAdam(m.parameters(), lr=0.01, eps=1e-7, stabilize=None)
+        if form == "eager":
+            for epoch in range(2):
+                for s in range(0, trip.shape[0], batch):
+                    opt.zero_grad(set_to_none=False)
+                    m.fused_loss_backward(trip[s:s + batch, :2].contiguous(), trip[s:s + batch, 2].to(torch.float64))
+                    torch.nn.utils.clip_grad_norm_(m.parameters(), 2.0)
+                    opt.step()
+        else:
+            st = GraphedTrainStep(m, opt, batch, 2.0, dev, deterministic=form == "det", accumulate_loss=True)
+            assert st.mode == "two_kernels"
+            for epoch in range(2):
+                full = st.load_epoch(trip)
+                assert full == steps
+                st.run_steps()
+                st(trip[full * batch:, :2], trip[full * batch:, 2].to(torch.float64))      # ragged remainder
+        ops.check_status(dev)
+        pows = opt.state[m.embeddings.embeds]["bias_pows"].clone()
+        extra = [p.detach().clone() for p in m.parameters() if p is not m.embeddings.embeds]
+        return m.embeddings.embeds.detach().clone(), extra, pows
+    eager, two, det1, det2 = run("eager"), run("two"), run("det"), run("det")
+    assert torch.equal(det1[0], det2[0]) and all(torch.equal(a, b_) for a, b_ in zip(det1[1], det2[1]))
+    t = 2 * (steps + 1)
+    for other in (two, det1):
+        assert float((other[0] - eager[0]).abs().max()) < 1e-8 * float(eager[0].abs().max())
+        for a, b_ in zip(other[1], eager[1]):
+            assert float((a - b_).abs().max()) < 1e-8 * max(1.0, float(b_.abs().max()))
+        assert abs(float(other[2][0]) - 0.9 ** t) < 1e-13 and abs(float(other[2][1]) - 0.999 ** t) < 1e-13
+    assert float((eager[0] - _toy_model(model, metric, n, nodes, dev).embeddings.embeds.detach()).abs().max()) > 1e-3
 
 
 def test_harness_deterministic_training_is_bitwise_reproducible():

@@ -33,6 +33,7 @@ gd = (torch.rand(b, dtype=torch.float64) * 5 + 1).to(dev)
 m1 = make()
 o1 = RiemannianAdam(m1.parameters(), lr=1e-3, eps=1e-7, stabilize=None)
 st = GraphedTrainStep(m1, o1, b, 50.0, dev)
+mode = st.mode
 for _ in range(3):
     st(ids, gd)
 torch.cuda.synchronize()
@@ -62,4 +63,4 @@ for _ in range(K):
     eager()
 torch.cuda.synchronize()
 te = (time.perf_counter() - t0) / K
-print(f"radam {model} n={n} nodes={nodes} batch={b}: graph replay {tg * 1e6:8.1f} us per training step | eager {te * 1e6:8.1f} us  ({te / tg:.2f}x)")
+print(f"radam {model} n={n} nodes={nodes} batch={b}: graph replay [{mode}] {tg * 1e6:8.1f} us per training step | eager {te * 1e6:8.1f} us  ({te / tg:.2f}x)")

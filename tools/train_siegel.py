@@ -53,7 +53,8 @@ def train(args, log=print):
     graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev,
                                deterministic=True if args.deterministic else None, accumulate_loss=True) \
         if (world == 1 and args.graph_step and args.grad_exchange == "none") else None
-    # (RiemannianAdam keeps its powers b^t in device words, so its step is captured too: classic mode, one replay per step)
+    # (RiemannianAdam keeps its powers b^t in device words, so its step is captured too -- as the same two kernels where the
+    # table qualifies: sympa_radam_step_fused)
     # N > 1 (or --grad_exchange given): gradients live in one persistent flat buffer; the table gradient travels dense
     # (one in-place all-reduce) or as touched rows (all-gather of the 2 b per-pair rows), whichever message is smaller
     ex = None
@@ -65,7 +66,7 @@ def train(args, log=print):
     # steps with an exchange in the middle run eagerly, but the optimiser side is still ONE launch where the fused kernel
     # applies (clip norm + RiemannianSGD + scale step + zero_grad on the exchanged gradient, which lives in ex's flat buffer)
     stepper = None
-    if ex is not None and args.optim == "rsgd":
+    if ex is not None:
         stepper = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev)
         if stepper.mode == "two_kernels":
             stepper._ensure_fused()          # after GradientExchange: p.grad are views of its flat buffer
