@@ -58,6 +58,7 @@ echo "== training-path kernels (times, A/Bs, whole graphed step, soak)"
   timeout 300 python3 tools/spd_time.py 16 1048576 100000 --train 2>&1 | grep "spd n="
   timeout 300 python3 tools/table_time.py upper 45500 8 2>&1 | grep rows=
   timeout 300 python3 tools/train_step_time.py 50 2>&1 | grep "training step"
+  OPTIM=radam WORKLOADS=grid,tree,margulis,headline timeout 300 python3 tools/train_step_time.py 50 2>&1 | grep "training step"
   timeout 300 python3 tools/fuzz_coop_bwd.py 120 2>&1 | tail -1
   timeout 200 python3 tools/fuzz_coop.py 60 2>&1 | tail -1
 } | tee $OUT/training_path.txt

@@ -16,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sympa_amd import data, ops  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
-from sympa_amd.optim import RiemannianSGD  # noqa: E402
+from sympa_amd.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
 from sympa_amd.train_step import GraphedTrainStep  # noqa: E402
 from tests.helpers import spd_points  # noqa: E402
 
@@ -54,7 +54,12 @@ for name, manifold, metric, n, nodes, batch in WORKLOADS:
     ids, gd = trip[:batch, :2].contiguous(), trip[:batch, 2].to(torch.float64)
     for form in ("classic", "2k, copy", "2k, epoch", "2k, epoch, det"):
         m = fresh(manifold, metric, n, nodes)
-        opt = RiemannianSGD(m.parameters(), lr=1e-4)
+        if os.environ.get("OPTIM", "rsgd") == "radam":           # train.py:69-70
+            if manifold == "spd":
+                continue
+            opt = RiemannianAdam(m.parameters(), lr=1e-4, eps=1e-7, stabilize=None)
+        else:
+            opt = RiemannianSGD(m.parameters(), lr=1e-4)
         try:
             step = GraphedTrainStep(m, opt, batch, 50.0, dev, two_kernels=form != "classic", deterministic=form.endswith("det"),
                                     accumulate_loss=form != "classic")
@@ -82,5 +87,5 @@ for name, manifold, metric, n, nodes, batch in WORKLOADS:
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
         ops.check_status(dev)
-        print(f"{name:10s} {manifold:7s} {metric} n={n:2d} nodes={nodes:6d} batch={batch:7d} [{form:14s}]: {dt * 1e6:10.1f} us per "
+        print(f"{name:10s} {manifold:7s} {metric} n={n:2d} nodes={nodes:6d} batch={batch:7d} {type(opt).__name__[10:]:4s} [{form:14s}]: {dt * 1e6:10.1f} us per "
               f"training step  {batch / dt / 1e6:9.2f} M pairs/s trained", flush=True)
