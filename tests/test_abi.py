@@ -45,6 +45,24 @@ def test_argument_validation_without_gpu():
     assert lib.sympa_model_forward(one, 0, 4, one, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, 0, None) == -1
 
 
+def test_radam_entry_points_validate_their_arguments_without_gpu():
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)   # never dereferenced: validation happens before any launch
+    D = ctypes.c_double
+    # rows == 0 is a no-op; null state, bad betas, dims outside 1..6 are refused
+    assert lib.sympa_radam_step(one, one, one, one, 0, 4, 0, D(0.1), D(0.9), D(0.999), D(1e-7), D(0.0), one, D(1e-5), None, None, None) == 0
+    assert lib.sympa_radam_step(one, one, None, one, 8, 4, 0, D(0.1), D(0.9), D(0.999), D(1e-7), D(0.0), one, D(1e-5), None, None, None) == -1
+    assert lib.sympa_radam_step(one, one, one, one, 8, 4, 0, D(0.1), D(1.0), D(0.999), D(1e-7), D(0.0), one, D(1e-5), None, None, None) == -1
+    assert lib.sympa_radam_step(one, one, one, one, 8, 4, 7, D(0.1), D(0.9), D(0.999), D(1e-7), D(0.0), one, D(1e-5), None, None, None) == -1
+    assert lib.sympa_radam_step(one, one, one, one, 8, 7, 0, D(0.1), D(0.9), D(0.999), D(1e-7), D(0.0), one, D(1e-5), None, None, None) == -2
+    assert b"dims" in lib.sympa_last_error()
+    # the fused step: null Adam state / empty table before anything touches a device
+    assert lib.sympa_radam_step_fused(one, one, None, one, one, 8, 4, 0, D(0.1), D(0.9), D(0.999), D(1e-7), D(0.0), D(1e-5), D(1.0), 1,
+                                      None, None, None, None, None, None, None, None, 0, one, 64, None, 0, None, None, None, None) == -1
+    assert lib.sympa_radam_step_fused(one, one, one, one, one, 0, 4, 0, D(0.1), D(0.9), D(0.999), D(1e-7), D(0.0), D(1e-5), D(1.0), 1,
+                                      None, None, None, None, None, None, None, None, 0, one, 64, None, 0, None, None, None, None) == -1
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
     from sympa_amd import ops
