@@ -117,7 +117,7 @@ __device__ __forceinline__ void csolve_right_lt(double (&ar)[M], double (&ai)[M]
 // d_k and |b_k|^2 are group-uniform; the lane with keep = true stores them.
 //
 // TB >= 2: only the first M - TB steps run here.  The TB x TB Hermitian block that is left is PARKED in the LDS, in the
-// column of the lane that keeps the pair (`park` points at that lane's column: element e of the block at park[64 e]),
+// column of the lane that keeps the pair (column `keeper` of `park_all`: element e of the block at park_all[65 e + keeper]),
 // and tridiagonalised one pair per lane after the last round (siegel_math.hpp herm_tridiagonalize): a step in this layout
 // costs ~110 wave instructions of group-uniform work next to its 12 (M - k - 1) DPP FMAs and serves four pairs, the
 // same step one pair per lane serves 64 (the hybrid of the spd forward kernel, spd_coop.hpp; there the block travels in
@@ -129,10 +129,12 @@ template <int TB>
 constexpr int park_slot(const int i, const int j) { return park_base<TB>(i) + j; }
 template <int TB>
 constexpr int park_doubles() { return TB * (TB + 1); }                          // per pair, both planes
+constexpr int PARK_STRIDE = 65;     // doubles between two elements: one column per lane of the wave + a dummy one
 
 template <int M, int TB = 0>
 __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[M], double (&hi)[M], const int r, const bool keep,
-                                                    double (&d)[M], double (&e2)[M], double* __restrict__ park = nullptr) {
+                                                    double (&d)[M], double (&e2)[M], double* __restrict__ park_all = nullptr,
+                                                    const int keeper = 0) {
     constexpr int KS = (TB >= 2) ? M - TB : M - 2;
     sfor<0, KS>([&](auto K) {
         constexpr int k = K;
@@ -187,12 +189,14 @@ __device__ __forceinline__ void tridiagonalize_rows(double (&hr)[M], double (&hi
         // stores ALL its TB columns from its own base; what lane i writes for j < i lands in slots of the rows above it,
         // whose owners write them with a LATER instruction (their column index is larger by park_base(i) - park_base(i') > 0),
         // and the LDS executes a wave's stores in program order.
-        if (r >= KS && r < M) {
-            const int i = r - KS;
-            double* const row = park + 64 * (i * TB - i * (i + 1) / 2);
+        // (No branch around the stores either: the lanes outside the block store their junk into a 65th, dummy column.)
+        {
+            const bool in_block = (r >= KS && r < M);
+            const int i = in_block ? r - KS : 0;
+            double* const row = park_all + PARK_STRIDE * (i * TB - i * (i + 1) / 2) + (in_block ? keeper : 64);
             sfor<0, TB>([&](auto J) {
-                row[64 * J] = hr[KS + J];
-                row[64 * (TB * (TB + 1) / 2 + J)] = hi[KS + J];
+                row[PARK_STRIDE * J] = hr[KS + J];
+                row[PARK_STRIDE * (TB * (TB + 1) / 2 + J)] = hi[KS + J];
                 // column J before column J + 1, as separate instructions: to the compiler a lane's stores go to different
                 // addresses and may be reordered or paired into one ds_write2 (measured: TB = 7 wrong without this)
                 asm volatile("" ::: "memory");
@@ -216,11 +220,11 @@ __device__ __forceinline__ void finish_parked(const double* __restrict__ park_al
     constexpr int IM = TB * (TB + 1) / 2;
     sfor<0, TB>([&](auto I) {
         constexpr int i = I;
-        hb.d[i] = park_all[64 * park_slot<TB>(i, i) + lane];
+        hb.d[i] = park_all[PARK_STRIDE * park_slot<TB>(i, i) + lane];
         sfor<i + 1, TB>([&](auto J) {
             constexpr int j = J;
-            hb.re[i][j] = park_all[64 * park_slot<TB>(i, j) + lane];
-            hb.im[i][j] = park_all[64 * (IM + park_slot<TB>(i, j)) + lane];
+            hb.re[i][j] = park_all[PARK_STRIDE * park_slot<TB>(i, j) + lane];
+            hb.im[i][j] = park_all[PARK_STRIDE * (IM + park_slot<TB>(i, j)) + lane];
         });
     });
     double aa[TB], bb[TB];

@@ -21,21 +21,20 @@ constexpr bool coop_two_waves() { return M <= (MODEL == sympa::MODEL_UPPER ? 14 
 // SYMPA_COOP_HALF (eight lanes per pair, M <= 8; siegel_coop_half.hip: the A/B of the dims 7, 8 forward against the
 // one-pair-per-lane kernels).  Lane GROUP g + t owns pair GPW t + g of the wave in the one-pair-per-lane QL phase.
 // Size of the trailing block that is parked in the LDS and tridiagonalised one pair per lane (siegel_coop.hpp): what the
-// LDS of the occupancy allows -- 20 KB per wave at two waves per SIMD (4 x 4: 10 KB next to the 9.7 KB of the transposition
-// buffers), 40 KB at one (7 x 7: 28 KB).  Eight lanes per pair (A/B unit): none.
+// LDS of the occupancy allows -- 20 KB per wave at two waves per SIMD (4 x 4: 10.4 KB next to the 9.7 KB of the transposition
+// buffers), 40 KB at one (7 x 7: 29.1 KB).  Eight lanes per pair (A/B unit): none.
 #ifndef SYMPA_SIEGEL_TB_TWO_WAVES
 #define SYMPA_SIEGEL_TB_TWO_WAVES 4
 #endif
 #ifndef SYMPA_SIEGEL_TB_ONE_WAVE
 #define SYMPA_SIEGEL_TB_ONE_WAVE 7
 #endif
-// (two waves per SIMD, M = 12..14 upper: the variant with the parked block needs ~20 registers more than the one
-// without and spills 11 / 34 / 52; measured even / +11 % / +19 % slower, so those three keep all their steps in the
-// row-per-lane layout -- profiles/r03_siegel_parked_block.txt)
+// (The stores of the block carry no branch: with one `if (lane is in the block)` around them the two-wave variants needed
+// ~20 registers more and upper M = 12..14 spilled and lost 0-19 %; with every lane storing -- the outside lanes into a dummy
+// column -- they need FEWER registers than without the parked block: profiles/r03_siegel_parked_block.txt.)
 template <int MODEL, int M>
 constexpr int coop_parked_block() {
-    return spd_coop::GROUP != 16 ? 0
-           : (coop_two_waves<MODEL, M>() ? (M <= 11 ? SYMPA_SIEGEL_TB_TWO_WAVES : 0) : SYMPA_SIEGEL_TB_ONE_WAVE);
+    return spd_coop::GROUP != 16 ? 0 : (coop_two_waves<MODEL, M>() ? SYMPA_SIEGEL_TB_TWO_WAVES : SYMPA_SIEGEL_TB_ONE_WAVE);
 }
 constexpr int COOP_GPW = spd_coop::GROUPS_PER_WAVE;
 constexpr int COOP_ROUNDS = 64 / COOP_GPW;
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
     constexpr int TB = coop_parked_block<MODEL, M>();
     static_assert(TB == 0 || (TB >= 2 && TB <= M - 2), "parked block");
     __shared__ __attribute__((aligned(16))) double tbuf_all[COOP_GPW * spd_coop::TBUF];
-    __shared__ double park_all[TB >= 2 ? TB * (TB + 1) * 64 : 1];
+    __shared__ double park_all[TB >= 2 ? TB * (TB + 1) * siegel_coop::PARK_STRIDE : 1];
     static_assert(M <= spd_coop::GROUP, "matrix rows per group");
     const int lane = threadIdx.x;
     const int g = lane / spd_coop::GROUP, r = lane % spd_coop::GROUP;
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
         gram_columns(er, ei, hr, hi);
         const bool keep = (r == t);
         ok = keep ? (pd1 && pd2) : ok;
-        tridiagonalize_rows<M, TB>(hr, hi, r, keep, d, e2, park_all + (spd_coop::GROUP * g + t));
+        tridiagonalize_rows<M, TB>(hr, hi, r, keep, d, e2, park_all, spd_coop::GROUP * g + t);
     }
     if constexpr (TB >= 2) {
         wave_lds_fence();
