@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_
     constexpr int n = M;
     constexpr int TB = trailing_block<M>();
     __shared__ __attribute__((aligned(16))) char tile[LDS_BYTES];
-    __shared__ __attribute__((aligned(16))) double hand_all[GROUPS_PER_WAVE * (TB >= 3 ? TB * TB : 2)];
+    __shared__ __attribute__((aligned(16))) double hand_all[GROUPS_PER_WAVE * (TB >= 3 ? TB * TB : 2) + (TB >= 3 ? TB + (TB & 1) : 0)];    // + one dummy row
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
     double* const hand = hand_all + g * (TB >= 3 ? TB * TB : 2);
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_
         if constexpr (!PADDED) if (t + 1 < ROUNDS) issue(t + 1);
         const bool keep = (r == t);
         ok = keep ? pd : ok;
-        reduce_pair_back<M, TB>(m, x, rdl, r, keep, 0x0001000100010001ull << t, d, e2, hand);
+        reduce_pair_back<M, TB>(m, x, rdl, r, keep, 0x0001000100010001ull << t, d, e2, hand,
+                                hand_all + GROUPS_PER_WAVE * (TB >= 3 ? TB * TB : 2));
     }
     if constexpr (TB >= 3) {
         wave_lds_fence();

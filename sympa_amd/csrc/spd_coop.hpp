@@ -377,7 +377,8 @@ __device__ __forceinline__ void take_block(double (&blk)[packed_len<TB>()], cons
 template <int M, int TB>
 __device__ __forceinline__ void reduce_pair_back(double (&m)[M], const double (&x)[M], const double rdl,
                                                  const int r, const bool keep, const unsigned long long keepmask,
-                                                 double (&d)[M], double (&e2)[M], double* __restrict__ hand) {
+                                                 double (&d)[M], double (&e2)[M], double* __restrict__ hand,
+                                                 double* __restrict__ hand_dummy) {
     solve_right_unit(m, x);
     {
         const double rs = settle(rdl);
@@ -429,7 +430,12 @@ __device__ __forceinline__ void reduce_pair_back(double (&m)[M], const double (&
         // The keeping lane collects it (take_block) at the start of the NEXT round, behind that round's loads, so that
         // nobody waits for these 55 loads here.
         wave_lds_fence();       // the previous round's block has been collected
-        if (r >= KS && r < M) sfor<KS, M>([&](auto J) { hand[(r - KS) * TB + (J - KS)] = m[J]; });
+        // No branch around the stores (a divergent region here costs the register allocator 20-40 registers, measured on the
+        // Siegel kernels): the lanes outside the block store their junk into the dummy row `hand_dummy` (one for the wave).
+        {
+            double* const row = (r >= KS && r < M) ? hand + (r - KS) * TB : hand_dummy;
+            sfor<KS, M>([&](auto J) { row[J - KS] = m[J]; });
+        }
     } else {
         const double last = settle(m[M - 1]);
         const double dm = bcast<M - 2>(settle(m[M - 2]));
