@@ -239,18 +239,20 @@ SYMPA_UNROLL
     }
     // reductions over the wave: one atomic per wave, or (deterministic mode) the wave's sums stored for a fixed-order sum
     if (a.wave_partials != nullptr) {
+        // a wave with no live pair (the tail of the last 256-thread block) has no row in the [ceil(b / 64)][2 + n] buffer
+        const bool writer = (threadIdx.x & 63) == 0 && i < f.b;
         double* wp = a.wave_partials + (i >> 6) * (2 + N);
         double x = loss_i;
         double y = (live && !bad && sc_active) ? go * dist * f.inv_scale_coef : 0.0;
 SYMPA_UNROLL
         for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
-        if ((threadIdx.x & 63) == 0) { wp[0] = x; wp[1] = y; }
+        if (writer) { wp[0] = x; wp[1] = y; }
 SYMPA_UNROLL
         for (int k = 0; k < N; ++k) {
             double w = (live && !bad && f.metric == sympa::METRIC_WSUM) ? gw[k] : 0.0;
 SYMPA_UNROLL
             for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
-            if ((threadIdx.x & 63) == 0) wp[2 + k] = w;
+            if (writer) wp[2 + k] = w;
         }
     } else {
     if (a.gw != nullptr && f.metric == sympa::METRIC_WSUM) {

@@ -79,7 +79,9 @@ class Model(nn.Module):
         through the fused multi-batch kernel (`siegel_dist_multi_kernel`), which is what fills the chip when a batch is
         one wave per SIMD or less.  `batches` is a list of int64 [b_i, 2|3] tensors or a plan from `prepare_batches`;
         for a list the plan is built on first use and cached (keyed by the identity of the tensors, which the plan keeps
-        alive; at most 8 plans).  Returns the list of [b_i] outputs, enqueued on the current stream."""
+        alive; at most 8 plans).  Returns the list of [b_i] outputs, enqueued on the current stream.  With outs=None the
+        outputs belong to the cached plan: a second call on the SAME list object writes into the same tensors (clone what
+        must survive the next call, or pass `outs`)."""
         if isinstance(batches, (list, tuple)):
             table = self.embeddings.embeds
             key = (tuple(map(id, batches)), None if outs is None else tuple(map(id, outs)),
@@ -116,7 +118,10 @@ class Model(nn.Module):
             self.__dict__["_eval_plan"] = ev
         with torch.no_grad():
             self.forward_batches(ev[1])
-            gd = graph_distances.to(device=table.device, dtype=torch.float64)
+            # the reference hands graph distances over as [b, 1] (metrics.py:21 docstring): flatten, never broadcast
+            gd = graph_distances.to(device=table.device, dtype=torch.float64).reshape(-1)
+            if gd.numel() != total:
+                raise ValueError(f"{total} triplets but {gd.numel()} graph distances")
             return float(((ev[2] - gd).abs() / gd).sum()) / total
 
     def fused_loss_backward(self, input_triplet, graph_distances, loss_scale=1.0, loss_out=None, zero_loss_out=True):

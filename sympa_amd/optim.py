@@ -108,17 +108,33 @@ class RiemannianAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, step=0))
         self._stabilize = stabilize
 
-    def _init_param_state(self, p, betas):
+    def _init_param_state(self, p, betas, steps_taken=0):
+        """Creates whatever the state of `p` lacks (all of it on first use; `bias_pows` / `betas` when the state came from
+        a checkpoint of the format that kept the powers on the host) and keeps the device copy of the betas equal to the
+        group's: geoopt evaluates betas ** step from the live group, so a change of group["betas"] takes effect in the
+        moments AND in the bias corrections from the next step on (the powers restart from the new betas at the same t)."""
         state = self.state[p]
-        if state:
-            return state
         manifold = getattr(p, "manifold", None)
         siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
-        state["exp_avg"] = torch.zeros_like(p)
-        state["exp_avg_sq"] = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device) if siegel else torch.zeros_like(p)
-        state["bias_pows"] = torch.ones(2, dtype=torch.float64, device=p.device)      # (b1^t, b2^t), advanced by the step
-        state["b1_pow"], state["b2_pow"] = state["bias_pows"][0], state["bias_pows"][1]   # views
-        state["betas"] = torch.tensor([float(betas[0]), float(betas[1])], dtype=torch.float64, device=p.device)
+        if "exp_avg" not in state:
+            state["exp_avg"] = torch.zeros_like(p)
+        if "exp_avg_sq" not in state:
+            state["exp_avg_sq"] = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device) if siegel else torch.zeros_like(p)
+        b = (float(betas[0]), float(betas[1]))
+        if "bias_pows" not in state:                       # (b1^t, b2^t), advanced by the step itself
+            t = int(steps_taken)
+            state["bias_pows"] = torch.tensor([b[0] ** t, b[1] ** t], dtype=torch.float64, device=p.device)
+        if "betas" not in state:
+            state["betas"] = torch.tensor(b, dtype=torch.float64, device=p.device)
+            state["betas_host"] = b
+        elif state.get("betas_host") != b:
+            if "betas_host" in state or tuple(float(x) for x in state["betas"].tolist()) != b:
+                # in place: captured graphs hold these addresses.  b_new^t from b_old^t: t = log(pow) / log(b_old)
+                old = state["betas"].clone()
+                t = torch.log(state["bias_pows"]) / torch.log(old)
+                state["betas"].copy_(torch.tensor(b, dtype=torch.float64, device=p.device))
+                state["bias_pows"].copy_(torch.pow(state["betas"], torch.nan_to_num(t.round(), nan=0.0)))
+            state["betas_host"] = b
         return state
 
     def init_state(self):
@@ -126,12 +142,12 @@ class RiemannianAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 if p.requires_grad:
-                    self._init_param_state(p, group["betas"])
+                    self._init_param_state(p, group["betas"], group["step"])
 
     def snapshot_state(self):
         """Copies of every state tensor and step count: GraphedTrainStep's warm-up steps (lr = 0) must not count."""
         return ([g["step"] for g in self.param_groups],
-                {p: {k: v.clone() for k, v in st.items()} for p, st in self.state.items()})
+                {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.state.items()})
 
     def restore_state(self, snap):
         steps, states = snap
@@ -158,7 +174,7 @@ class RiemannianAdam(torch.optim.Optimizer):
                 siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
                 if isinstance(manifold, SymmetricPositiveDefinite):
                     raise NotImplementedError("RiemannianAdam on the spd model needs geoopt's parallel transport: use rsgd")
-                state = self._init_param_state(p, (b1, b2))
+                state = self._init_param_state(p, (b1, b2), group["step"] - 1)
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 pows = state["bias_pows"].mul_(state["betas"])      # (b1^t, b2^t), t = steps this parameter has taken: one launch
                 if siegel and p.shape[2] <= ops.RADAM_FUSED_MAX_DIMS and p.data.is_contiguous() and p.dtype == torch.float64:

@@ -58,6 +58,8 @@ class GraphedTrainStep:
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.steps_loaded = 0
         self._fused = None
+        self._fused_sig = None
+        self.state_ptrs = None
 
     # ------------------------------------------------------------------------------------------------------------
     def _two_kernels_possible(self):
@@ -159,7 +161,9 @@ class GraphedTrainStep:
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p.data)
-        if self.mode != "two_kernels" or self._fused is not None:
+        if self.mode != "two_kernels":
+            return
+        if self._fused is not None and self._fused_sig == self._fused_signature():
             return
         table = self.model.embeddings.embeds
         man = self.model.manifold
@@ -180,6 +184,7 @@ class GraphedTrainStep:
         self._fused = ops.FusedStep(table.data, table.grad, man.model_name, extras, counter=self.counter,
                                     projected=man.projected_counter(table.device), zero_grads=True,
                                     sq_partials=self.sq_partials, adam=adam)
+        self._fused_sig = self._fused_signature()
         if self.deterministic:
             n = table.shape[2]
             self.rows = torch.empty(2 * self.batch_size, 2, n, n, dtype=torch.float64, device=self.device)
@@ -229,13 +234,37 @@ class GraphedTrainStep:
             ops.segment_sum_rows_(table.grad, rows, order, rowptr, wave_partials=partials, num_waves=(b + 63) // 64,
                                   partial_stride=2 + n, loss=loss, grad_scale=gs, grad_weights=gw,
                                   sq_partials=self.sq_partials)
+        if b == 0:
+            return loss                 # nothing to step on (and the deterministic clip would read the last step's partials)
         self._fused_step()
+        # the fused optimiser kernel advances the device step counter that addresses the batches of a loaded epoch; an
+        # eager step is not one of them, so the window stays where run_steps left it (stream-ordered, no sync)
+        self.counter.sub_(1)
         return loss
 
     def _key(self):
-        """Everything the captured launches bake in as immediates: per-group lr and weight decay, the clip norm."""
-        return (tuple((float(g["lr"]), float(g.get("weight_decay", 0.0))) for g in self.opt.param_groups),
+        """Everything the captured launches bake in as immediates: per-group lr and weight decay, the clip norm, and (Adam)
+        betas / eps."""
+        return (tuple((float(g["lr"]), float(g.get("weight_decay", 0.0)),
+                       tuple(float(x) for x in g["betas"]) if "betas" in g else None,
+                       float(g["eps"]) if "eps" in g else None) for g in self.opt.param_groups),
                 self.max_grad_norm)
+
+    def _fused_signature(self):
+        """What the fused optimiser kernel's plan bakes in beside lr / weight decay (passed per run): the addresses of the
+        optimiser's state tensors and Adam's betas / eps."""
+        return (self._state_ptrs(), tuple((tuple(float(x) for x in g["betas"]), float(g["eps"]))
+                                          for g in self.opt.param_groups if "betas" in g))
+
+    def _state_ptrs(self):
+        """Addresses of every optimiser state tensor the captured launches / the fused kernel's plan hold (RiemannianAdam's
+        moments and power words): `opt.load_state_dict` replaces those tensors, and a replay would go on updating the
+        orphaned ones."""
+        out = []
+        for p in self.params:
+            st = self.opt.state.get(p, {})
+            out.append(tuple((k, v.data_ptr()) for k, v in sorted(st.items()) if torch.is_tensor(v)))
+        return out
 
     def _capture(self):
         if ops._debug:
@@ -280,10 +309,15 @@ class GraphedTrainStep:
         self.key = self._key()
         # the graph writes the gradients through these addresses
         self.grad_ptrs = [None if p.grad is None else p.grad.data_ptr() for p in self.params]
+        self.state_ptrs = self._state_ptrs()
 
     def _ready(self):
+        if self.graph is not None and self._state_ptrs() != self.state_ptrs:
+            # the optimiser's state tensors were replaced (load_state_dict): the graph holds the old addresses (and so
+            # does the fused kernel's plan, which _ensure_fused rebuilds on the same signature)
+            self.graph = None
         if self.graph is None or self._key() != self.key:
-            self._capture()          # learning rate / weight decay / clip norm of any group changed (end of burn-in)
+            self._capture()          # learning rate / weight decay / clip norm / betas of any group changed (end of burn-in)
         for p, ptr in zip(self.params, self.grad_ptrs):
             if (None if p.grad is None else p.grad.data_ptr()) != ptr:
                 # e.g. zero_grad(set_to_none=True) between replays: the graph would write freed memory

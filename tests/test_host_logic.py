@@ -270,7 +270,7 @@ def test_riemannian_adam_plain_parameters_match_torch_adam_and_state_snapshot():
     with torch.no_grad():
         a.copy_(w0)
     ours.restore_state(snap)            # ... leave no trace
-    assert ours.param_groups[0]["step"] == 0 and float(ours.state[a]["b1_pow"]) == 1.0
+    assert ours.param_groups[0]["step"] == 0 and float(ours.state[a]["bias_pows"][0]) == 1.0
     for it in range(6):
         grad = torch.randn(7, 3, generator=g, dtype=torch.float64)
         a.grad = grad.clone()
@@ -278,4 +278,39 @@ def test_riemannian_adam_plain_parameters_match_torch_adam_and_state_snapshot():
         ours.step()
         ref.step()
         assert torch.allclose(a.detach(), b.detach(), rtol=1e-12, atol=1e-14), it
-    assert abs(float(ours.state[a]["b1_pow"]) - 0.9 ** 6) < 1e-15
+    assert abs(float(ours.state[a]["bias_pows"][0]) - 0.9 ** 6) < 1e-15
+
+
+def test_riemannian_adam_follows_changed_betas_and_loads_the_old_state_format():
+    """Round-3 ADVICE: (i) geoopt evaluates betas ** step from the live group, so after group["betas"] changes the bias
+    corrections must use the new betas like the moments do (same trajectory as torch.optim.Adam with the same change);
+    (ii) a state dict written before the powers lived on the device (no bias_pows / betas entries) loads and steps."""
+    import torch
+    from sympa_amd.optim import RiemannianAdam
+    g = torch.Generator().manual_seed(11)
+    w0 = torch.randn(5, 2, generator=g, dtype=torch.float64)
+    a, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    ours, ref = RiemannianAdam([a], lr=0.05, eps=1e-7), torch.optim.Adam([b], lr=0.05, eps=1e-7)
+    for it in range(7):
+        if it == 3:
+            ours.param_groups[0]["betas"] = (0.8, 0.95)
+            ref.param_groups[0]["betas"] = (0.8, 0.95)
+        grad = torch.randn(5, 2, generator=g, dtype=torch.float64)
+        a.grad, b.grad = grad.clone(), grad.clone()
+        ours.step()
+        ref.step()
+        assert torch.allclose(a.detach(), b.detach(), rtol=1e-12, atol=1e-14), it
+    # old format: only the moments, powers implied by group["step"]
+    import copy
+    sd = copy.deepcopy(ours.state_dict())      # (state_dict() shares the per-parameter dicts with the optimiser)
+    for st in sd["state"].values():
+        for k in ("bias_pows", "betas", "betas_host"):
+            st.pop(k, None)
+    c = torch.nn.Parameter(a.detach().clone())
+    loaded = RiemannianAdam([c], lr=0.05, eps=1e-7)
+    loaded.load_state_dict(sd)
+    grad = torch.randn(5, 2, generator=g, dtype=torch.float64)
+    a.grad, c.grad = grad.clone(), grad.clone()
+    ours.step()
+    loaded.step()
+    assert torch.allclose(a.detach(), c.detach(), rtol=1e-12, atol=1e-14)

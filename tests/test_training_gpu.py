@@ -122,7 +122,7 @@ def test_riemannian_adam_step_captured_in_a_graph(manifold):
         assert float((ta - tb).abs().max()) < 1e-11 * float(tb.abs().max()), (manifold, it)
         assert abs(float(ma.scale.detach()) - float(mb.scale.detach())) < 1e-12
     sa, sb = oa.state[ma.embeddings.embeds], ob.state[mb.embeddings.embeds]
-    assert abs(float(sa["b1_pow"]) - 0.9 ** 5) < 1e-14 and abs(float(sb["b1_pow"]) - 0.9 ** 5) < 1e-14
+    assert abs(float(sa["bias_pows"][0]) - 0.9 ** 5) < 1e-14 and abs(float(sb["bias_pows"][0]) - 0.9 ** 5) < 1e-14
     assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) < 1e-12 * float(sb["exp_avg"].abs().max())
 
 
@@ -305,6 +305,31 @@ def test_deterministic_gradient_accumulation(model, n):
     assert float((acc - (1.0 + 0.5 * a1[0])).abs().max()) < 1e-13 * max(1.0, float(a1[0].abs().max()))
 
 
+@pytest.mark.parametrize("n", [2, 4, 6])
+@pytest.mark.parametrize("tail", [1, 65, 129, 192])
+def test_wave_partials_are_not_written_past_their_last_row(n, tail):
+    """The per-wave sums are [ceil(b / 64)][2 + n]; the last 256-thread block has up to three waves with no live pair,
+    which must not store anything (round-3 ADVICE: they wrote up to 3 (2 + n) doubles past the end).  Sentinel rows
+    after the buffer stay untouched for b % 256 in {1, 65, 129, 192}."""
+    from sympa_amd import data, ops
+    dev = torch.device("cuda:0")
+    nodes, b = 97, 512 + tail
+    g = torch.Generator().manual_seed(n * 1000 + tail)
+    table = data.trained_like_table(nodes, n, model="upper", seed=5).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b,), generator=g), torch.randint(0, nodes, (b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    waves = (b + 63) // 64
+    buf = torch.full((waves + 4, 2 + n), -777.0, dtype=torch.float64, device=dev)
+    rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    ops.model_train_backward(table, trip, gd, b, loss, "upper", "riem", None, None, None, None, 1.0, 1.0, grad_rows=rows,
+                             wave_partials=buf[:waves])
+    ops.check_status(dev)
+    torch.cuda.synchronize()
+    assert bool((buf[waves:] == -777.0).all()), buf[waves:]
+    assert bool((buf[:waves] != -777.0).all())
+
+
 def test_two_kernel_epoch_trains_like_the_classic_graph_and_the_deterministic_form_is_reproducible():
     """The two-kernel step driven by the device step counter (load_epoch + run_steps) == round 2's classic graph called
     batch by batch (tolerance: atomics); the deterministic form run twice gives bit-identical tables, scales and losses."""
@@ -390,6 +415,57 @@ def test_two_kernel_radam_epoch_equals_the_optimiser_called_step_by_step(model, 
             assert float((a - b_).abs().max()) < 1e-8 * max(1.0, float(b_.abs().max()))
         assert abs(float(other[2][0]) - 0.9 ** t) < 1e-13 and abs(float(other[2][1]) - 0.999 ** t) < 1e-13
     assert float((eager[0] - _toy_model(model, metric, n, nodes, dev).embeddings.embeds.detach()).abs().max()) > 1e-3
+
+
+def test_graphed_adam_step_follows_a_restored_optimizer_state_and_an_eager_step_leaves_the_batch_window_alone():
+    """Round-3 ADVICE: (i) `opt.load_state_dict` replaces RiemannianAdam's moment / power tensors; the replayed graph and
+    the fused kernel's plan hold their old addresses -> GraphedTrainStep must notice and rebuild, so that a resumed run
+    equals the uninterrupted one.  (ii) An eager step between `load_epoch` and the end of `run_steps` must not shift the
+    device step counter that addresses the loaded batches."""
+    import copy
+    from sympa_amd import ops
+    from sympa_amd.optim import RiemannianAdam
+    from sympa_amd.train_step import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    nodes, n, batch, steps = 300, 3, 512, 6
+    g = torch.Generator().manual_seed(23)
+    trip = torch.stack((torch.randint(0, nodes, (steps * batch,), generator=g),
+                        torch.randint(0, nodes, (steps * batch,), generator=g),
+                        torch.randint(1, 9, (steps * batch,), generator=g)), 1).to(dev)
+    extra = torch.stack((torch.randint(0, nodes, (100,), generator=g), torch.randint(0, nodes, (100,), generator=g),
+                         torch.randint(1, 9, (100,), generator=g)), 1).to(dev)
+
+    def make():
+        m = _toy_model("upper", "riem", n, nodes, dev)
+        opt = RiemannianAdam(m.parameters(), lr=0.01, eps=1e-7, stabilize=None)
+        return m, opt, GraphedTrainStep(m, opt, batch, 2.0, dev, deterministic=True)
+    # uninterrupted: 3 steps, an eager ragged batch in the middle of the window, 3 more steps
+    m1, o1, s1 = make()
+    assert s1.mode == "two_kernels"
+    s1.load_epoch(trip)
+    s1.run_steps(3)
+    s1(extra[:, :2], extra[:, 2].to(torch.float64))
+    s1.run_steps(3)
+    assert int(s1.counter) == steps
+    # the same with a checkpoint after the eager step: model + optimiser state into fresh objects, then the last 3 batches
+    m2, o2, s2 = make()
+    s2.load_epoch(trip)
+    s2.run_steps(3)
+    s2(extra[:, :2], extra[:, 2].to(torch.float64))
+    sd_m, sd_o = copy.deepcopy(m2.state_dict()), copy.deepcopy(o2.state_dict())
+    m3, o3, s3 = make()
+    s3.load_epoch(trip[:batch])
+    s3.run_steps(1)                     # a captured graph and a plan exist, holding the addresses of o3's first state
+    m3.load_state_dict(sd_m)
+    o3.load_state_dict(sd_o)            # replaces the state tensors
+    s3.load_epoch(trip[3 * batch:])
+    s3.run_steps(3)
+    ops.check_status(dev)
+    a, b_ = m1.embeddings.embeds.detach(), m3.embeddings.embeds.detach()
+    assert float((a - b_).abs().max()) < 1e-12 * float(a.abs().max())
+    t1, t3 = o1.state[m1.embeddings.embeds], o3.state[m3.embeddings.embeds]
+    assert float((t1["bias_pows"] - t3["bias_pows"]).abs().max()) < 1e-15
+    assert float((t1["exp_avg"] - t3["exp_avg"]).abs().max()) < 1e-12 * max(1e-30, float(t1["exp_avg"].abs().max()))
 
 
 def test_harness_deterministic_training_is_bitwise_reproducible():
