@@ -248,16 +248,21 @@ int sympa_tangent_sqnorm(const double* z, const double* u, int64_t b, int n, int
 /* projx: SiegelManifold.projx + UpperHalfManifold.projx (siegel_manifold.py:130-137, upper_half.py:42-66,
  * csym_math.py:252-278): symmetrise, clamp the eigenvalues of Im z at eps, rows already inside are left
  * untouched; BoundedDomainManifold.projx as intended by bounded_domain.py:55-84: clamp the Takagi values
- * at 1 - eps.  projected_count[0] += number of rows that were moved (manifold.projected_points). */
+ * at 1 - eps.  projected_count[0] += number of rows that were moved (manifold.projected_points).
+ * outside_word: caller-owned device int32 scratch word, one per call in flight (dims >= 7: the lanes-per-row kernel counts
+ * the rows that left the eps-interior in it and the exact eigenvalue clamp runs gated on that count; the library keeps no
+ * state of its own -- re-entrant across streams, devices and threads).  NULL: every row goes through the exact clamp
+ * (one row per lane; same result, slower at dims >= 7).  Ignored at dims <= 6. */
 int sympa_projx(const double* z, int64_t b, int n, int model, double eps, double* out, int32_t* projected_count,
-                int32_t* status, void* stream);
+                int32_t* status, int32_t* outside_word, void* stream);
 
 /* One RiemannianSGD step over the whole table, in place (geoopt.optim.RiemannianSGD.step with momentum 0,
  * the optimiser train.py:66-68 builds; geoopt is absent from the reference tree, semantics restated):
  *     table <- retr(table, -lr * egrad2rgrad(table, grad + weight_decay * table)),  retr(x,u) = projx(x + u)
- * (sympa/manifolds/siegel_manifold.py:74-87). */
+ * (sympa/manifolds/siegel_manifold.py:74-87).  outside_word: as in sympa_projx. */
 int sympa_rsgd_step(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
-                    double weight_decay, double eps, int32_t* projected_count, int32_t* status, void* stream);
+                    double weight_decay, double eps, int32_t* projected_count, int32_t* status, int32_t* outside_word,
+                    void* stream);
 
 /* One RiemannianAdam step over the whole table, in place, ONE launch (geoopt.optim.RiemannianAdam as train.py:69-70 builds it:
  * `--optim radam`, eps = 1e-7, stabilize = None; geoopt is absent from the reference tree, the step is restated from
@@ -283,7 +288,7 @@ int sympa_sgd_step_clipped(double* p, const double* grad, int64_t count, double 
                            const double* total_sqnorm, double max_norm, void* stream);
 int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows, int n, int model, double lr,
                             double weight_decay, double eps, const double* total_sqnorm, double max_norm,
-                            int32_t* projected_count, int32_t* status, void* stream);
+                            int32_t* projected_count, int32_t* status, int32_t* outside_word, void* stream);
 
 /* The backward half of a training step inside a replayed hipGraph (sympa/runner.py:98-105), dims 1..8.  Like
  * sympa_model_loss_backward (grad_table given: fp64-atomic scatter into the dense gradient) or

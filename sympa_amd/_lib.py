@@ -152,7 +152,7 @@ def load():
                                          _c_i32_p, ctypes.c_void_p]
     lib.sympa_projx.restype = ctypes.c_int
     lib.sympa_projx.argtypes = [_c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, _c_double_p,
-                                _c_i32_p, _c_i32_p, ctypes.c_void_p]
+                                _c_i32_p, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_model_train_backward.restype = ctypes.c_int
     lib.sympa_model_train_backward.argtypes = [
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
@@ -191,7 +191,7 @@ def load():
                                      _c_double_p, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_rsgd_step.restype = ctypes.c_int
     lib.sympa_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                    ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
+                                    ctypes.c_double, ctypes.c_double, _c_i32_p, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_sqnorm_accum.restype = ctypes.c_int
     lib.sympa_sqnorm_accum.argtypes = [_c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_void_p]
     lib.sympa_sgd_step_clipped.restype = ctypes.c_int
@@ -200,7 +200,7 @@ def load():
     lib.sympa_rsgd_step_clipped.restype = ctypes.c_int
     lib.sympa_rsgd_step_clipped.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_double_p,
-                                            ctypes.c_double, _c_i32_p, _c_i32_p, ctypes.c_void_p]
+                                            ctypes.c_double, _c_i32_p, _c_i32_p, _c_i32_p, ctypes.c_void_p]
     lib.sympa_spd_dist_fwd.restype = ctypes.c_int
     lib.sympa_spd_dist_fwd.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, _c_i32_p,
                                        ctypes.c_int, ctypes.c_void_p]

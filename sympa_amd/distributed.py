@@ -54,6 +54,11 @@ class GradientExchange:
       (sympa_scatter_add_rows, alpha = 1 / world).  Message per step: 2 B 16 n^2 bytes over all ranks (B = global
       batch) instead of N 16 n^2 per rank -- "auto" picks it when that is smaller, i.e. 2 B < N (large graphs with the
       reference's default batch sizes); for BASELINE's configs 2 B > N and the dense all-reduce is the smaller message.
+    * mode "sharded" (reduce-scatter -> sharded RSGD + projx -> all-gather): the table gradient is
+      reduce-scattered by contiguous row shards (rows padded to a multiple of the world size), every rank runs the
+      RiemannianSGD step -- egrad2rgrad, retraction and projection -- on ITS shard of the table only, and the updated rows
+      are all-gathered.  Same bytes on the links as the dense all-reduce (which is a reduce-scatter + all-gather of the
+      gradient), 1 / world of the optimiser work per GPU; the clip norm costs one 8-byte all-reduce.
     The small parameters (model scale, wsum weights) always go through the flat all-reduce."""
 
     def __init__(self, params, table=None, local_batch=0, mode="auto", group=None, scatter_fn=None):
@@ -66,29 +71,42 @@ class GradientExchange:
         n_rows = table.shape[0] if table is not None else 0
         if mode == "auto":
             mode = "rows" if (table is not None and local_batch > 0 and 2 * local_batch * self.world < n_rows) else "dense"
-        if mode not in ("dense", "rows"):
+        if mode not in ("dense", "rows", "sharded"):
             raise ValueError(mode)
         if mode == "rows" and (table is None or local_batch <= 0):
             raise ValueError("mode 'rows' needs the table parameter and the per-rank batch size")
+        if mode == "sharded" and table is None:
+            raise ValueError("mode 'sharded' needs the table parameter")
         self.mode = mode
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
+        # sharded: the table gradient comes first and is padded to world x rows_per rows (reduce_scatter_tensor wants equal
+        # blocks); the padding rows stay zero
+        pad = 0
+        if mode == "sharded":
+            self.rows_per = (n_rows + self.world - 1) // self.world
+            pad = (self.rows_per * self.world - n_rows) * table[0].numel()
+        total = sum(p.numel() for p in self.params) + pad
         self.flat = torch.zeros(total, dtype=torch.float64, device=dev)
+        order = self.params if mode != "sharded" else [table] + [p for p in self.params if p is not table]
         off = 0
-        self._views = []
-        self._small = []           # (offset, numel) of everything but the table, for the "rows" mode
-        for p in self.params:
+        views = {}
+        self._small = []           # (offset, numel) of everything but the table, for the "rows" / "sharded" modes
+        for p in order:
             if p.dtype != torch.float64:
                 raise TypeError("parameters are float64 (reference default dtype, config.py:17-18)")
             v = self.flat[off:off + p.numel()].view(p.shape)
             p.grad = v
-            self._views.append(v)
+            views[id(p)] = v
             if p is table:
                 self._table_span = (off, p.numel())
+                off += pad
             else:
                 self._small.append((off, p.numel()))
             off += p.numel()
+        self._views = [views[id(p)] for p in self.params]
         self.local_batch = int(local_batch)
+        self.small = None
         if mode == "rows":
             rowd = table[0].numel()
             b2 = 2 * self.local_batch
@@ -99,6 +117,18 @@ class GradientExchange:
             # the small parameters share one contiguous tail/head buffer for their all-reduce
             n_small = sum(k for _, k in self._small)
             self.small = torch.zeros(n_small, dtype=torch.float64, device=dev) if n_small else None
+        if mode == "sharded":
+            rowd = table[0].numel()
+            rp = self.rows_per
+            self.first_row = self.rank * rp
+            self.my_rows = max(0, min(rp, n_rows - self.first_row))          # the last shard may be short (padding)
+            self.table_grad_padded = self.flat[:self.world * rp * rowd]                        # reduce-scatter input
+            self.shard_grad = torch.zeros((rp,) + tuple(table.shape[1:]), dtype=torch.float64, device=dev)
+            self.shard_send = torch.zeros((rp,) + tuple(table.shape[1:]), dtype=torch.float64, device=dev)
+            self.table_padded = torch.zeros((self.world * rp,) + tuple(table.shape[1:]), dtype=torch.float64, device=dev)
+            # the small gradients are contiguous behind the table gradient: one all-reduce of that tail
+            self.small_tail = self.flat[self.world * rp * rowd:]
+            self.sq = torch.zeros(1, dtype=torch.float64, device=dev)
         if scatter_fn is None:
             from sympa_amd import ops
             scatter_fn = ops.scatter_add_flat_rows_     # HIP kernel; raises on CPU tensors (no CPU path in the product)
@@ -108,7 +138,7 @@ class GradientExchange:
     @property
     def message_bytes(self):
         g = self.world
-        if self.mode == "dense":
+        if self.mode in ("dense", "sharded"):     # reduce-scatter + all-gather move what the ring all-reduce moves
             return int(2 * (g - 1) / g * self.flat.numel() * 8)
         small = 0 if self.small is None else int(2 * (g - 1) / g * self.small.numel() * 8)
         return (self.rows.numel() * 8 + self.idx.numel() * 8) * (g - 1) + small
@@ -128,6 +158,75 @@ class GradientExchange:
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)
+
+    def step_after_exchange(self, opt, max_grad_norm):
+        """clip_grad_norm_ + optimizer.step() (runner.py:115-118) on the exchanged gradient (dense / rows modes): every rank
+        holds the same mean gradient and takes the same step on its replica of the table."""
+        if hasattr(opt, "clip_max_norm"):            # sympa_amd.optim.RiemannianSGD: the clip rides inside the step
+            opt.clip_max_norm = max_grad_norm
+            try:
+                opt.step()
+            finally:
+                opt.clip_max_norm = None
+        else:
+            torch.nn.utils.clip_grad_norm_(self.params, max_grad_norm)
+            opt.step()
+
+    def _reduce_scatter(self, out, inp):
+        if self.world == 1:
+            out.view(-1).copy_(inp)
+        elif dist.get_backend(self.group) == "gloo":
+            # gloo (the CPU / shared-GPU TEST backend) has no reduce-scatter: all-reduce, keep this rank's block
+            dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=self.group)
+            k = out.numel()
+            out.view(-1).copy_(inp[self.rank * k:(self.rank + 1) * k])
+        else:
+            dist.reduce_scatter_tensor(out.view(-1), inp, op=dist.ReduceOp.SUM, group=self.group)
+
+    def sharded_step(self, opt, max_grad_norm):
+        """Sharded mode, after the local backward has accumulated into the flat buffer: reduce-scatter the table gradient,
+        all-reduce the small gradients, one 8-byte all-reduce for the clip norm (clip_grad_norm_ over ALL parameters,
+        runner.py:115), RiemannianSGD (egrad2rgrad + retr + projx, one kernel) on this rank's rows, plain SGD of the small
+        parameters on every rank, all-gather of the updated rows; leaves the gradients zero.  sympa_amd.optim.RiemannianSGD
+        on a Siegel table only (the step is issued per shard, not through optimizer.step())."""
+        from sympa_amd import ops
+        from sympa_amd.manifolds.siegel_manifold import SiegelManifold
+        from sympa_amd.optim import RiemannianSGD
+        table = self.table
+        manifold = getattr(table, "manifold", None)
+        if not isinstance(opt, RiemannianSGD) or not isinstance(manifold, SiegelManifold):
+            raise TypeError("sharded_step: sympa_amd.optim.RiemannianSGD on a table of a Siegel manifold")
+        inv = 1.0 / self.world
+        self._reduce_scatter(self.shard_grad, self.table_grad_padded)
+        if self.small_tail.numel() and self.world > 1:
+            dist.all_reduce(self.small_tail, op=dist.ReduceOp.SUM, group=self.group)
+        k, r0 = self.my_rows, self.first_row
+        if inv != 1.0:                               # DDP's mean
+            self.shard_grad.mul_(inv)
+            self.small_tail.mul_(inv)
+        self.sq.zero_()
+        if k > 0:
+            ops.sqnorm_accum_(self.shard_grad[:k], self.sq)
+        if self.rank == 0 and self.small_tail.numel():
+            ops.sqnorm_accum_(self.small_tail, self.sq)
+        if self.world > 1:
+            dist.all_reduce(self.sq, op=dist.ReduceOp.SUM, group=self.group)
+        groups = {id(p): g for g in opt.param_groups for p in g["params"]}
+        tg = groups[id(table)]
+        if k > 0:
+            rows = table.data[r0:r0 + k]
+            ops.rsgd_step_(rows, self.shard_grad[:k], manifold.model_name, tg["lr"], tg.get("weight_decay", 0.0),
+                           counter=manifold.projected_counter(table.device), clip_sqnorm=self.sq, max_norm=max_grad_norm)
+            self.shard_send[:k].copy_(rows)
+        for p in self.params:
+            if p is not table:
+                g = groups[id(p)]
+                ops.sgd_step_clipped_(p.data, p.grad, g["lr"], g.get("weight_decay", 0.0), clip_sqnorm=self.sq,
+                                      max_norm=max_grad_norm)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.table_padded, self.shard_send, group=self.group)
+            table.data.copy_(self.table_padded[:table.shape[0]])
+        self.flat.zero_()
 
     def exchange_rows(self, idx_src, idx_dst):
         """Rows mode, after the local backward has written this rank's per-pair rows into `self.rows`

@@ -502,6 +502,14 @@ def tangent_sqnorm(z, u, model):
     return out
 
 
+def _outside_word(n, dev):
+    """The scratch word the dims >= 7 projection is gated on (C-ABI `outside_word`): the CALLER's, one per call in flight.
+    A fresh one-element tensor per call: the caching allocator hands it out stream-ordered on the current stream (inside a
+    hipGraph capture: from the graph's pool), so calls on different streams, devices or threads never share a word and the
+    library needs no state of its own."""
+    return torch.empty(1, dtype=torch.int32, device=dev) if n >= 7 else None
+
+
 def projx(z, model, eps=None, counter=None):
     """Returns projx(z); `counter` (int32[1] device tensor) += rows that were moved."""
     lib = _lib.load()
@@ -510,9 +518,11 @@ def projx(z, model, eps=None, counter=None):
     out = torch.empty_like(z)
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(z.device)
+    word = _outside_word(z.shape[2], z.device)
     with torch.cuda.device(z.device):
         rc = lib.sympa_projx(z.data_ptr(), z.shape[0], z.shape[2], MODEL_IDS[model], eps, out.data_ptr(),
-                             None if counter is None else counter.data_ptr(), st.data_ptr(), _stream())
+                             None if counter is None else counter.data_ptr(), st.data_ptr(),
+                             None if word is None else word.data_ptr(), _stream())
     _lib.check(rc)
     return out
 
@@ -559,16 +569,18 @@ def rsgd_step_(table, grad, model, lr, weight_decay=0.0, eps=None, counter=None,
         _gate(_sc.SIEGEL_TABLE, model, table.shape[2], table.device)
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(table.device)
+    word = _outside_word(table.shape[2], table.device)
+    wp = None if word is None else word.data_ptr()
     with torch.cuda.device(table.device):
         if clip_sqnorm is not None:
             rc = lib.sympa_rsgd_step_clipped(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2],
                                              MODEL_IDS[model], float(lr), float(weight_decay), eps,
                                              clip_sqnorm.data_ptr(), float(max_norm),
-                                             None if counter is None else counter.data_ptr(), st.data_ptr(), _stream())
+                                             None if counter is None else counter.data_ptr(), st.data_ptr(), wp, _stream())
         else:
             rc = lib.sympa_rsgd_step(table.data_ptr(), grad.data_ptr(), table.shape[0], table.shape[2], MODEL_IDS[model],
                                      float(lr), float(weight_decay), eps, None if counter is None else counter.data_ptr(),
-                                     st.data_ptr(), _stream())
+                                     st.data_ptr(), wp, _stream())
     _lib.check(rc)
     return table
 

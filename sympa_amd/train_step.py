@@ -389,5 +389,212 @@ class GraphedTrainStep:
         self.loss.zero_()
 
 
+class DistributedTrainStep:
+    """The data-parallel training step (train.py:59,105-110,136 + runner.py:98-118: every rank runs backward on its shard of
+    the global batch, the gradients are averaged, every rank takes the optimiser step) as REPLAYED GRAPHS around the
+    exchange -- the multi-GPU counterpart of GraphedTrainStep's two-kernel step, RiemannianSGD, Siegel models with dims <= 8.
+
+        graph A   sympa_model_train_backward: distances + loss + backward of batch c (device step counter; an epoch's
+                  shard is loaded once with `load_epoch`), scattered into the table-gradient view of GradientExchange's flat
+                  buffer (mode "rows": per-pair rows + the batch's row indices gathered on the device)
+        exchange  dense: ONE in-place all-reduce of the flat buffer on the same stream;  rows: all-gather of rows + indices,
+                  scatter-add;  sharded: reduce-scatter / 8-byte all-reduce / all-gather around the shard's step
+        graph B   clip + RiemannianSGD + scale / weight step + zero_grad + counter increment: sympa_rsgd_step_fused (one
+                  launch) where the table qualifies, the separate kernels otherwise
+
+    With a backend whose collectives are stream work (RCCL) the whole step is tried as ONE captured graph first
+    (`capture_collective`; `graphs_per_step` says what was achieved: 1, or 2 with the exchange enqueued between the replays);
+    the sharded mode's optimiser side runs between the graphs.  No host synchronisation anywhere in `run_steps`."""
+
+    def __init__(self, model, optimizer, batch_size, max_grad_norm, device, mode="dense", group=None, capture_collective=None,
+                 accumulate_loss=True):
+        import torch.distributed as dist
+        from sympa_amd.distributed import GradientExchange
+        from sympa_amd.optim import RiemannianSGD
+        man = model.manifold
+        table = model.embeddings.embeds
+        if getattr(man, "model_name", None) not in ("upper", "bounded") or table.shape[2] > 8:
+            raise NotImplementedError("DistributedTrainStep: Siegel models with dims <= 8 (the step-counter backward kernel); "
+                                      "other models run the eager exchange of tools/train_siegel.py")
+        if not isinstance(optimizer, RiemannianSGD):
+            raise NotImplementedError("DistributedTrainStep: sympa_amd.optim.RiemannianSGD")
+        self.model, self.opt, self.dist = model, optimizer, dist
+        self.batch_size, self.max_grad_norm = int(batch_size), float(max_grad_norm)
+        self.device = torch.device(device)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.ex = GradientExchange(self.params, table=table, local_batch=self.batch_size, mode=mode, group=group)
+        self.mode = self.ex.mode
+        self.world = self.ex.world
+        self.accumulate_loss = bool(accumulate_loss)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.arange = torch.arange(self.batch_size, dtype=torch.int64, device=device)
+        self.capacity = 0
+        self._alloc(self.batch_size)
+        self.steps_loaded = 0
+        self.replays = 0
+        self.graphs = None
+        self.key = None
+        backend = dist.get_backend(group) if (dist.is_available() and dist.is_initialized()) else None
+        self.capture_collective = (backend == "nccl") if capture_collective is None else bool(capture_collective)
+        self.graphs_per_step = None
+        # the optimiser side: one fused launch where the table qualifies (after GradientExchange: .grad are its views)
+        self._extra = [p for p in self.params if p is not table]
+        self._fused = None
+        if self.mode != "sharded" and ops.FusedStep.supported(table.data) and len(self._extra) <= 2 and \
+                all(p.numel() <= 64 for p in self._extra):
+            self._fused = ops.FusedStep(table.data, table.grad, man.model_name, [(p.data, p.grad) for p in self._extra],
+                                        counter=self.counter, projected=man.projected_counter(table.device), zero_grads=True)
+
+    def _alloc(self, pairs):
+        self.capacity = int(pairs)
+        self.ids = torch.zeros(self.capacity, 2, dtype=torch.int64, device=self.device)
+        self.gd = torch.ones(self.capacity, dtype=torch.float64, device=self.device)
+        self.graphs = None
+
+    def _group_of(self, p):
+        for g in self.opt.param_groups:
+            if any(p is q for q in g["params"]):
+                return g
+        raise KeyError("parameter not in the optimiser")
+
+    # ---- the three pieces of a step --------------------------------------------------------------------------------
+    def _backward(self):
+        m, man, ex = self.model, self.model.manifold, self.ex
+        table = m.embeddings.embeds
+        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
+        weights = man.metric.weights if wsum else None
+        gw = weights.grad if wsum else None
+        gs = m.scale.grad if m.scale.requires_grad else None
+        b = self.batch_size
+        if not self.accumulate_loss:
+            self.loss.zero_()
+        if self.mode == "rows":
+            ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
+                                     None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                     grad_rows=ex.rows, step_counter=self.counter)
+            sel = self.arange + self.counter * b                 # the batch's rows of the loaded shard, on the device
+            ex.idx[:b].copy_(self.ids[:, 0].index_select(0, sel))
+            ex.idx[b:].copy_(self.ids[:, 1].index_select(0, sel))
+        else:
+            ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
+                                     None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                     grad_table=table.grad, step_counter=self.counter)
+
+    def _exchange(self):
+        ex = self.ex
+        if self.mode == "dense":
+            ex.allreduce()
+        elif self.mode == "rows":
+            ex.exchange_rows(ex.idx[:self.batch_size], ex.idx[self.batch_size:])
+
+    def _optimise(self):
+        if self.mode == "sharded":
+            self.ex.sharded_step(self.opt, self.max_grad_norm)          # leaves the flat buffer zero
+            self.counter.add_(1)
+            return
+        if self._fused is not None:
+            tg = self._group_of(self.model.embeddings.embeds)
+            xg = [self._group_of(p) for p in self._extra]
+            self._fused.run(tg["lr"], tg.get("weight_decay", 0.0), self.max_grad_norm,
+                            [g["lr"] for g in xg], [g.get("weight_decay", 0.0) for g in xg])
+            return
+        self.ex.step_after_exchange(self.opt, self.max_grad_norm)
+        self.ex.zero_()
+        self.counter.add_(1)
+
+    # ---- capture -----------------------------------------------------------------------------------------------------
+    def _key(self):
+        return (tuple((float(g["lr"]), float(g.get("weight_decay", 0.0))) for g in self.opt.param_groups), self.max_grad_norm)
+
+    def _graph_of(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            fn()
+        return g
+
+    def _capture(self):
+        if ops._debug:
+            raise RuntimeError("ops.set_debug(True) synchronises after every kernel and cannot run inside a hipGraph capture")
+        # warm-up with lr = 0 on a side stream (allocations, status words, RCCL's lazy communicator setup): retr(x, 0) =
+        # projx(x) is the identity for points on the manifold; loss, counter and gradients are put back
+        saved_lr = [g["lr"] for g in self.opt.param_groups]
+        saved = (self.loss.clone(), self.counter.clone())
+        for g in self.opt.param_groups:
+            g["lr"] = 0.0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.counter.zero_()
+                self._backward()
+                self._exchange()
+                self._optimise()
+        torch.cuda.current_stream().wait_stream(side)
+        for g, lr in zip(self.opt.param_groups, saved_lr):
+            g["lr"] = lr
+        self.loss.copy_(saved[0])
+        self.counter.copy_(saved[1])
+        self.ex.zero_()
+        self.graphs = None
+        if self.capture_collective:
+            def whole():
+                self._backward()
+                self._exchange()
+                self._optimise()
+            try:
+                self.graphs = [("graph", self._graph_of(whole))]
+            except Exception as e:  # noqa: BLE001 -- a backend that cannot enqueue its collective into a capture
+                torch.cuda.synchronize(self.device)
+                self.capture_error = repr(e)
+                self.graphs = None
+                self.loss.copy_(saved[0])
+                self.counter.copy_(saved[1])
+                self.ex.zero_()
+        if self.graphs is None:
+            plan = [("graph", self._graph_of(self._backward))]
+            if self.world > 1 and self.mode != "sharded":
+                plan.append(("eager", self._exchange))
+            if self.mode == "sharded":
+                plan.append(("eager", self._optimise))          # collectives inside
+            else:
+                plan.append(("graph", self._graph_of(self._optimise)))
+            self.graphs = plan
+        self.graphs_per_step = sum(1 for kind, _ in self.graphs if kind == "graph")
+        self.key = self._key()
+
+    def load_epoch(self, triplets):
+        """This rank's shard of the epoch (DistributedSampler order, train.py:105-110), [T, 3] int64 on the device; returns
+        the number of full batches `run_steps` may replay."""
+        total = triplets.shape[0]
+        if total > self.capacity:
+            self._alloc(total)
+        self.ids[:total].copy_(triplets[:, :2])
+        self.gd[:total].copy_(triplets[:, 2])
+        self.counter.zero_()
+        self.steps_loaded = total // self.batch_size
+        return self.steps_loaded
+
+    def run_steps(self, k=None):
+        if self.graphs is None or self._key() != self.key:
+            self._capture()
+        self.ex.check_views()
+        k = self.steps_loaded if k is None else int(k)
+        if k > self.steps_loaded:
+            raise ValueError("more steps than full batches left in the loaded epoch")
+        for _ in range(k):
+            for kind, item in self.graphs:
+                if kind == "graph":
+                    item.replay()
+                    self.replays += 1
+                else:
+                    item()
+        self.steps_loaded -= k
+        return self.loss
+
+    def reset_loss(self):
+        self.loss.zero_()
+
+
 def check(device):
     ops.check_status(device)

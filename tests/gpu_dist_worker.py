@@ -1,0 +1,130 @@
+"""Rank body of tests/test_multirank_gpu.py -- started by `python -m torch.distributed.run` as a CHILD of the pytest process
+(never an exec from a process that holds the GPU).  Every rank of a ONE-GPU box shares cuda:0; the process group is gloo for
+world size 2 (RCCL cannot put two ranks on one device) and RCCL ("nccl") for world size 1.  All tensors that go through the
+collectives are device tensors, the kernels are the product's.
+
+    exchange <mode> <out dir>   one data-parallel training step (train.py:59,105-110,136; runner.py:98-118) through
+                                sympa_amd.distributed.GradientExchange in `dense`, `rows` or `sharded` mode: rank r takes
+                                triplets r::world of the global batch, backward, exchange, clip + RiemannianSGD; rank 0 saves
+                                the resulting parameters
+    graphed <mode> <out dir>    the same through sympa_amd.train_step.DistributedTrainStep (replayed graphs around the
+                                collective), three steps
+    ddp <out dir>               the reference's own wrapper (train.py:59): DistributedDataParallel(Model) over RCCL at world
+                                size 1, .grad against the unwrapped model"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def toy_model(manifold, metric, dims, nodes, dev, seed=1):
+    from sympa_amd import data
+    from sympa_amd.model import Model
+
+    class A:
+        pass
+    A.manifold, A.metric, A.dims, A.num_points = manifold, metric, dims, nodes
+    A.scale_coef, A.scale_init, A.train_scale = 2.0, 1.5, True
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.trained_like_table(nodes, dims, model=manifold, seed=seed)
+    return m.to(dev)
+
+
+def global_batch(nodes, pairs, step=0):
+    g = torch.Generator().manual_seed(100 + step)
+    return torch.stack((torch.randint(0, nodes, (pairs,), generator=g), torch.randint(0, nodes, (pairs,), generator=g),
+                        torch.randint(1, 9, (pairs,), generator=g)), 1)
+
+
+SHAPE = dict(manifold="upper", metric="wsum", dims=3, nodes=150, pairs=1024, lr=0.05, max_norm=0.7)
+
+
+def main():
+    what = sys.argv[1]
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if world == 1:
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympa_amd import ops
+        from sympa_amd.distributed import GradientExchange
+        from sympa_amd.optim import RiemannianSGD
+        S = SHAPE
+        if what in ("exchange", "graphed"):
+            mode, out = sys.argv[2], sys.argv[3]
+            m = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
+            opt = RiemannianSGD(m.parameters(), lr=S["lr"] * world, weight_decay=0.0, stabilize=None)     # train.py:136
+            b = S["pairs"] // world
+            if what == "exchange":
+                ex = GradientExchange(list(m.parameters()), table=m.embeddings.embeds, local_batch=b, mode=mode)
+                assert ex.mode == mode and ex.world == world
+                mine = global_batch(S["nodes"], S["pairs"])[rank::world].contiguous().to(dev)
+                ids, gd = mine[:, :2].contiguous(), mine[:, 2].to(torch.float64)
+                ex.zero_()
+                if mode == "rows":
+                    loss = m.fused_loss_backward_rows(ids, gd, ex.rows)
+                    ex.exchange_rows(ids[:, 0], ids[:, 1])
+                    ex.step_after_exchange(opt, S["max_norm"])
+                elif mode == "dense":
+                    loss = m.fused_loss_backward(ids, gd)
+                    ex.allreduce()
+                    ex.step_after_exchange(opt, S["max_norm"])
+                else:
+                    loss = m.fused_loss_backward(ids, gd)
+                    ex.sharded_step(opt, S["max_norm"])
+                steps = 1
+            else:
+                from sympa_amd.train_step import DistributedTrainStep
+                st = DistributedTrainStep(m, opt, b, S["max_norm"], dev, mode=mode)
+                steps = 3
+                trip = torch.cat([global_batch(S["nodes"], S["pairs"], s)[rank::world] for s in range(steps)]).to(dev)
+                assert st.load_epoch(trip) == steps
+                st.run_steps()
+                loss = st.loss.clone()
+                assert st.replays == steps * st.graphs_per_step, (st.replays, st.graphs_per_step)
+            ops.check_status(dev)
+            tot = loss.clone()
+            dist.all_reduce(tot)                     # device tensor through the group's backend
+            torch.cuda.synchronize()
+            if rank == 0:
+                torch.save({"table": m.embeddings.embeds.detach().cpu(), "scale": m.scale.detach().cpu(),
+                            "weights": m.manifold.metric.weights.detach().cpu(), "loss": tot.cpu(), "world": world,
+                            "steps": steps}, os.path.join(out, f"{what}_{mode}.pt"))
+        elif what == "ddp":
+            out = sys.argv[2]
+            from torch.nn.parallel import DistributedDataParallel
+            m = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
+            plain = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
+            ddp = DistributedDataParallel(m, device_ids=None)                       # train.py:59
+            trip = global_batch(S["nodes"], S["pairs"]).to(dev)
+            gd = trip[:, 2].to(torch.float64)
+
+            def loss_of(net):                        # AverageDistortionLoss (losses.py:16-19)
+                d = net(trip)
+                return ((d / gd) ** 2 - 1.0).abs().sum()
+            loss_of(ddp).backward()                                                  # runner.py:101-105
+            loss_of(plain).backward()
+            ops.check_status(dev)
+            torch.cuda.synchronize()
+            res = {}
+            for (name, p), (_, q) in zip(m.named_parameters(), plain.named_parameters()):
+                assert p.grad is not None and q.grad is not None, name
+                res[name] = float((p.grad - q.grad).abs().max() / q.grad.abs().max().clamp_min(1e-300))
+            res["keys"] = sorted(ddp.state_dict().keys())
+            torch.save(res, os.path.join(out, "ddp.pt"))
+        else:
+            raise SystemExit(f"unknown worker mode {what}")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,12 +144,14 @@ def test_edge_cases(dev):
         ops.siegel_dist_forward(torch.zeros(2, 2, 17, 17, device=dev), torch.zeros(2, 2, 17, 17, device=dev))
 
 
-@pytest.mark.parametrize("model,n,b,N", [("upper", 4, 8192, 1093), ("bounded", 4, 65536, 5041),
-                                         ("upper", 8, 262144, 45500), ("upper", 2, 512, 125)])
-def test_full_size_properties(dev, model, n, b, N):
-    """BASELINE.json config sizes, checked through properties that need no CPU reference:
-    symmetry d(x,y) = d(y,x); d(x,x) = 0; invariance under the isometries Z -> A Z A^T + S of the
-    upper half space (and agreement upper == bounded through the Cayley map on a sample)."""
+@pytest.mark.parametrize("model,metric,n,b,N", [("upper", "riem", 4, 8192, 1093), ("bounded", "finf", 4, 65536, 5041),
+                                                ("bounded", "riem", 4, 65536, 5041), ("upper", "riem", 4, 65536, 5041),
+                                                ("upper", "riem", 8, 262144, 45500), ("upper", "riem", 2, 512, 125)])
+def test_full_size_properties(dev, model, metric, n, b, N):
+    """BASELINE.json config sizes in their own metric (configs[2] is bounded / F-infinity; the headline shape upper / riem /
+    n = 4 / 65 536 pairs / 5 041 rows is here too), checked through properties that need no CPU reference: symmetry
+    d(x,y) = d(y,x); d(x,x) = 0; invariance under the isometries Z -> A Z A^T + S of the upper half space (and agreement
+    upper == bounded through the Cayley map); plus a 256-pair sample against the oracle."""
     from sympa_amd import ops
     g = torch.Generator().manual_seed(11)
     tab_u = upper_points(N, n, 0.4, g)
@@ -157,26 +159,26 @@ def test_full_size_properties(dev, model, n, b, N):
     src = torch.randint(0, N, (b,), generator=g)
     dst = (src + 1 + torch.randint(0, N - 1, (b,), generator=g)) % N
     trip = torch.stack((src, dst), 1).to(dev)
-    d_xy = ops.model_forward(table, trip, model, "riem")
-    d_yx = ops.model_forward(table, trip.flip(1).contiguous(), model, "riem")
+    d_xy = ops.model_forward(table, trip, model, metric)
+    d_yx = ops.model_forward(table, trip.flip(1).contiguous(), model, metric)
     ops.check_status(dev)
     assert torch.isfinite(d_xy).all() and (d_xy > 0).all()
     assert rel_err(d_xy.cpu(), d_yx.cpu()) < 1e-10
     same = torch.stack((src, src), 1).to(dev)
-    assert torch.all(ops.model_forward(table, same, model, "riem") == 0)
+    assert torch.all(ops.model_forward(table, same, model, metric) == 0)
     if model == "upper":
         a = (torch.eye(n) + 0.3 * torch.randn(n, n, generator=g)).to(dev)
         s = sym(torch.randn(n, n, generator=g)).to(dev)
         moved = torch.stack((a @ table[:, 0] @ a.T + s, a @ table[:, 1] @ a.T), 1)
         moved = torch.stack((sym(moved[:, 0]), sym(moved[:, 1])), 1)
-        d_moved = ops.model_forward(moved, trip, model, "riem")
+        d_moved = ops.model_forward(moved, trip, model, metric)
         assert rel_err(d_moved.cpu(), d_xy.cpu()) < 1e-9
     else:
-        d_up = ops.model_forward(tab_u.to(dev), trip, "upper", "riem")
+        d_up = ops.model_forward(tab_u.to(dev), trip, "upper", metric)
         assert rel_err(d_xy.cpu(), d_up.cpu()) < 1e-9
-    # a bounded sample against the oracle as well
+    # a 256-pair sample against the oracle as well
     k = 256
-    want = so.model_forward(table.cpu(), trip[:k].cpu(), model, "riem")
+    want = so.model_forward(table.cpu(), trip[:k].cpu(), model, metric)
     assert rel_err(d_xy[:k].cpu(), want) < 1e-8
 
 

@@ -282,6 +282,50 @@ def test_gpu_table_operations_dims_9_to_16(dev, model, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_rsgd_step_is_reentrant_across_many_streams(dev, model):
+    """Round-3 review: the word the exact projection of the dims >= 7 step is gated on was one of 64 process-global slots
+    keyed by stream handle (a mutex, never released, the 65th stream raced).  It is the caller's now (C-ABI `outside_word`).
+    200 steps at n = 8 on 100 short-lived streams, all in flight together, every one with rows that leave the interior:
+    each table equals the step run alone and every projection is counted; with outside_word = NULL the entry runs the exact
+    one-row-per-lane kernel and gives the same table."""
+    from sympa_amd import _lib, ops
+    n, rows = 8, 50
+    g = torch.Generator().manual_seed(77)
+    table, grad = step_inputs(model, n, g)
+    lr = 0.7                               # pushes rows off the manifold -> the gated projection must run
+    want, keep = so.rsgd_step(model, table, grad, lr, 0.01)
+    moved = int((~keep).sum())
+    assert moved > 0
+    gd = grad.to(dev)
+    tabs = [table.clone().to(dev) for _ in range(200)]
+    cnts = torch.zeros(200, 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    streams = []
+    for k, tab in enumerate(tabs):
+        if k % 2 == 0:
+            streams.append(torch.cuda.Stream())            # > 64 distinct streams alive at once
+        with torch.cuda.stream(streams[-1]):
+            ops.rsgd_step_(tab, gd, model, lr, 0.01, counter=cnts[k])
+    torch.cuda.synchronize()
+    ops.check_status(dev)
+    assert len({s.cuda_stream for s in streams}) > 1
+    for k, tab in enumerate(tabs):
+        assert relmax(tab.cpu(), want) < 1e-8, k
+    assert bool((cnts == moved).all()), cnts.flatten().tolist()
+    # no scratch word: the exact kernel on every row
+    lib = _lib.load()
+    tab = table.clone().to(dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = torch.zeros(2, dtype=torch.int32, device=dev)
+    rc = lib.sympa_rsgd_step(tab.data_ptr(), gd.data_ptr(), rows, n, ops.MODEL_IDS[model], lr, 0.01, 1e-5, cnt.data_ptr(),
+                             st.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert relmax(tab.cpu(), want) < 1e-8 and int(cnt) == moved
+
+
+@pytest.mark.gpu
 def test_gpu_sgd_step_of_a_parameter_without_manifold(dev):
     """sympa_sgd_step_clipped (the scale's step inside RiemannianSGD): p <- p - lr (coef g + wd p), coef from the device-side
     squared total norm like clip_grad_norm_."""
