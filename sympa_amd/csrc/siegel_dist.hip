@@ -27,7 +27,7 @@ int validate(const DistArgs& a, int model, int n) {
     if (a.metric == SYMPA_METRIC_WSUM && a.metric_w == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "metric wsum needs metric_w");
     if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
-    if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
+    if (a.b > (int64_t)0x7fffffff * 64) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
     // only the LDS-DMA / staged gathers of dims <= 4 address rows with 32-bit byte offsets
     if (n <= 4 && a.num_rows * 16 * n * n >= ((int64_t)1 << 32))
@@ -92,7 +92,7 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     if (a.metric == SYMPA_METRIC_WSUM && a.metric_w == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "metric wsum needs metric_w");
     if (!(a.inv_eps > 0.0) || !(a.inv_eps < 1e300)) return fail(SYMPA_ERR_BAD_ARG, "eps must be > 0");
-    if (a.b > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
+    if (a.b > (int64_t)0x7fffffff * 64) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
     if (a.num_rows > (int64_t)0x7fffffff) return fail(SYMPA_ERR_BAD_ARG, "more than 2^31-1 table rows");
     if (n <= 4 && a.num_rows * 16 * n * n >= ((int64_t)1 << 32))
         return fail(SYMPA_ERR_BAD_ARG, "tables of dims <= 4 are limited to 4 GiB (32-bit row offsets in the gather)");
@@ -150,11 +150,12 @@ int launch_multi(const double* table, int64_t num_rows, int n, const int64_t* co
     m.c.flags = flags;
     uint64_t blocks = 0;
     int k = 0;
+    const int fb = fwd_block(n);
     for (int i = 0; i < cnt; ++i) {
         if (b[i] < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
         if (b[i] == 0) continue;
         if (triplets[i] == nullptr || out[i] == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
-        blocks += (uint64_t)((b[i] + BLOCK - 1) / BLOCK);
+        blocks += (uint64_t)((b[i] + fb - 1) / fb);
         if (blocks > 0x7fffffffull) return fail(SYMPA_ERR_BAD_ARG, "batches too large for one launch");
         m.trip[k] = triplets[i];
         m.out[k] = out[i];

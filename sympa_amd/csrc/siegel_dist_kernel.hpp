@@ -104,9 +104,9 @@ template <int N, int MODEL> constexpr int fwd_min_blocks() {
 }
 
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
-__global__ __launch_bounds__(BLOCK, (fwd_min_blocks<N, MODEL>())) void siegel_dist_kernel(const DistArgs a) {
-    __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
-    dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * BLOCK, lds);
+__global__ __launch_bounds__(fwd_block(N), (fwd_min_blocks<N, MODEL>())) void siegel_dist_kernel(const DistArgs a) {
+    __shared__ v2d lds[(fwd_block(N) / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
+    dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * fwd_block(N), lds);
 }
 
 // Several batches in ONE launch (C-ABI sympa_model_forward_batches with SYMPA_FLAG_FUSE): block x belongs to the
@@ -136,9 +136,9 @@ constexpr int multi_min_blocks() {
 }
 
 template <int N, int MODEL>
-__global__ __launch_bounds__(BLOCK, (multi_min_blocks<N, MODEL>())) void siegel_dist_multi_kernel(const MultiArgs m) {
+__global__ __launch_bounds__(fwd_block(N), (multi_min_blocks<N, MODEL>())) void siegel_dist_multi_kernel(const MultiArgs m) {
     constexpr bool LOW = DmaTile<N>::ENABLED;
-    __shared__ v2d lds[(BLOCK / 64) * BlockLds<N, MODEL, LOW>::WAVE_SLOTS];
+    __shared__ v2d lds[(fwd_block(N) / 64) * BlockLds<N, MODEL, LOW>::WAVE_SLOTS];
     // batch of this block: binary search over <= 32 prefix ends (block-uniform, scalar)
     int lo = 0, hi = m.num_batches - 1;
 #pragma unroll
@@ -155,37 +155,38 @@ __global__ __launch_bounds__(BLOCK, (multi_min_blocks<N, MODEL>())) void siegel_
     a.idx2 = m.trip[k] + 1;
     a.out = m.out[k];
     a.b = m.b[k];
-    dist_block<N, MODEL, LOW>(a, (int64_t)(blockIdx.x - blk0) * BLOCK, lds);
+    dist_block<N, MODEL, LOW>(a, (int64_t)(blockIdx.x - blk0) * fwd_block(N), lds);
 }
 
 // One launch.  SYMPA_FLAG_ANY_ORDER: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch), so the command
 // processor may start it while earlier launches of the SAME stream are still running -- independent steps overlap
 // without any cross-stream dependency.
 template <typename K>
-hipError_t launch_kernel(K kern, unsigned grid, const DistArgs& a, hipStream_t s) {
+hipError_t launch_kernel(K kern, unsigned grid, int block, const DistArgs& a, hipStream_t s) {
     if (a.flags & SYMPA_FLAG_ANY_ORDER) {
         void* args[] = {const_cast<DistArgs*>(&a)};
-        return hipExtLaunchKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(BLOCK), args, 0, s, nullptr,
+        return hipExtLaunchKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(block), args, 0, s, nullptr,
                                   nullptr, hipExtAnyOrderLaunch);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, a);
     return hipGetLastError();
 }
 
 template <int N>
 int launch_n(const DistArgs& a, int model, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.b + BLOCK - 1) / BLOCK);
+    constexpr int FB = fwd_block(N);
+    const unsigned grid = (unsigned)((a.b + FB - 1) / FB);
     // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
-    const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256);
+    const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256 * (BLOCK / FB));
     hipError_t e;
     if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
-        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, a, s);
+        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, FB, a, s);
     } else if (model == SYMPA_MODEL_UPPER) {
-        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, a, s);
-        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, a, s);
+        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, FB, a, s);
+        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, FB, a, s);
     } else {
-        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>, grid, a, s);
-        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>, grid, a, s);
+        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>, grid, FB, a, s);
+        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>, grid, FB, a, s);
     }
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
@@ -194,9 +195,9 @@ int launch_n(const DistArgs& a, int model, hipStream_t s) {
 template <int N>
 int launch_multi_n(const MultiArgs& m, unsigned grid, int model, hipStream_t s) {
     if (model == SYMPA_MODEL_UPPER)
-        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(BLOCK), 0, s, m);
+        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_UPPER>), dim3(grid), dim3(fwd_block(N)), 0, s, m);
     else
-        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(BLOCK), 0, s, m);
+        hipLaunchKernelGGL((siegel_dist_multi_kernel<N, sympa::MODEL_BOUNDED>), dim3(grid), dim3(fwd_block(N)), 0, s, m);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

@@ -90,6 +90,7 @@ def siegel_forms(n, pairs, seed=42):
 
 
 TINY = 1e-290
+VARIANTS = ("rut:1.0", "rut:0.95", "rut:0.8", "rut:0.5")
 
 
 def negligible(e2, da, db):
@@ -179,12 +180,16 @@ def dqds_lockstep(d, e, variant="safe", look=2, verbose=False):
     assert (q > 0).all(), q.min()
     sigma = g.copy()
     lam = np.full((B, n), np.nan)
-    BIG = 1e300
+    gmax = (d + off).max(1)
+    BIG = (4.0 * (gmax - g) + 1e-300)[:, None] * np.ones((1, n))      # a decoupled position: large, never the minimum
     bottom = np.full(B, n - 1)                 # per-lane bottom position (>= wave's `last` - look)
     work = 0
     fails = 0
     prev_dmin = np.full(B, np.inf)
     shrink = np.ones(B)
+    late_ok = np.zeros(B, bool)
+    late_shift = np.zeros(B)
+    theta = float(variant.split(":")[1]) if ":" in variant else 0.9
     for last in range(n - 1, 0, -1):
         for it in range(80):
             # deflation bookkeeping for positions last, last-1, ..., last-look
@@ -198,12 +203,13 @@ def dqds_lockstep(d, e, variant="safe", look=2, verbose=False):
                     done = at & (ee[:, pos - 1] <= 2.5e-17 * np.abs(sigma + q[:, pos]) + 1e-290)
                 if done.any():
                     lam[done, pos] = sigma[done] + q[done, pos]
-                    q[done, pos] = BIG
+                    q[done, pos] = BIG[done, pos]
                     if pos > 0:
                         ee[done, pos - 1] = 0.0
                     bottom[done] = pos - 1
                     prev_dmin[done] = np.inf
                     shrink[done] = 1.0
+                    late_ok[done] = False
             if (bottom < last).all():
                 break
             # shift per lane from its bottom 2 x 2 (positions b-1, b of the active block)
@@ -221,29 +227,37 @@ def dqds_lockstep(d, e, variant="safe", look=2, verbose=False):
                 s = np.minimum(s, np.where(np.isfinite(prev_dmin), prev_dmin, s))
                 s = np.where(live, s, 0.0)
             else:
-                # aggressive: eigenvalue of the trailing 2 x 2 of L L^T-form closest to qb, times a safety that shrinks after a failure
+                # upper bounds of the smallest eigenvalue of the active block: the smaller eigenvalue of its trailing 2 x 2 (a
+                # principal submatrix: interlacing) and dmin of the last successful sweep.  A shift must stay BELOW lambda_min:
+                #   rut:  after a LATE failure (only the last d negative) s_fail + d_last is a guaranteed lower bound
+                #         (Rutishauser); otherwise theta x the upper bound, theta shrinking with every early failure
                 a11 = qa + np.where(bottom >= 2, ee[idx, np.clip(b - 2, 0, n - 1)], 0.0)
                 a22 = qb + eb
                 a12sq = qa * eb
                 tr, det = a11 + a22, a11 * a22 - a12sq
                 disc = np.sqrt(np.maximum(0.25 * tr * tr - det, 0.0))
-                small = det / (0.5 * tr + disc)            # smaller root, stable form
-                s = np.where(live, np.maximum(small, 0.0) * shrink, 0.0)
-                s = np.where(bottom == 0, 0.0, s)
+                small = np.maximum(det, 0.0) / (0.5 * tr + disc)            # smaller root, stable form
+                ub = np.minimum(small, np.where(np.isfinite(prev_dmin), prev_dmin, small))
+                s = np.where(late_ok, late_shift, ub * theta * shrink)
+                s = np.where(live, np.maximum(s, 0.0), 0.0)
+                s = np.where(shrink < 0.01, 0.0, s)         # repeated early failures: a zero-shift (dqd) sweep cannot fail
             # one dqds sweep over [0, last] (positions beyond a lane's bottom are decoupled BIGs: pass through)
             qq = q.copy()
             en = ee.copy()
             dd = q[:, 0] - s
             dmin = dd.copy()
+            dlast = dd.copy()
             bad = dd < 0
+            early = bad.copy()
             for i in range(last):
                 qq[:, i] = dd + ee[:, i]
-                with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-                    t = q[:, i + 1] / qq[:, i]
+                t = q[:, i + 1] / np.maximum(qq[:, i], 1e-150)
                 en[:, i] = ee[:, i] * t
                 dd = dd * t - s
                 active = (i + 1) <= bottom
                 bad |= active & ~(dd >= 0)
+                early |= ((i + 1) < bottom) & ~(dd >= 0)
+                dlast = np.where((i + 1) == bottom, dd, dlast) if i > 0 or True else dlast
                 dmin = np.where(active, np.minimum(dmin, dd), dmin)
                 work += 1
             qq[:, last] = dd
@@ -252,13 +266,17 @@ def dqds_lockstep(d, e, variant="safe", look=2, verbose=False):
             # successful lanes take the new arrays; failed lanes keep the old ones and shrink their shift
             q = np.where(ok[:, None], qq, q)
             ee = np.where(ok[:, None], en, ee)
-            # decoupled positions stay BIG
-            for pos in range(n):
+            for pos in range(n):               # (simulation only: decoupled positions are reset every sweep)
                 beyond = pos > bottom
-                q[:, pos] = np.where(beyond, BIG, q[:, pos])
+                q[:, pos] = np.where(beyond, BIG[:, pos], q[:, pos])
+                if pos > 0:
+                    ee[:, pos - 1] = np.where(beyond, 0.0, ee[:, pos - 1])
             sigma = np.where(ok, sigma + s, sigma)
             prev_dmin = np.where(ok, dmin, prev_dmin)
-            shrink = np.where(ok, np.minimum(1.0, shrink * 1.0), shrink * 0.25)
+            late = bad & ~early & np.isfinite(dlast)          # only the bottom d went negative
+            late_shift = np.where(late, s + dlast, 0.0)
+            late_ok = late & (late_shift > 0)
+            shrink = np.where(ok, 1.0, np.where(late, shrink, shrink * 0.25))
         else:
             raise RuntimeError(f"no convergence at last={last}")
     # position 0
@@ -273,21 +291,21 @@ def main():
     waves = int(sys.argv[3]) if len(sys.argv) > 3 else 24
     (d, e), want = (spd_forms if kind == "spd" else siegel_forms)(n, 64 * waves)
     scale = np.abs(want).max(1)
-    tot = {"ql": 0, "safe": 0, "aggr": 0}
-    err = {"ql": 0.0, "safe": 0.0, "aggr": 0.0}
-    fails = {"safe": 0, "aggr": 0}
+    tot = dict({"ql": 0}, **{v: 0 for v in VARIANTS})
+    err = dict({"ql": 0.0}, **{v: 0.0 for v in VARIANTS})
+    fails = {v: 0 for v in VARIANTS}
     for w in range(waves):
         sl = slice(64 * w, 64 * (w + 1))
         got, work = ql_lockstep(d[sl], e[sl])
         tot["ql"] += work
         err["ql"] = max(err["ql"], float((np.abs(np.sort(got, 1) - want[sl]).max(1) / scale[sl]).max()))
-        for variant in ("aggr",):
+        for variant in VARIANTS:
             lam, work, f = dqds_lockstep(d[sl], e[sl], variant)
             tot[variant] += work
             fails[variant] += f
             err[variant] = max(err[variant], float((np.abs(np.sort(lam, 1) - want[sl]).max(1) / scale[sl]).max()))
     print(f"{kind} n={n}: {waves} waves")
-    for k, cost in (("ql", 30), ("aggr", 15)):
+    for k, cost in [("ql", 30)] + [(v, 16) for v in VARIANTS]:
         print(f"  {k:5s} element-sweeps per wave {tot[k] / waves:8.1f}   x {cost} instr = {tot[k] / waves * cost:9.0f}   "
               f"max |err| / |lambda|_max {err[k]:.2e}   failed lane-sweeps {fails.get(k, 0)}")
 
