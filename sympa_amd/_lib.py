@@ -59,10 +59,31 @@ _c_i64_p = ctypes.c_void_p
 _c_i32_p = ctypes.c_void_p
 
 _lib = None
+_fast = None          # sympa_amd/_fast.<abi>.so (csrc/torch_binding.cpp) once bound; False when absent or switched off
 
 
 class SympaHipError(RuntimeError):
     pass
+
+
+def fast():
+    """The thin torch binding of sympa_model_forward (csrc/torch_binding.cpp: tensors in, one C call), bound to the SAME
+    loaded libsympa_hip.so as the ctypes prototypes -- or None when it is not built (`__graft_entry__.build()` builds it) or
+    SYMPA_NO_FAST_BINDING is set: callers then go through ctypes, which calls the same C-ABI entry of the same library."""
+    global _fast
+    if _fast is None:
+        _fast = False
+        if not os.environ.get("SYMPA_NO_FAST_BINDING"):
+            try:
+                import torch  # noqa: F401  (the extension links against libtorch)
+                from sympa_amd import _fast as mod
+                lib = load()
+                mod.bind(ctypes.cast(lib.sympa_model_forward, ctypes.c_void_p).value,
+                         ctypes.cast(lib.sympa_last_error, ctypes.c_void_p).value)
+                _fast = mod
+            except ImportError:
+                _fast = False
+    return _fast or None
 
 
 def load():

@@ -130,7 +130,33 @@ def model_forward(table, triplets, model="upper", metric="riem", weights=None, s
                   eps=None, out=None, flags=0):
     """Fused Model.forward (C-ABI sympa_model_forward; reference model.py:16-41): gathers table rows
     triplets[:,0] / triplets[:,1] inside the kernel, returns dist * clamp_min(scale/scale_coef, 0.1).
-    The argument checks are kept cheap: this is called once per batch and the kernel takes ~8 us."""
+    The argument checks are kept cheap: this is called once per batch and the kernel takes ~7 us.  Where the thin torch
+    binding is built (sympa_amd/_fast, csrc/torch_binding.cpp) the checks, the output allocation and the stream lookup
+    happen in C++ and the call costs a third of the ctypes route (profiles/r04_host_call.txt); both call the same C-ABI entry
+    of the same library."""
+    fast = _lib.fast()
+    if fast is not None and table.is_cuda and triplets.is_cuda and table.dim() == 4:
+        n = table.shape[2]
+        dev = table.device
+        if n > 8:
+            _gate(_sc.SIEGEL_FWD, model, n, dev)
+        if not table.is_contiguous():
+            table = table.contiguous()
+        if triplets.dim() == 2 and triplets.stride(1) != 1:
+            triplets = triplets.contiguous()
+        w = _weights(metric, weights, n, dev) if metric == "wsum" else None
+        if scale is not None and (not scale.is_cuda or scale.dtype is not torch.float64 or scale.device != dev):
+            scale = scale.detach().to(device=dev, dtype=torch.float64)
+        try:
+            out = fast.model_forward(table, triplets, MODEL_IDS[model], METRIC_IDS[metric], w, scale, float(scale_coef),
+                                     1e-5 if eps is None else float(eps), _status_buf(dev), int(flags), out)
+        except RuntimeError as e:            # one error type for both bindings
+            if type(e) is RuntimeError:
+                raise _lib.SympaHipError(str(e).split("\n")[0]) from None
+            raise
+        if _debug:
+            check_status(dev)
+        return out
     lib = _lib.load()
     if not (table.is_cuda and triplets.is_cuda):
         _need_gpu(table, "table"); _need_gpu(triplets, "triplets")

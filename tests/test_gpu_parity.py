@@ -682,3 +682,51 @@ def test_eight_lanes_per_pair_forward_ab_kernel(dev, model, n):
     a = ops.model_forward(table, trip, model, "riem", None, sc, 2.0, flags=ops.FLAG_COOP)
     c = ops.model_forward(table, trip, model, "riem", None, sc, 2.0)
     assert rel_err(a.cpu(), c.cpu()) < 1e-10
+
+
+@pytest.mark.gpu
+def test_thin_torch_binding_equals_the_ctypes_binding(dev):
+    """sympa_amd/_fast (csrc/torch_binding.cpp) is a second binding of C-ABI sympa_model_forward for per-batch callers: bit-
+    identical outputs to the ctypes route for every model / metric / stride form, on the CURRENT stream (a side stream's
+    launch is ordered after that stream's work), same error types, and it is the route Model.forward takes."""
+    from sympa_amd import _lib, ops
+    assert _lib.fast() is not None, "sympa_amd/_fast is not built (__graft_entry__.build())"
+    g = torch.Generator().manual_seed(3)
+    for model, n in (("upper", 4), ("bounded", 3), ("upper", 8), ("upper", 11)):
+        tab_u = upper_points(120, n, 0.4, g)
+        table = (tab_u if model == "upper" else __import__("tests.helpers", fromlist=["to_bounded"]).to_bounded(tab_u)).to(dev)
+        trip3 = torch.stack((torch.randint(0, 120, (700,), generator=g), torch.randint(0, 120, (700,), generator=g),
+                             torch.randint(1, 9, (700,), generator=g)), 1).to(dev)
+        w = torch.linspace(0.2, 1.4, n, dtype=torch.float64).to(dev)
+        sc = torch.tensor([1.3], dtype=torch.float64, device=dev)
+        for metric in ("riem", "finf", "wsum"):
+            for trip in (trip3, trip3[:, :2].contiguous(), trip3[:1]):
+                _lib._fast = None
+                a = ops.model_forward(table, trip, model, metric, w, sc, 2.0)
+                _lib._fast = False                    # ctypes
+                b = ops.model_forward(table, trip, model, metric, w, sc, 2.0)
+                _lib._fast = None
+                assert torch.equal(a, b), (model, n, metric)
+    # stream semantics: on a side stream the launch is ordered behind that stream's earlier work
+    side = torch.cuda.Stream()
+    table = upper_points(120, 4, 0.4, g).to(dev)
+    trip = torch.stack((torch.randint(0, 120, (4096,), generator=g), torch.randint(0, 120, (4096,), generator=g)), 1).to(dev)
+    want = ops.model_forward(table, trip)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        moved = torch.zeros_like(trip)
+        torch.cuda._sleep(20_000_000)
+        moved.copy_(trip)                             # the forward must see the copied indices
+        got = ops.model_forward(table, moved)
+    side.synchronize()
+    assert torch.equal(got, want)
+    # error contract
+    with pytest.raises(_lib.SympaHipError):
+        ops.model_forward(table.cpu(), trip.cpu())
+    with pytest.raises(TypeError):
+        ops.model_forward(table.float(), trip)
+    with pytest.raises(RuntimeError):
+        ops.model_forward(torch.zeros(4, 2, 17, 17, dtype=torch.float64, device=dev), trip)
+    ops.model_forward(table, torch.tensor([[0, 500]], device=dev))
+    with pytest.raises(IndexError):
+        ops.check_status(dev)
