@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""The data-parallel training step (sympa_amd.train_step.DistributedTrainStep: replayed graphs around the gradient exchange)
+against the single-GPU two-kernel step, on ONE GPU over RCCL at world size 1 (the N > 1 code path: process group, collectives
+on the stream, the flat exchange buffer; what is missing is the xGMI time of the collective itself):
+    python tools/dist_step_time.py [steps]
+Shapes: the headline (upper / riem / n = 4, 65 536 triplets per step, 5 041 rows) and configs[3] (n = 8, 262 144, 45 500)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from sympa_amd import data, ops  # noqa: E402
+from sympa_amd.model import Model  # noqa: E402
+from sympa_amd.optim import RiemannianSGD  # noqa: E402
+from sympa_amd.train_step import DistributedTrainStep, GraphedTrainStep  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+g = torch.Generator().manual_seed(5)
+
+
+def fresh(manifold, metric, n, nodes):
+    class A:
+        pass
+    A.manifold, A.metric, A.dims, A.num_points = manifold, metric, n, nodes
+    A.scale_coef, A.scale_init, A.train_scale = 1.0, 1.0, True
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.trained_like_table(nodes, n, model=manifold, seed=1)
+    return m.to(dev)
+
+
+def timed(step, trip, batch):
+    def run(k):
+        step.load_epoch(trip[:batch * k])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step.run_steps(k)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+    run(3)
+    return min(run(steps) for _ in range(3))
+
+
+for name, manifold, metric, n, nodes, batch in (("headline", "upper", "riem", 4, 5041, 65536),
+                                                ("cartesian", "upper", "riem", 8, 45500, 262144)):
+    trip = torch.stack((torch.randint(0, nodes, (batch * steps,), generator=g), torch.randint(0, nodes, (batch * steps,), generator=g),
+                        torch.randint(1, 9, (batch * steps,), generator=g)), 1).to(dev)
+    rows = []
+    for form in ("single-GPU two-kernel step (atomic scatter)", "single-GPU two-kernel step (deterministic)"):
+        m = fresh(manifold, metric, n, nodes)
+        opt = RiemannianSGD(m.parameters(), lr=1e-4)
+        st = GraphedTrainStep(m, opt, batch, 50.0, dev, deterministic="determ" in form, accumulate_loss=True)
+        if st.mode != "two_kernels":
+            continue
+        rows.append((form, timed(st, trip, batch), ""))
+    for mode, cap in (("dense", True), ("dense", False), ("rows", False), ("sharded", True), ("sharded", False)):
+        m = fresh(manifold, metric, n, nodes)
+        opt = RiemannianSGD(m.parameters(), lr=1e-4)
+        st = DistributedTrainStep(m, opt, batch, 50.0, dev, mode=mode, capture_collective=cap)
+        dt = timed(st, trip, batch)
+        rows.append((f"DistributedTrainStep mode={mode}, RCCL world 1", dt,
+                     f"{st.graphs_per_step} graph(s) per step" + (f" (whole-step capture refused: {st.capture_error[:60]})"
+                                                                  if cap and st.graphs_per_step != 1 and hasattr(st, 'capture_error') else "")
+                     + f", {st.ex.message_bytes / 1e6:.2f} MB/rank/step at world 8: {int(2 * 7 / 8 * st.ex.flat.numel() * 8) / 1e6:.2f} MB"))
+    ops.check_status(dev)
+    for form, dt, note in rows:
+        print(f"{name:10s} n={n} batch={batch:7d} nodes={nodes:6d}  {form:52s} {dt * 1e6:9.1f} us/step  {note}", flush=True)
+dist.barrier()
+dist.destroy_process_group()
