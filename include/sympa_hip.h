@@ -290,7 +290,8 @@ int sympa_rsgd_step_clipped(double* table, const double* grad, int64_t num_rows,
                             double weight_decay, double eps, const double* total_sqnorm, double max_norm,
                             int32_t* projected_count, int32_t* status, int32_t* outside_word, void* stream);
 
-/* The backward half of a training step inside a replayed hipGraph (sympa/runner.py:98-105), dims 1..8.  Like
+/* The backward half of a training step inside a replayed hipGraph (sympa/runner.py:98-105), dims 1..16 (wave_partials: dims
+ * 1..8).  Like
  * sympa_model_loss_backward (grad_table given: fp64-atomic scatter into the dense gradient) or
  * sympa_model_loss_backward_rows (grad_rows [2 b, 2, n, n] given: rows [0, b) belong to src, [b, 2 b) to dst), plus
  *   step_counter   device int64 c (may be NULL = 0): the launch processes pairs [c b, (c + 1) b) of src / dst / graph_dist,

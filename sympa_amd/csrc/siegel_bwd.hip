@@ -15,10 +15,13 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     // (tools/bwd_coop_ab_small.py, per 262 144 pairs): the fused step at n = 8 (upper 1.78 -> 1.49 ms, bounded 2.59 -> 1.99 ms),
     // bounded n = 8 dense rows (2.51 -> 2.15 ms), bounded n = 7 fused (1.70 -> 1.56 ms).  SYMPA_FLAG_COOP forces it for
     // dims 5..8, SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels.
-    // the training graph's batch window and the deterministic per-wave sums exist in the one-pair-per-lane kernels only
-    const bool graph_mode = a.f.batch_counter != nullptr || a.wave_partials != nullptr;
-    if (graph_mode && n > 8) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "step_counter / wave_partials: dims 1..8");
-    const bool one_lane = (a.f.flags & SYMPA_FLAG_GENERIC) || instance_fallback(SYMPA_FAMILY_SIEGEL_BWD, model, n) || graph_mode;
+    // the deterministic per-wave sums exist in the one-pair-per-lane kernels only (dims <= 8); the training graph's batch
+    // window (step_counter) in every kernel family but the rolled one-lane kernels of dims 9..16
+    const bool det_mode = a.wave_partials != nullptr;
+    if (det_mode && n > 8) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "wave_partials: dims 1..8");
+    const bool one_lane = (a.f.flags & SYMPA_FLAG_GENERIC) || instance_fallback(SYMPA_FAMILY_SIEGEL_BWD, model, n) || det_mode;
+    if (a.f.batch_counter != nullptr && n > 8 && one_lane)
+        return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "step_counter at dims 9..16: the sixteen-lanes kernels only");
     if (n >= 5 && n <= 8 && !one_lane) {
         const bool bounded = model == SYMPA_MODEL_BOUNDED;
         const bool faster = (n == 8 && (scatter || bounded)) || (n == 7 && bounded && scatter);

@@ -49,6 +49,8 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
     double gw_acc[M];
 #pragma unroll
     for (int k = 0; k < M; ++k) gw_acc[k] = 0.0;
+    // the training graph's batch window (DistArgs::batch_counter): pairs [c b, (c + 1) b) of the index / graph-distance lists
+    const int64_t boff = (f.batch_counter != nullptr) ? f.batch_counter[0] * f.b : 0;
 
     for (int t = 0; t < rounds; ++t) {
         const int64_t first = ((int64_t)blockIdx.x * rounds + t) * spd_coop::GROUPS_PER_WAVE;
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
         int64_t r1 = ii, r2 = ii;
         bool bad = false;
         if (f.idx1 != nullptr) {
-            r1 = f.idx1[ii * f.idx1_stride];
-            r2 = f.idx2[ii * f.idx2_stride];
+            r1 = f.idx1[(ii + boff) * f.idx1_stride];
+            r2 = f.idx2[(ii + boff) * f.idx2_stride];
             if (r1 < 0 || r1 >= f.num_rows || r2 < 0 || r2 >= f.num_rows) { bad = true; r1 = 0; r2 = 0; }
         }
         const double* pa = f.base1 + r1 * ROW;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
         if (!finite) dist = __builtin_nan("");
         double go = 0.0, loss_i = 0.0;
         if (a.graph_dist != nullptr) {   // AverageDistortionLoss (losses.py:10-19): sum |(d/g)^2 - 1|
-            const double gd = live ? a.graph_dist[i] : 1.0;
+            const double gd = live ? a.graph_dist[i + boff] : 1.0;
             const double ratio = dist * sc / gd;
             const double ee = ratio * ratio - 1.0;
             loss_i = (live && !bad) ? fabs(ee) * a.loss_scale : 0.0;

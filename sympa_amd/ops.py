@@ -640,7 +640,7 @@ def radam_step_(table, grad, exp_avg, exp_avg_sq, bias_pows, model, lr, betas=(0
 def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper", metric="riem", weights=None,
                          grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, grad_table=None,
                          grad_rows=None, step_counter=None, wave_partials=None, eps=None, flags=0):
-    """The backward half of a training step for replayed graphs (C-ABI sympa_model_train_backward, dims <= 8): pairs
+    """The backward half of a training step for replayed graphs (C-ABI sympa_model_train_backward; wave_partials: dims <= 8): pairs
     [c * batch, (c + 1) * batch) of `triplets` [T, >=2] int64 / `graph_dist` [T] fp64, c = step_counter[0] (device int64; None:
     0).  grad_table: atomic scatter into the dense gradient; grad_rows [2 batch, 2, n, n]: per-pair rows (written).
     wave_partials [ceil(batch / 64), 2 + n]: deterministic mode, see segment_sum_rows_."""

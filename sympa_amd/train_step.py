@@ -392,7 +392,7 @@ class GraphedTrainStep:
 class DistributedTrainStep:
     """The data-parallel training step (train.py:59,105-110,136 + runner.py:98-118: every rank runs backward on its shard of
     the global batch, the gradients are averaged, every rank takes the optimiser step) as REPLAYED GRAPHS around the
-    exchange -- the multi-GPU counterpart of GraphedTrainStep's two-kernel step, RiemannianSGD, Siegel models with dims <= 8.
+    exchange -- the multi-GPU counterpart of GraphedTrainStep's two-kernel step, RiemannianSGD, Siegel models.
 
         graph A   sympa_model_train_backward: distances + loss + backward of batch c (device step counter; an epoch's
                   shard is loaded once with `load_epoch`), scattered into the table-gradient view of GradientExchange's flat
@@ -413,9 +413,9 @@ class DistributedTrainStep:
         from sympa_amd.optim import RiemannianSGD
         man = model.manifold
         table = model.embeddings.embeds
-        if getattr(man, "model_name", None) not in ("upper", "bounded") or table.shape[2] > 8:
-            raise NotImplementedError("DistributedTrainStep: Siegel models with dims <= 8 (the step-counter backward kernel); "
-                                      "other models run the eager exchange of tools/train_siegel.py")
+        if getattr(man, "model_name", None) not in ("upper", "bounded"):
+            raise NotImplementedError("DistributedTrainStep: Siegel models (the step-counter backward kernels); the spd model "
+                                      "runs the eager exchange of tools/train_siegel.py")
         if not isinstance(optimizer, RiemannianSGD):
             raise NotImplementedError("DistributedTrainStep: sympa_amd.optim.RiemannianSGD")
         self.model, self.opt, self.dist = model, optimizer, dist

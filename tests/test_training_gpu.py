@@ -330,6 +330,45 @@ def test_wave_partials_are_not_written_past_their_last_row(n, tail):
     assert bool((buf[:waves] != -777.0).all())
 
 
+@pytest.mark.parametrize("model,n", [("upper", 7), ("upper", 8), ("bounded", 8), ("upper", 11), ("bounded", 9)])
+def test_step_counter_window_in_the_lanes_per_pair_backward_kernels(model, n):
+    """Round 4: the training graph's batch window (device step counter) also exists in the eight- / sixteen-lanes-per-pair
+    backward kernels (dims 7..16), so the replayed multi-GPU step runs the FAST dims-8 kernel: batch c of a loaded epoch
+    through sympa_model_train_backward == sympa_model_loss_backward on that slice (same kernel family: to rounding of the
+    atomics), in the scatter and in the per-pair-rows form."""
+    from sympa_amd import data, ops
+    dev = torch.device("cuda:0")
+    nodes, b, steps = 97, 300, 3
+    g = torch.Generator().manual_seed(70 + n)
+    table = data.trained_like_table(nodes, n, model=model, seed=4).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (steps * b,), generator=g), torch.randint(0, nodes, (steps * b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (steps * b,), generator=g).to(torch.float64).to(dev)
+    sc = torch.tensor([1.7], dtype=torch.float64, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    for step in (0, 2):
+        counter.fill_(step)
+        sl = slice(step * b, (step + 1) * b)
+        want = torch.zeros_like(table)
+        lw, gsw = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward(table, trip[sl], gd[sl], want, lw, model, "riem", None, None, sc, gsw, 2.0, 1.0)
+        got = torch.zeros_like(table)
+        lg, gsg = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_train_backward(table, trip, gd, b, lg, model, "riem", None, None, sc, gsg, 2.0, 1.0, grad_table=got,
+                                 step_counter=counter)
+        ops.check_status(dev)
+        big = float(want.abs().max())
+        assert float((got - want).abs().max()) < 1e-11 * big, (model, n, step)
+        assert abs(float(lg - lw)) < 1e-11 * abs(float(lw)) and abs(float(gsg - gsw)) < 1e-10 * abs(float(gsw))
+        rows = torch.zeros(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+        lr_ = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_train_backward(table, trip, gd, b, lr_, model, "riem", None, None, sc, None, 2.0, 1.0, grad_rows=rows,
+                                 step_counter=counter)
+        dense = torch.zeros_like(table)
+        dense.index_add_(0, trip[sl, 0], rows[:b])
+        dense.index_add_(0, trip[sl, 1], rows[b:])
+        assert float((dense - want).abs().max()) < 1e-11 * big, (model, n, step, "rows")
+
+
 def test_two_kernel_epoch_trains_like_the_classic_graph_and_the_deterministic_form_is_reproducible():
     """The two-kernel step driven by the device step counter (load_epoch + run_steps) == round 2's classic graph called
     batch by batch (tolerance: atomics); the deterministic form run twice gives bit-identical tables, scales and losses."""
