@@ -54,10 +54,11 @@ def test_graphed_step_equals_eager_step(dims):
     assert h_graph[-1][2] < 0.9 * h_graph[0][2]
 
 
-@pytest.mark.parametrize("mode", ["dense", "rows"])
+@pytest.mark.parametrize("mode", ["dense", "rows", "sharded"])
 def test_gradient_exchange_step_equals_plain_step(mode):
-    """The data-parallel step (persistent flat gradient buffer; dense all-reduce or touched-row exchange with the rows
-    backward kernel + scatter kernel) at world size 1 trains exactly like the plain eager step."""
+    """The data-parallel step (persistent flat gradient buffer; dense all-reduce, touched-row exchange with the rows
+    backward kernel + scatter kernel, or reduce-scatter + sharded step + all-gather; since round 4 replayed as graphs by
+    DistributedTrainStep, ragged last batch eager) at world size 1 trains exactly like the plain eager step."""
     import train_siegel
     common = ["--graph", "grid3d-125", "--manifold", "bounded", "--metric", "riem", "--dims", "3", "--epochs", "8",
               "--batch_size", "512", "--val_every", "2", "--learning_rate", "0.02", "--burnin", "3"]

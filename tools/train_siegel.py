@@ -7,7 +7,9 @@ rewrite of them: SURVEY 8f): graph -> triplets -> Model -> fused training step -
 Per batch it runs exactly two kernels: sympa_model_loss_backward (forward + AverageDistortionLoss + backward +
 scatter, runner.py:101-105) and sympa_rsgd_step (geoopt RiemannianSGD, train.py:66-68), plus the gradient clip
 of runner.py:115.  Multi-GPU: launch with torch.distributed.run; triplets are sharded with DistributedSampler
-semantics and the gradients are averaged with one flat RCCL all-reduce (sympa_amd/distributed.py)."""
+semantics and the gradients are exchanged over RCCL (sympa_amd/distributed.py: one flat all-reduce, touched rows, or
+reduce-scatter + sharded step + all-gather); the step with the exchange in it is a graph replay too
+(sympa_amd/train_step.py::DistributedTrainStep)."""
 import argparse
 import os
 import sys
@@ -21,7 +23,7 @@ from sympa_amd import data, ops  # noqa: E402
 from sympa_amd.distributed import GradientExchange, shard_triplets  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
 from sympa_amd.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
-from sympa_amd.train_step import GraphedTrainStep  # noqa: E402
+from sympa_amd.train_step import DistributedTrainStep, GraphedTrainStep  # noqa: E402
 
 
 def evaluate(model, ids, gd, batch):
@@ -49,7 +51,7 @@ def train(args, log=print):
     gd_all = trip[:, 2].to(torch.float64).to(dev)
     batch = max(1, args.batch_size // world)
     history = []
-    # single GPU: the whole step is one hipGraph replay; multi-GPU steps have an all-reduce in the middle and run eagerly
+    # single GPU: the whole step is one hipGraph replay
     graphed = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev,
                                deterministic=True if args.deterministic else None, accumulate_loss=True) \
         if (world == 1 and args.graph_step and args.grad_exchange == "none") else None
@@ -58,15 +60,24 @@ def train(args, log=print):
     # N > 1 (or --grad_exchange given): gradients live in one persistent flat buffer; the table gradient travels dense
     # (one in-place all-reduce) or as touched rows (all-gather of the 2 b per-pair rows), whichever message is smaller
     ex = None
+    dstep = None
     if world > 1 or args.grad_exchange != "none":
-        ex = GradientExchange(list(model.parameters()), table=model.embeddings.embeds, local_batch=batch,
-                              mode="auto" if args.grad_exchange == "none" else args.grad_exchange)
+        mode = "auto" if args.grad_exchange == "none" else args.grad_exchange
+        if args.graph_step and args.optim == "rsgd" and args.manifold in ("upper", "bounded"):
+            # round 4: the step with the exchange in the middle is replayed too -- backward graph, the collective on the same
+            # stream (captured inside the graph where the backend enqueues it: RCCL), optimiser graph; an epoch's shard is
+            # loaded once and addressed through the device step counter
+            dstep = DistributedTrainStep(model, opt, batch, args.max_grad_norm, dev, mode=mode, accumulate_loss=True)
+            ex = dstep.ex
+        else:
+            ex = GradientExchange(list(model.parameters()), table=model.embeddings.embeds, local_batch=batch, mode=mode)
         if rank == 0:
-            log(f"gradient exchange: {ex.mode}, {ex.message_bytes / 1e6:.3f} MB sent per rank per step")
+            log(f"gradient exchange: {ex.mode}, {ex.message_bytes / 1e6:.3f} MB sent per rank per step"
+                + ("" if dstep is None else ", replayed graphs"))
     # steps with an exchange in the middle run eagerly, but the optimiser side is still ONE launch where the fused kernel
     # applies (clip norm + RiemannianSGD + scale step + zero_grad on the exchanged gradient, which lives in ex's flat buffer)
     stepper = None
-    if ex is not None:
+    if ex is not None and dstep is None:
         stepper = GraphedTrainStep(model, opt, batch, args.max_grad_norm, dev)
         if stepper.mode == "two_kernels":
             stepper._ensure_fused()          # after GradientExchange: p.grad are views of its flat buffer
@@ -87,6 +98,10 @@ def train(args, log=print):
                 # its batch through a device counter (no per-step copy, memset or host arithmetic)
                 first = graphed.load_epoch(mine) * batch
                 graphed.run_steps()
+        if dstep is not None:
+            dstep.reset_loss()
+            first = dstep.load_epoch(mine) * batch
+            dstep.run_steps()                 # recaptures when the learning rate changed (end of burn-in)
         for s in range(first, mine.shape[0], batch):
             b = mine[s:s + batch]
             if graphed is not None:
@@ -96,6 +111,11 @@ def train(args, log=print):
             if ex is None:
                 opt.zero_grad(set_to_none=False)
                 loss_sum += model.fused_loss_backward(ids, gd)
+            elif ex.mode == "sharded":
+                ex.zero_()
+                loss_sum += model.fused_loss_backward(ids, gd)
+                ex.sharded_step(opt, args.max_grad_norm)
+                continue
             else:
                 ex.zero_()
                 if ex.mode == "rows" and ids.shape[0] == batch:
@@ -114,6 +134,8 @@ def train(args, log=print):
         ops.check_status(dev)
         if graphed is not None:
             loss_sum += graphed.loss
+        if dstep is not None:
+            loss_sum += dstep.loss
         if epoch % args.val_every == 0 or epoch == args.epochs:
             torch.cuda.synchronize(dev)
             t_train = time.perf_counter() - t0
@@ -144,7 +166,7 @@ def parser():
     ap.add_argument("--burnin", type=int, default=10)
     ap.add_argument("--val_every", type=int, default=5)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--grad_exchange", default="none", choices=["none", "auto", "dense", "rows"],
+    ap.add_argument("--grad_exchange", default="none", choices=["none", "auto", "dense", "rows", "sharded"],
                     help="single GPU: run the step through sympa_amd.distributed.GradientExchange anyway (tests); with "
                          "N > 1 GPUs the exchange is always on and this picks its mode (none = auto)")
     ap.add_argument("--deterministic", action="store_true", default=False,
