@@ -407,7 +407,7 @@ class DistributedTrainStep:
     the sharded mode's optimiser side runs between the graphs.  No host synchronisation anywhere in `run_steps`."""
 
     def __init__(self, model, optimizer, batch_size, max_grad_norm, device, mode="dense", group=None, capture_collective=None,
-                 accumulate_loss=True):
+                 accumulate_loss=True, deterministic=None):
         import torch.distributed as dist
         from sympa_amd.distributed import GradientExchange
         from sympa_amd.optim import RiemannianSGD
@@ -426,9 +426,23 @@ class DistributedTrainStep:
         self.mode = self.ex.mode
         self.world = self.ex.world
         self.accumulate_loss = bool(accumulate_loss)
+        # deterministic local accumulation (dense / sharded modes, dims <= 6): per-pair gradient rows + the segmented sum in a
+        # precomputed order + fixed-order scalar sums instead of fp64 atomics -- every rank's local gradient is bitwise
+        # reproducible (the collective's own summation order is the backend's), and at large batches it is also the faster
+        # form (GraphedTrainStep: 55 against 63 us at 65 536 triplets).  None: taken from 32 768 triplets per batch on.
+        det_ok = self.mode in ("dense", "sharded") and table.shape[2] <= 6
+        if deterministic is None:
+            deterministic = det_ok and self.batch_size >= 32768
+        if deterministic and not det_ok:
+            raise ValueError("deterministic accumulation: dense / sharded exchange, dims <= 6")
+        self.deterministic = bool(deterministic)
         self.loss = torch.zeros(1, dtype=torch.float64, device=device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.arange = torch.arange(self.batch_size, dtype=torch.int64, device=device)
+        if self.deterministic:
+            n = table.shape[2]
+            self.rows = torch.empty(2 * self.batch_size, 2, n, n, dtype=torch.float64, device=device)
+            self.partials = torch.zeros((self.batch_size + 63) // 64, 2 + n, dtype=torch.float64, device=device)
         self.capacity = 0
         self._alloc(self.batch_size)
         self.steps_loaded = 0
@@ -450,6 +464,10 @@ class DistributedTrainStep:
         self.capacity = int(pairs)
         self.ids = torch.zeros(self.capacity, 2, dtype=torch.int64, device=self.device)
         self.gd = torch.ones(self.capacity, dtype=torch.float64, device=self.device)
+        if self.deterministic:
+            steps = max(1, self.capacity // self.batch_size)
+            self.order = torch.zeros(steps, 2 * self.batch_size, dtype=torch.int32, device=self.device)
+            self.rowptr = torch.zeros(steps, self.model.embeddings.embeds.shape[0] + 1, dtype=torch.int32, device=self.device)
         self.graphs = None
 
     def _group_of(self, p):
@@ -476,6 +494,13 @@ class DistributedTrainStep:
             sel = self.arange + self.counter * b                 # the batch's rows of the loaded shard, on the device
             ex.idx[:b].copy_(self.ids[:, 0].index_select(0, sel))
             ex.idx[b:].copy_(self.ids[:, 1].index_select(0, sel))
+        elif self.deterministic:
+            ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
+                                     None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
+                                     grad_rows=self.rows, step_counter=self.counter, wave_partials=self.partials)
+            ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=self.counter,
+                                  wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
+                                  loss=self.loss, grad_scale=gs, grad_weights=gw)
         else:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
@@ -537,7 +562,7 @@ class DistributedTrainStep:
         self.counter.copy_(saved[1])
         self.ex.zero_()
         self.graphs = None
-        if self.capture_collective:
+        if (self.capture_collective or self.world == 1) and not getattr(self, "force_split", False):     # (world 1: no collective at all)
             def whole():
                 self._backward()
                 self._exchange()
@@ -553,8 +578,8 @@ class DistributedTrainStep:
                 self.ex.zero_()
         if self.graphs is None:
             plan = [("graph", self._graph_of(self._backward))]
-            if self.world > 1 and self.mode != "sharded":
-                plan.append(("eager", self._exchange))
+            if self.mode != "sharded":
+                plan.append(("eager", self._exchange))          # host-side collectives (gloo), or the scatter of the rows mode
             if self.mode == "sharded":
                 plan.append(("eager", self._optimise))          # collectives inside
             else:
@@ -571,8 +596,18 @@ class DistributedTrainStep:
             self._alloc(total)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
+        steps = total // self.batch_size
+        if self.deterministic and steps > 0:       # ONE stable sort per epoch: the order the segmented sums add in
+            used = self.ids[:steps * self.batch_size].view(steps, self.batch_size, 2)
+            order, rowptr = ops.sorted_slots(torch.cat((used[:, :, 0], used[:, :, 1]), dim=1),
+                                             self.model.embeddings.embeds.shape[0])
+            self.order[:steps].copy_(order)
+            self.rowptr[:steps].copy_(rowptr)
         self.counter.zero_()
-        self.steps_loaded = total // self.batch_size
+        # the replayed backward ACCUMULATES into the gradient buffer and relies on the optimiser side leaving it zero: whatever
+        # ran between two epochs (an eager ragged batch through the same GradientExchange) must not leak into the first step
+        self.ex.zero_()
+        self.steps_loaded = steps
         return self.steps_loaded
 
     def run_steps(self, k=None):

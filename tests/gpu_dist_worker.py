@@ -8,7 +8,7 @@ collectives are device tensors, the kernels are the product's.
                                 triplets r::world of the global batch, backward, exchange, clip + RiemannianSGD; rank 0 saves
                                 the resulting parameters
     graphed <mode> <out dir>    the same through sympa_amd.train_step.DistributedTrainStep (replayed graphs around the
-                                collective), three steps
+                                collective), three steps; graphed_det: with the deterministic local accumulation
     ddp <out dir>               the reference's own wrapper (train.py:59): DistributedDataParallel(Model) over RCCL at world
                                 size 1, .grad against the unwrapped model"""
 import os
@@ -57,7 +57,7 @@ def main():
         from sympa_amd.distributed import GradientExchange
         from sympa_amd.optim import RiemannianSGD
         S = SHAPE
-        if what in ("exchange", "graphed"):
+        if what in ("exchange", "graphed", "graphed_det"):
             mode, out = sys.argv[2], sys.argv[3]
             m = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
             opt = RiemannianSGD(m.parameters(), lr=S["lr"] * world, weight_decay=0.0, stabilize=None)     # train.py:136
@@ -82,7 +82,7 @@ def main():
                 steps = 1
             else:
                 from sympa_amd.train_step import DistributedTrainStep
-                st = DistributedTrainStep(m, opt, b, S["max_norm"], dev, mode=mode)
+                st = DistributedTrainStep(m, opt, b, S["max_norm"], dev, mode=mode, deterministic=(what == "graphed_det"))
                 steps = 3
                 trip = torch.cat([global_batch(S["nodes"], S["pairs"], s)[rank::world] for s in range(steps)]).to(dev)
                 assert st.load_epoch(trip) == steps
@@ -96,7 +96,8 @@ def main():
             if rank == 0:
                 torch.save({"table": m.embeddings.embeds.detach().cpu(), "scale": m.scale.detach().cpu(),
                             "weights": m.manifold.metric.weights.detach().cpu(), "loss": tot.cpu(), "world": world,
-                            "steps": steps}, os.path.join(out, f"{what}_{mode}.pt"))
+                            "steps": steps, "graphs_per_step": getattr(locals().get("st"), "graphs_per_step", None)},
+                           os.path.join(out, f"{what}_{mode}.pt"))
         elif what == "ddp":
             out = sys.argv[2]
             from torch.nn.parallel import DistributedDataParallel

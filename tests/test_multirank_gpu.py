@@ -115,14 +115,16 @@ def test_two_rank_gradient_exchange_step_equals_the_single_process_step_on_the_u
     assert moved > 1e-6                        # the step did something
 
 
-@pytest.mark.parametrize("mode", ["dense", "rows", "sharded"])
+@pytest.mark.parametrize("mode", ["dense", "rows", "sharded", "dense-det", "sharded-det"])
 def test_two_rank_graphed_distributed_step_equals_the_single_process_steps(tmp_path, mode):
     """DistributedTrainStep (replayed graphs around the exchange, device step counter) in two processes over gloo: three
     steps == three single-process steps on the union batches.  gloo's collectives are host calls, so the step is two graphs
     with the exchange between them (the worker asserts the replay count)."""
-    _torchrun(2, [WORKER, "graphed", mode, str(tmp_path)])
-    got = torch.load(os.path.join(str(tmp_path), f"graphed_{mode}.pt"))
-    assert got["world"] == 2 and got["steps"] == 3
+    what = "graphed_det" if mode.endswith("-det") else "graphed"
+    mode = mode.split("-")[0]
+    _torchrun(2, [WORKER, what, mode, str(tmp_path)])
+    got = torch.load(os.path.join(str(tmp_path), f"{what}_{mode}.pt"))
+    assert got["world"] == 2 and got["steps"] == 3 and got["graphs_per_step"] == (1 if mode == "sharded" else 2)
     dev = torch.device("cuda:0")
     m, loss = _single_process_step(3, dev)
     assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-11)
@@ -136,7 +138,7 @@ def test_graphed_distributed_step_over_rccl_at_world_size_one(tmp_path, mode):
     """The same step over RCCL (world size 1 on the one GPU): collectives are stream work, the whole step is captured."""
     _torchrun(1, [WORKER, "graphed", mode, str(tmp_path)])
     got = torch.load(os.path.join(str(tmp_path), f"graphed_{mode}.pt"))
-    assert got["world"] == 1
+    assert got["world"] == 1 and got["graphs_per_step"] == 1          # RCCL's collectives are captured with the step
     dev = torch.device("cuda:0")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gpu_dist_worker as w

@@ -76,17 +76,21 @@ for name, manifold, metric, n, nodes, batch in (("headline", "upper", "riem", 4,
                 rows.append(("single-GPU classic graph (eight lanes per pair backward)", (time.perf_counter() - t0) / steps, ""))
             continue
         rows.append((form, timed(st, trip, batch), ""))
-    for mode, cap in (("dense", True), ("dense", False), ("rows", False), ("sharded", True), ("sharded", False)):
+    for mode, cap, det in (("dense", True, False), ("dense", False, False), ("dense", True, True), ("rows", False, False),
+                           ("sharded", True, False), ("sharded", True, True)):
+        if det and n > 6:
+            continue
         m = fresh(manifold, metric, n, nodes)
         opt = RiemannianSGD(m.parameters(), lr=1e-4)
-        st = DistributedTrainStep(m, opt, batch, 50.0, dev, mode=mode, capture_collective=cap)
+        st = DistributedTrainStep(m, opt, batch, 50.0, dev, mode=mode, capture_collective=cap, deterministic=det)
+        st.force_split = not cap            # A/B: backward graph, exchange between the replays, optimiser graph
         dt = timed(st, trip, batch)
-        rows.append((f"DistributedTrainStep mode={mode}, RCCL world 1", dt,
+        rows.append((f"DistributedTrainStep mode={mode}{', deterministic' if det else ''}, RCCL world 1", dt,
                      f"{st.graphs_per_step} graph(s) per step" + (f" (whole-step capture refused: {st.capture_error[:60]})"
                                                                   if cap and st.graphs_per_step != 1 and hasattr(st, 'capture_error') else "")
                      + f", {st.ex.message_bytes / 1e6:.2f} MB/rank/step at world 8: {int(2 * 7 / 8 * st.ex.flat.numel() * 8) / 1e6:.2f} MB"))
     ops.check_status(dev)
     for form, dt, note in rows:
-        print(f"{name:10s} n={n} batch={batch:7d} nodes={nodes:6d}  {form:52s} {dt * 1e6:9.1f} us/step  {note}", flush=True)
+        print(f"{name:10s} n={n} batch={batch:7d} nodes={nodes:6d}  {form:62s} {dt * 1e6:9.1f} us/step  {note}", flush=True)
 dist.barrier()
 dist.destroy_process_group()
