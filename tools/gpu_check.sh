@@ -2,7 +2,7 @@
 # One gpurun call: GPU tests, smoke, the numerical self-check of every lanes-per-pair kernel instantiation, bench at the
 # driver's K and at the default K, rocprofv3 kernel trace + PMC passes, secondary workloads, training path.
 # usage: tools/gpu_check.sh <tag> [notests]
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -65,5 +65,9 @@ echo "== training-path kernels (times, A/Bs, whole graphed step, soak)"
 echo "== rocprof kernel trace of the two-kernel training step (headline shape)"
 WORKLOADS=headline timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -- python3 tools/train_step_time.py 50 > $OUT/prof_train.log 2>&1
 find $OUT/prof_train -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | tee $OUT/train_kernel_stats_head.txt
+echo "== round 4: per-call host cost of the two bindings, --launch direct, the replayed multi-GPU step at world size 1 over RCCL"
+timeout 300 python3 tools/host_call_time.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_call.txt
+timeout 300 python bench.py --launch direct --steps 2000 --warmup 200 --no-cpu-baseline --no-live-traffic 2>$OUT/bench_direct.err | tail -1 | tee $OUT/bench_direct.json | cut -c1-260
+timeout 600 python3 tools/dist_step_time.py 24 2>&1 | grep "us/step" | tee $OUT/dist_step.txt
 echo "== gpu_check status: FAIL=$FAIL"
 exit $FAIL
