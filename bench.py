@@ -235,7 +235,10 @@ def self_launch(nproc, argv, worker=None):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    # dmabuf IPC: this pool's host driver supports no other kind (the environment exports HSA_ENABLE_IPC_MODE_LEGACY=0 here and
+    # on the GPU boxes, and without it RCCL's cross-process handles fail with `hipIpcGetMemHandle: invalid argument`);
+    # setdefault only covers a launch from a scrubbed environment -- a value the caller set is never overridden
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), worker] + list(argv)
