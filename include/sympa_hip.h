@@ -388,14 +388,23 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
                             int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
                             double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
                             double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
-                            int32_t* status, int flags, void* stream);
+                            int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
+/* workspace (both backward entries; caller-owned device scratch, 16-byte aligned, may be NULL): with at least
+ * sympa_spd_backward_workspace_bytes(b, n) bytes the THREE-PHASE kernel runs where it is built (n = 16, csrc/
+ * spd_coop_bwd3_kernel.hpp): Householder form sixteen lanes per pair, then eigenvalues (lockstep QL) and eigenvectors (inverse
+ * iteration) ONE PAIR PER LANE with the vectors parked in the workspace, then the gradient rows sixteen lanes per pair again --
+ * 3x the kernel that runs the QL with accumulated rotations in the sixteen-lanes layout; pairs with a block of more than four
+ * close eigenvalues (y = c x) are finished by that kernel in a second launch behind it.  NULL, a size of 0 or SYMPA_FLAG_COOP /
+ * SYMPA_FLAG_GENERIC: the other kernels, as before.  sympa_spd_backward_workspace_bytes returns 0 where no kernel uses one. */
+int64_t sympa_spd_backward_workspace_bytes(int64_t b, int n);
 /* The same with the scatter inside the kernel (n >= 3, index lists required): the gradient rows of each pair are added
  * into grad_table [num_rows, n, n] with fp64 atomics, consecutive lanes on consecutive doubles -- one launch for
  * Model.forward + AverageDistortionLoss + backward + embedding-gradient accumulation (runner.py:98-118 for the spd model). */
 int sympa_spd_loss_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                             const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
                             const double* grad_out, const double* graph_dist, double loss_scale, double* loss,
-                            double* grad_table, double* grad_scale, double* out, int32_t* status, int flags, void* stream);
+                            double* grad_table, double* grad_scale, double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags,
+                            void* stream);
 /* geoopt SymmetricPositiveDefinite.egrad2rgrad (x sym(u) x), .projx (V |lambda| V^T of sym(x); projected_count += rows with
  * a negative eigenvalue), and one geoopt.optim.RiemannianSGD step over the table in place,
  *     x <- retr(x, -lr * egrad2rgrad(x, grad + weight_decay * x)),   retr(x, u) = sym(x + u + u x^-1 u / 2),

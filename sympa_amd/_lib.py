@@ -48,6 +48,7 @@ SYMBOLS = (
     "sympa_spd_model_forward",
     "sympa_scatter_add_flat_rows",
     "sympa_spd_backward_rows",
+    "sympa_spd_backward_workspace_bytes",
     "sympa_spd_loss_backward",
     "sympa_spd_egrad2rgrad",
     "sympa_spd_projx",
@@ -236,13 +237,16 @@ def load():
     lib.sympa_spd_backward_rows.argtypes = [
         _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64,
         ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_double, _c_double_p,
-        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+        ctypes.c_void_p,
     ]
+    lib.sympa_spd_backward_workspace_bytes.restype = ctypes.c_int64
+    lib.sympa_spd_backward_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
     lib.sympa_spd_loss_backward.restype = ctypes.c_int
     lib.sympa_spd_loss_backward.argtypes = [
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, ctypes.c_int64,
         _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p,
-        _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+        _c_double_p, _c_i32_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
     ]
     lib.sympa_spd_egrad2rgrad.restype = ctypes.c_int
     lib.sympa_spd_egrad2rgrad.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p, ctypes.c_void_p]

@@ -7,7 +7,7 @@
 
 #include "siegel_common.hpp"
 #include "spd_math_bwd.hpp"
-#include "spd_coop_bwd_kernel.hpp"
+#include "spd_coop_bwd3_kernel.hpp"
 
 namespace {
 using namespace sympa_hip;
@@ -137,7 +137,8 @@ static int spd_backward_impl(const double* x, const double* y, int64_t num_rows,
                             int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
                             double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
                             double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
-                            int32_t* status, int flags, void* stream, double* grad_table) {
+                            int32_t* status, int flags, void* stream, double* grad_table, void* workspace,
+                            int64_t workspace_bytes) {
     if (b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (b == 0) return 0;
     if (x == nullptr || y == nullptr || (grad_table == nullptr && (grad_x_rows == nullptr || grad_y_rows == nullptr)))
@@ -160,6 +161,11 @@ static int spd_backward_impl(const double* x, const double* y, int64_t num_rows,
     a.gtab = grad_table; a.gx = grad_x_rows; a.gy = grad_y_rows; a.gscale = grad_scale; a.out = out; a.status = status;
     const dim3 grid((unsigned)((b + 63) / 64));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // with a workspace: the three-phase kernel (eigenvectors one pair per lane by inverse iteration), where instantiated
+    if (workspace != nullptr && workspace_bytes > 0 && !(flags & (SYMPA_FLAG_COOP | SYMPA_FLAG_GENERIC))) {
+        int rc3 = 0;
+        if (launch_spd_bwd3(a, n, workspace, workspace_bytes, s, &rc3)) return rc3;
+    }
     // default: the QL of two rounds run together (8 pairs per wave and step) once the batch fills the chip that way;
     // SYMPA_FLAG_COOP forces the single-round kernel (A/B), SYMPA_FLAG_GENERIC the one-lane-per-pair kernel
     if (!(flags & (SYMPA_FLAG_COOP | SYMPA_FLAG_GENERIC)) && n >= 4 && b >= 8192 &&
@@ -181,18 +187,26 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
                             int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
                             double scale_coef, const double* grad_out, const double* graph_dist, double loss_scale,
                             double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
-                            int32_t* status, int flags, void* stream) {
+                            int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     return spd_backward_impl(x, y, num_rows, n, src, src_stride, dst, dst_stride, b, scale, scale_coef, grad_out, graph_dist,
-                             loss_scale, loss, grad_x_rows, grad_y_rows, grad_scale, out, status, flags, stream, nullptr);
+                             loss_scale, loss, grad_x_rows, grad_y_rows, grad_scale, out, status, flags, stream, nullptr,
+                             workspace, workspace_bytes);
+}
+
+int64_t sympa_spd_backward_workspace_bytes(int64_t b, int n) {
+    if (b <= 0 || n != 16) return 0;                      // the three-phase kernel is instantiated for n = 16
+    return spd_bwd3_workspace_bytes(b, n);
 }
 
 int sympa_spd_loss_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                             const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
                             const double* grad_out, const double* graph_dist, double loss_scale, double* loss,
-                            double* grad_table, double* grad_scale, double* out, int32_t* status, int flags, void* stream) {
+                            double* grad_table, double* grad_scale, double* out, int32_t* status, void* workspace,
+                            int64_t workspace_bytes, int flags, void* stream) {
     if (b > 0 && grad_table == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null gradient table");
     return spd_backward_impl(table, table, num_rows, n, src, src_stride, dst, dst_stride, b, scale, scale_coef, grad_out,
-                             graph_dist, loss_scale, loss, nullptr, nullptr, grad_scale, out, status, flags, stream, grad_table);
+                             graph_dist, loss_scale, loss, nullptr, nullptr, grad_scale, out, status, flags, stream, grad_table,
+                             workspace, workspace_bytes);
 }
 
 int sympa_spd_egrad2rgrad(const double* x, const double* u, int64_t b, int n, double* out, void* stream) {

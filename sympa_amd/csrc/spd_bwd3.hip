@@ -1,0 +1,39 @@
+// Three-phase SPD backward (spd_coop_bwd3_kernel.hpp): instantiations and the launcher.  One translation unit so that the
+// build compiles it beside the other spd units.
+#include "spd_coop_bwd3_kernel.hpp"
+
+namespace sympa_hip {
+
+namespace {
+template <int M>
+int launch3(const SpdBwdArgs& a, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    if (workspace == nullptr || workspace_bytes < spd_bwd3_workspace_bytes(a.b, M))
+        return fail(SYMPA_ERR_BAD_ARG, "spd backward: workspace too small (sympa_spd_backward_workspace_bytes)");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(SYMPA_ERR_BAD_ARG, "spd backward: workspace must be 16-byte aligned");
+    const int64_t chunks = (a.b + 63) / 64;
+    int32_t* flags = reinterpret_cast<int32_t*>(workspace);
+    double* ws = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 8 * (chunks + (chunks & 1)));
+    const int rounds = spd_bwd3_rounds(a.b);
+    const unsigned grid = (unsigned)((a.b + 4 * rounds - 1) / (4 * rounds));
+    hipLaunchKernelGGL(spd_bwd3_front_kernel<M>, dim3(grid), dim3(64), 0, s, a, rounds, ws);
+    hipLaunchKernelGGL(spd_bwd3_eig_kernel<M>, dim3((unsigned)chunks), dim3(64), 0, s, a.b, ws, flags);
+    hipLaunchKernelGGL(spd_bwd3_back_kernel<M>, dim3(grid), dim3(64), 0, s, a, rounds, ws, flags);
+    // the pairs of flagged chunks (a block of more than INVIT_KEEP + 1 close eigenvalues): the QL-with-vectors kernel on the
+    // same block -> pairs mapping; every other block leaves at once
+    SpdBwdArgs m = a;
+    m.only_if = flags;
+    hipLaunchKernelGGL(spd_coop_bwd_kernel<M>, dim3(grid), dim3(64), 0, s, m, rounds);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+}  // namespace
+
+bool launch_spd_bwd3(const SpdBwdArgs& a, int n, void* workspace, int64_t workspace_bytes, hipStream_t s, int* rc) {
+    switch (n) {
+        case 16: *rc = launch3<16>(a, workspace, workspace_bytes, s); return true;
+        default: return false;
+    }
+}
+
+}  // namespace sympa_hip

@@ -34,6 +34,9 @@ struct SpdBwdArgs {
     double* gscale;
     double* out;
     int32_t* status;
+    const int32_t* only_if;   // spd_coop_bwd_kernel: a block runs only when the 64-pair chunk of its first pair is flagged here
+                              // (nullptr: every block; a block's pairs must not straddle chunks) -- the last launch behind
+                              // the three-kernel backward (spd_coop_bwd3_kernel.hpp) takes the flagged chunks
 };
 
 inline dim3 spd_coop_bwd_grid(const int64_t b, const int n) {
@@ -55,6 +58,7 @@ void launch_spd_coop_bwd_lo(const SpdBwdArgs& a, int n, dim3 grid, hipStream_t s
 template <int M>
 __global__ __launch_bounds__(64, spd_coop_bwd_waves<M>()) void spd_coop_bwd_kernel(const SpdBwdArgs a, const int rounds) {
     using namespace spd_coop;
+    if (a.only_if != nullptr && a.only_if[((int64_t)blockIdx.x * rounds * 4) >> 6] == 0) return;      // block-uniform
     __shared__ __attribute__((aligned(16))) double tbuf_all[4 * TBUF];
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;

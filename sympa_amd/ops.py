@@ -7,6 +7,7 @@ Error contract: the reference raises AssertionError from inside d
 accumulated in a per-device status word; `check_status()` (or `set_debug(True)`) surfaces them as
 the same AssertionError / IndexError lazily."""
 import ctypes
+import os
 
 import torch
 
@@ -944,8 +945,26 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, fla
     return out
 
 
+def _spd_bwd_workspace(lib, b, n, dev, flags, workspace):
+    """The caller-owned scratch of the three-phase spd backward (C-ABI sympa_spd_backward_workspace_bytes; 0 bytes where no kernel
+    uses one): `workspace` when given (a persistent uint8 tensor: what a replayed graph wants), else a fresh tensor -- the caching
+    allocator serves it stream-ordered (inside a hipGraph capture from the graph's pool).  SYMPA_SPD_BWD_NO_WORKSPACE=1 (A/B) and
+    FLAG_COOP / FLAG_GENERIC keep the kernels that need none."""
+    if (flags & (FLAG_COOP | FLAG_GENERIC)) or os.environ.get("SYMPA_SPD_BWD_NO_WORKSPACE"):
+        return None, 0
+    need = int(lib.sympa_spd_backward_workspace_bytes(int(b), int(n)))
+    if need <= 0:
+        return None, 0
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or not workspace.is_cuda or workspace.numel() < need or workspace.data_ptr() % 16:
+            raise ValueError(f"workspace: a 16-byte aligned uint8 device tensor of at least {need} bytes")
+        return workspace, workspace.numel()
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    return ws, need
+
+
 def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale=None, scale_coef=1.0, loss_scale=1.0,
-                      loss=None, grad_scale=None, rows=None, want_out=False, flags=0):
+                      loss=None, grad_scale=None, rows=None, want_out=False, flags=0, workspace=None):
     """Backward of the spd distance (C-ABI sympa_spd_backward_rows).  triplets None: pair i = (x[i], y[i]); otherwise
     x is y is the [N, n, n] table and pair i = (table[triplets[i, 0]], table[triplets[i, 1]]).  Give grad_out [b] or
     graph_dist [b] (fused AverageDistortionLoss, accumulated into `loss`).  Returns (rows [2b, n, n], out or None):
@@ -983,13 +1002,15 @@ def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale
     if scale is not None:
         sc = scale.detach().reshape(-1)[:1].to(device=dev, dtype=torch.float64).contiguous()
     st = _status_buf(dev)
+    ws, ws_bytes = _spd_bwd_workspace(lib, b, n, dev, flags, workspace)
     with torch.cuda.device(dev):
         rc = lib.sympa_spd_backward_rows(
             x.data_ptr(), y.data_ptr(), x.shape[0], n, sp, stride, dp, stride, b, None if sc is None else sc.data_ptr(),
             float(scale_coef), None if go is None else go.data_ptr(), None if gd is None else gd.data_ptr(),
             float(loss_scale), None if loss is None else loss.data_ptr(), rows.data_ptr(),
             rows.data_ptr() + b * n * n * 8, None if grad_scale is None else grad_scale.data_ptr(),
-            None if out is None else out.data_ptr(), st.data_ptr(), int(flags), _stream())
+            None if out is None else out.data_ptr(), st.data_ptr(), None if ws is None else ws.data_ptr(), int(ws_bytes),
+            int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(dev)
@@ -997,7 +1018,7 @@ def spd_backward_rows(x, y, triplets=None, grad_out=None, graph_dist=None, scale
 
 
 def spd_loss_backward(table, triplets, grad_table, grad_out=None, graph_dist=None, scale=None, scale_coef=1.0,
-                      loss_scale=1.0, loss=None, grad_scale=None, want_out=False, flags=0):
+                      loss_scale=1.0, loss=None, grad_scale=None, want_out=False, flags=0, workspace=None):
     """spd backward with the scatter inside the kernel (C-ABI sympa_spd_loss_backward, n >= 3): the gradient rows of pair
     i = (table[triplets[i, 0]], table[triplets[i, 1]]) are ACCUMULATED into grad_table [N, n, n]; grad_out [b] or
     graph_dist [b] (fused AverageDistortionLoss into `loss`) as in spd_backward_rows.  Returns out [b] or None."""
@@ -1034,13 +1055,14 @@ def spd_loss_backward(table, triplets, grad_table, grad_out=None, graph_dist=Non
         sc = scale.detach().reshape(-1)[:1].to(device=dev, dtype=torch.float64).contiguous()
     st = _status_buf(dev)
     tp = triplets.data_ptr()
+    ws, ws_bytes = _spd_bwd_workspace(lib, b, n, dev, flags, workspace)
     with torch.cuda.device(dev):
         rc = lib.sympa_spd_loss_backward(
             tab.data_ptr(), tab.shape[0], n, tp, stride, tp + 8, stride, b, None if sc is None else sc.data_ptr(),
             float(scale_coef), None if go is None else go.data_ptr(), None if gd is None else gd.data_ptr(),
             float(loss_scale), None if loss is None else loss.data_ptr(), grad_table.data_ptr(),
             None if grad_scale is None else grad_scale.data_ptr(), None if out is None else out.data_ptr(),
-            st.data_ptr(), int(flags), _stream())
+            st.data_ptr(), None if ws is None else ws.data_ptr(), int(ws_bytes), int(flags), _stream())
     _lib.check(rc)
     if _debug:
         check_status(dev)

@@ -9,6 +9,7 @@
 #include "../../sympa_amd/csrc/siegel_math_generic.hpp"
 #include "../../sympa_amd/csrc/spd_math.hpp"
 #include "../../sympa_amd/csrc/spd_math_bwd.hpp"
+#include "../../sympa_amd/csrc/tridiag_invit.hpp"
 
 namespace {
 template <int N>
@@ -243,6 +244,37 @@ extern "C" int sympa_hostsim_tridiag_packed(const double* a, int64_t b, int s, d
         case 10: run_tridiag_packed<10>(a, b, eig); return 0;
         case 12: run_tridiag_packed<12>(a, b, eig); return 0;
         case 16: run_tridiag_packed<16>(a, b, eig); return 0;
+        default: return -2;
+    }
+}
+
+
+// Eigen-decomposition of b symmetric tridiagonal S x S matrices (d [b, S], e [b, S]: e[i] = T[i+1][i], e[S-1] ignored) the way
+// the two-phase SPD backward does it: eigenvalues by the lockstep PWK QL (siegel_math.hpp), sorted, eigenvectors by inverse
+// iteration (tridiag_invit.hpp).  lam [b, S] ascending, z [b, S, S]: row i = eigenvector i; flag [b] = 1 where a block of
+// more than INVIT_KEEP + 1 close eigenvalues was met (the kernel routes such pairs to the QL-with-vectors kernel).
+template <int S>
+static void run_tridiag_invit(const double* dd, const double* ee, int64_t b, double* lam_out, double* z_out, int32_t* flag) {
+    for (int64_t q = 0; q < b; ++q) {
+        double d[S], e[S], w[S], e2[S];
+        for (int i = 0; i < S; ++i) { d[i] = dd[q * S + i]; e[i] = (i < S - 1) ? ee[q * S + i] : 0.0; w[i] = d[i]; e2[i] = e[i] * e[i]; }
+        const bool conv = sympa::tridiag_ql_lockstep<S>(w, e2);
+        sympa::sort_ascending<S>(w);
+        double* zq = z_out + q * S * S;
+        const bool ok = sympa::tridiag_eigvecs_invit<S>(d, e, w, [&](auto IC, const double (&x)[S]) {
+            constexpr int i = decltype(IC)::value;
+            for (int j = 0; j < S; ++j) zq[i * S + j] = x[j];
+        });
+        for (int i = 0; i < S; ++i) lam_out[q * S + i] = w[i];
+        flag[q] = (ok ? 0 : 1) | (conv ? 0 : 2);
+    }
+}
+extern "C" int sympa_hostsim_tridiag_invit(const double* d, const double* e, int64_t b, int s, double* lam, double* z, int32_t* flag) {
+    switch (s) {
+        case 3: run_tridiag_invit<3>(d, e, b, lam, z, flag); return 0;
+        case 8: run_tridiag_invit<8>(d, e, b, lam, z, flag); return 0;
+        case 12: run_tridiag_invit<12>(d, e, b, lam, z, flag); return 0;
+        case 16: run_tridiag_invit<16>(d, e, b, lam, z, flag); return 0;
         default: return -2;
     }
 }

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""SPD backward at n = 16: the three-phase kernel (eigenvectors one pair per lane by inverse iteration, vectors parked in a
+caller-owned workspace; csrc/spd_coop_bwd3_kernel.hpp) against the kernel that runs the QL with accumulated rotations in the
+sixteen-lanes layout -- same inputs, gradients compared, both timed.
+    python tools/spd_bwd3_ab.py [pairs] [rows]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from sympa_amd import data, ops  # noqa: E402
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+n = 16
+dev = torch.device("cuda:0")
+table = data.spd_table(rows, n, seed=42).to(dev)
+trip = data.sample_pairs(rows, b, 0, 42).to(dev)
+g = torch.Generator().manual_seed(1)
+gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+sc = torch.ones(1, dtype=torch.float64, device=dev)
+
+
+def run(flags, reps=5):
+    grad = torch.zeros_like(table)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    gs = torch.zeros(1, dtype=torch.float64, device=dev)
+    out = ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, grad_scale=gs, want_out=True, flags=flags)
+    ops.check_status(dev)
+    torch.cuda.synchronize()
+    scratch = torch.zeros_like(table)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.spd_loss_backward(table, trip, scratch, graph_dist=gd, scale=sc, loss=loss.clone(), flags=flags)
+    e1.record()
+    torch.cuda.synchronize()
+    return grad, loss, gs, out, e0.elapsed_time(e1) / reps
+
+
+new = run(0)
+os.environ["SYMPA_SPD_BWD_NO_WORKSPACE"] = "1"
+old = run(0)
+del os.environ["SYMPA_SPD_BWD_NO_WORKSPACE"]
+big = float(old[0].abs().max())
+print(f"spd n={n} b={b} rows={rows}: three-phase {new[4]:.3f} ms   QL-with-vectors (two rounds together) {old[4]:.3f} ms   "
+      f"x{old[4] / new[4]:.2f}")
+print(f"  grad max abs diff / max {float((new[0] - old[0]).abs().max()) / big:.2e}   loss rel diff "
+      f"{abs(float(new[1] - old[1])) / abs(float(old[1])):.2e}   dist max rel diff "
+      f"{float(((new[3] - old[3]).abs() / old[3].abs().clamp_min(1e-300)).max()):.2e}   grad_scale rel diff "
+      f"{abs(float(new[2] - old[2])) / max(1e-300, abs(float(old[2]))):.2e}")
