@@ -193,3 +193,20 @@ def hostsim_spd_table(op, x, g=None, lr=0.0, wd=0.0):
                                      ctypes.c_double(wd), ctypes.byref(moved))
     assert st == 0, st
     return out, moved.value
+
+
+def hostsim_tridiag_invit(d, e):
+    """Eigen-decomposition of symmetric tridiagonals the way the three-kernel SPD backward does it (g++ build of
+    tridiag_invit.hpp behind the lockstep QL): d [b, s], e [b, s] (e[:, i] = T[i+1][i]; the last column is ignored).
+    Returns (lam [b, s] ascending, z [b, s, s] with row i = eigenvector i, flag [b]: bit 0 = a block of more than
+    INVIT_KEEP + 1 close eigenvalues, bit 1 = QL did not converge)."""
+    lib = hostsim()
+    P = ctypes.c_void_p
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    e = np.ascontiguousarray(e, dtype=np.float64)
+    b, s = d.shape
+    lam, z, flag = np.zeros((b, s)), np.zeros((b, s, s)), np.zeros(b, np.int32)
+    rc = lib.sympa_hostsim_tridiag_invit(P(d.ctypes.data), P(e.ctypes.data), ctypes.c_int64(b), s, P(lam.ctypes.data),
+                                         P(z.ctypes.data), P(flag.ctypes.data))
+    assert rc == 0
+    return lam, z, flag

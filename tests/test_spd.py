@@ -518,3 +518,82 @@ def test_gpu_spd_loss_backward_in_kernel_scatter(n):
     gt5 = torch.zeros_like(table)
     ops.spd_loss_backward(table, trip, gt5, graph_dist=gd)
     assert rel_err(gt4.cpu(), gt5.cpu(), atol=1e-13) < 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_spd16_three_kernel_backward_against_the_ql_kernel(monkeypatch):
+    """Round 4: n = 16 backward in three kernels (csrc/spd_coop_bwd3_kernel.hpp: Householder form sixteen lanes per pair,
+    eigenvalues + inverse-iteration eigenvectors ONE PAIR PER LANE through a caller-owned workspace, gradient rows sixteen
+    lanes per pair) == the kernel that runs the QL with accumulated rotations (SYMPA_SPD_BWD_NO_WORKSPACE=1), on batch sizes
+    around the 64-pair chunk, in the rows and the in-kernel-scatter form, with a persistent workspace, inside a hipGraph --
+    and on the pairs it must hand back: y = c x (every eigenvalue equal), y = x, blocks of six close eigenvalues."""
+    from sympa_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    n = 16
+    g = torch.Generator().manual_seed(2024)
+    lib = _lib.load()
+    assert lib.sympa_spd_backward_workspace_bytes(1000, 16) > 0 and lib.sympa_spd_backward_workspace_bytes(1000, 12) == 0
+
+    def both(fn):
+        monkeypatch.delenv("SYMPA_SPD_BWD_NO_WORKSPACE", raising=False)
+        new = fn()
+        monkeypatch.setenv("SYMPA_SPD_BWD_NO_WORKSPACE", "1")
+        old = fn()
+        monkeypatch.delenv("SYMPA_SPD_BWD_NO_WORKSPACE")
+        return new, old
+    for b, s in ((1, 0.3), (63, 1e-3), (64, 0.2), (65, 0.4), (1000, 0.8), (4099, 0.1)):
+        x, y = spd_points(b, n, s, g).to(dev), spd_points(b, n, s, g).to(dev)
+        if b >= 63:                              # pairs the inverse iteration hands back (their whole 64-pair chunk goes)
+            y[5] = 1.7 * x[5]                    # all sixteen eigenvalues equal
+            y[40] = x[40]                        # all zero: zero subgradient
+            lam = torch.linspace(-0.3, 0.9, n, dtype=torch.float64)
+            lam[4:10] = lam[4] + 1e-11 * torch.arange(6, dtype=torch.float64)          # a six-fold block
+            q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+            lx = torch.linalg.cholesky(x[50].cpu())
+            y[50] = (lx @ (torch.eye(n, dtype=torch.float64) + (q * lam) @ q.T) @ lx.T).to(dev)
+            y[50] = 0.5 * (y[50] + y[50].T)
+        go = (torch.rand(b, generator=g, dtype=torch.float64) + 0.5).to(dev)
+        (rows_n, out_n), (rows_o, out_o) = both(lambda: ops.spd_backward_rows(x, y, grad_out=go, want_out=True))
+        ops.check_status(dev)
+        assert rel_err(out_n.cpu(), out_o.cpu(), atol=1e-14) < 1e-10, (b, s)
+        scale_ = rows_o.abs().reshape(2 * b, -1).max(1).values.clamp_min(1e-300).cpu()
+        diff = (rows_n - rows_o).abs().reshape(2 * b, -1).max(1).values.cpu()
+        assert (diff / scale_).max() < 1e-8, (b, s, float((diff / scale_).max()))
+        if b >= 63:
+            assert float(out_n[40]) == 0.0 and float(rows_n[40].abs().max()) == 0.0
+            assert abs(float(out_n[5]) - 4.0 * abs(np.log(1.7))) < 1e-12
+    # in-kernel scatter through a table, fused loss and scale gradient; explicit persistent workspace; a replayed graph
+    table = spd_points(300, n, 0.3, g).to(dev)
+    b = 2000
+    trip = torch.stack((torch.randint(0, 300, (b,), generator=g), torch.randint(0, 300, (b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    sc = torch.tensor([1.7], dtype=torch.float64, device=dev)
+
+    def scatter(workspace=None):
+        grad = torch.zeros_like(table)
+        loss, gs = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+        out = ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, grad_scale=gs, want_out=True,
+                                    workspace=workspace)
+        return grad, loss, gs, out
+    new, old = both(scatter)
+    ops.check_status(dev)
+    big = float(old[0].abs().max())
+    assert float((new[0] - old[0]).abs().max()) < 1e-10 * big
+    assert abs(float(new[1] - old[1])) < 1e-11 * abs(float(old[1])) and abs(float(new[2] - old[2])) < 1e-9 * abs(float(old[2]))
+    ws = torch.empty(int(lib.sympa_spd_backward_workspace_bytes(b, n)), dtype=torch.uint8, device=dev)
+    again = scatter(ws)
+    assert float((again[0] - new[0]).abs().max()) < 1e-12 * big          # (atomics: not bitwise)
+    with pytest.raises(ValueError):
+        scatter(ws[:1000])
+    grad = torch.zeros_like(table)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, workspace=ws)       # warm
+    grad.zero_(); loss.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, workspace=ws)
+    grad.zero_(); loss.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float((grad - new[0]).abs().max()) < 1e-12 * big and abs(float(loss - new[1])) < 1e-12 * abs(float(new[1]))
+    ops.check_status(dev)
