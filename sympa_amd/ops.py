@@ -952,6 +952,10 @@ def _spd_bwd_workspace(lib, b, n, dev, flags, workspace):
     FLAG_COOP / FLAG_GENERIC keep the kernels that need none."""
     if (flags & (FLAG_COOP | FLAG_GENERIC)) or os.environ.get("SYMPA_SPD_BWD_NO_WORKSPACE"):
         return None, 0
+    # four launches instead of one: below ~1 000 pairs the launch latencies outweigh the saved QL (measured equal at 4 099);
+    # a caller that hands over its own workspace gets the three-kernel path whatever the batch
+    if workspace is None and b < int(os.environ.get("SYMPA_SPD_BWD_WORKSPACE_MIN", "1024")):
+        return None, 0
     need = int(lib.sympa_spd_backward_workspace_bytes(int(b), int(n)))
     if need <= 0:
         return None, 0

@@ -534,6 +534,8 @@ def test_gpu_spd16_three_kernel_backward_against_the_ql_kernel(monkeypatch):
     lib = _lib.load()
     assert lib.sympa_spd_backward_workspace_bytes(1000, 16) > 0 and lib.sympa_spd_backward_workspace_bytes(1000, 12) == 0
 
+    monkeypatch.setenv("SYMPA_SPD_BWD_WORKSPACE_MIN", "1")        # (the binding keeps batches below 1 024 pairs on the old kernel)
+
     def both(fn):
         monkeypatch.delenv("SYMPA_SPD_BWD_NO_WORKSPACE", raising=False)
         new = fn()
