@@ -132,7 +132,9 @@ def _check_spd_fwd(model, n, dev):
 def _check_spd_bwd(model, n, dev):
     from sympa_amd import ops
     res = []
-    for b in (333, 8192 + 5):       # from 8 192 pairs on the default is the kernel that runs the QL of two rounds together
+    # 333: the single-round kernel (also what finishes flagged chunks behind the three-kernel path); 8 197: n = 16 the
+    # three-kernel path (eigenvectors one pair per lane, from 1 024 pairs on), other n the QL of two rounds run together
+    for b in (333, 8192 + 5):
         table, trip, gd = _inputs("spd", n, dev, b)
         idx = torch.cat((trip[:, 0], trip[:, 1])).contiguous()
 

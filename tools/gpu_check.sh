@@ -69,5 +69,9 @@ echo "== round 4: per-call host cost of the two bindings, --launch direct, the r
 timeout 300 python3 tools/host_call_time.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_call.txt
 timeout 300 python bench.py --launch direct --steps 2000 --warmup 200 --no-cpu-baseline --no-live-traffic 2>$OUT/bench_direct.err | tail -1 | tee $OUT/bench_direct.json | cut -c1-260
 timeout 600 python3 tools/dist_step_time.py 24 2>&1 | grep "us/step" | tee $OUT/dist_step.txt
+echo "== round 4: spd n = 16 backward, three kernels (eigenvectors one pair per lane) against the QL-with-vectors kernel"
+{ timeout 600 python3 tools/spd_bwd3_ab.py 1048576 2>&1 | grep -v amdgpu.ids | tail -2; timeout 300 python3 tools/spd_bwd3_ab.py 65536 2>&1 | grep -v amdgpu.ids | tail -2; } | tee $OUT/spd_bwd3_ab.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_spd_bwd3 -- python3 tools/spd_bwd3_ab.py 1048576 > $OUT/prof_spd_bwd3.log 2>&1
+find $OUT/prof_spd_bwd3 -name "*kernel_stats.csv" | head -1 | xargs -r head -7 | cut -c1-220
 echo "== gpu_check status: FAIL=$FAIL"
 exit $FAIL
