@@ -191,11 +191,13 @@ class GradientExchange:
         on a Siegel table only (the step is issued per shard, not through optimizer.step())."""
         from sympa_amd import ops
         from sympa_amd.manifolds.siegel_manifold import SiegelManifold
+        from sympa_amd.manifolds.spd import SymmetricPositiveDefinite
         from sympa_amd.optim import RiemannianSGD
         table = self.table
         manifold = getattr(table, "manifold", None)
-        if not isinstance(opt, RiemannianSGD) or not isinstance(manifold, SiegelManifold):
-            raise TypeError("sharded_step: sympa_amd.optim.RiemannianSGD on a table of a Siegel manifold")
+        spd = isinstance(manifold, SymmetricPositiveDefinite)
+        if not isinstance(opt, RiemannianSGD) or not (spd or isinstance(manifold, SiegelManifold)):
+            raise TypeError("sharded_step: sympa_amd.optim.RiemannianSGD on a table of a Siegel or the spd manifold")
         inv = 1.0 / self.world
         self._reduce_scatter(self.shard_grad, self.table_grad_padded)
         if self.small_tail.numel() and self.world > 1:
@@ -215,8 +217,12 @@ class GradientExchange:
         tg = groups[id(table)]
         if k > 0:
             rows = table.data[r0:r0 + k]
-            ops.rsgd_step_(rows, self.shard_grad[:k], manifold.model_name, tg["lr"], tg.get("weight_decay", 0.0),
-                           counter=manifold.projected_counter(table.device), clip_sqnorm=self.sq, max_norm=max_grad_norm)
+            if spd:          # geoopt's SPD step: retr(x, -lr x sym(g + wd x) x), one kernel over the shard
+                ops.spd_rsgd_step_(rows, self.shard_grad[:k], tg["lr"], tg.get("weight_decay", 0.0), clip_sqnorm=self.sq,
+                                   max_norm=max_grad_norm)
+            else:
+                ops.rsgd_step_(rows, self.shard_grad[:k], manifold.model_name, tg["lr"], tg.get("weight_decay", 0.0),
+                               counter=manifold.projected_counter(table.device), clip_sqnorm=self.sq, max_norm=max_grad_norm)
             self.shard_send[:k].copy_(rows)
         for p in self.params:
             if p is not table:

@@ -413,9 +413,11 @@ class DistributedTrainStep:
         from sympa_amd.optim import RiemannianSGD
         man = model.manifold
         table = model.embeddings.embeds
-        if getattr(man, "model_name", None) not in ("upper", "bounded"):
-            raise NotImplementedError("DistributedTrainStep: Siegel models (the step-counter backward kernels); the spd model "
-                                      "runs the eager exchange of tools/train_siegel.py")
+        if getattr(man, "model_name", None) not in ("upper", "bounded", "spd"):
+            raise NotImplementedError("DistributedTrainStep: the Siegel models and spd")
+        self.spd = man.model_name == "spd"
+        if self.spd and mode == "rows":
+            raise NotImplementedError("DistributedTrainStep: the spd model exchanges dense or sharded (configs[4]: 2 B > N)")
         if not isinstance(optimizer, RiemannianSGD):
             raise NotImplementedError("DistributedTrainStep: sympa_amd.optim.RiemannianSGD")
         self.model, self.opt, self.dist = model, optimizer, dist
@@ -430,7 +432,7 @@ class DistributedTrainStep:
         # precomputed order + fixed-order scalar sums instead of fp64 atomics -- every rank's local gradient is bitwise
         # reproducible (the collective's own summation order is the backend's), and at large batches it is also the faster
         # form (GraphedTrainStep: 55 against 63 us at 65 536 triplets).  None: taken from 32 768 triplets per batch on.
-        det_ok = self.mode in ("dense", "sharded") and table.shape[2] <= 6
+        det_ok = self.mode in ("dense", "sharded") and not self.spd and table.shape[2] <= 6
         if deterministic is None:
             deterministic = det_ok and self.batch_size >= 32768
         if deterministic and not det_ok:
@@ -455,7 +457,15 @@ class DistributedTrainStep:
         # the optimiser side: one fused launch where the table qualifies (after GradientExchange: .grad are its views)
         self._extra = [p for p in self.params if p is not table]
         self._fused = None
-        if self.mode != "sharded" and ops.FusedStep.supported(table.data) and len(self._extra) <= 2 and \
+        if self.spd:
+            # the spd backward has no batch window of its own: the batch of the step is gathered from the loaded shard by two
+            # index_selects on the device step counter (capturable torch ops), and the three-kernel backward gets a persistent
+            # workspace (a replayed graph must not allocate)
+            self.ids_b = torch.zeros(self.batch_size, 2, dtype=torch.int64, device=device)
+            self.gd_b = torch.ones(self.batch_size, dtype=torch.float64, device=device)
+            need = int(ops._lib.load().sympa_spd_backward_workspace_bytes(self.batch_size, table.shape[1]))
+            self.spd_ws = torch.empty(need, dtype=torch.uint8, device=device) if need > 0 else None
+        if not self.spd and self.mode != "sharded" and ops.FusedStep.supported(table.data) and len(self._extra) <= 2 and \
                 all(p.numel() <= 64 for p in self._extra):
             self._fused = ops.FusedStep(table.data, table.grad, man.model_name, [(p.data, p.grad) for p in self._extra],
                                         counter=self.counter, projected=man.projected_counter(table.device), zero_grads=True)
@@ -480,13 +490,20 @@ class DistributedTrainStep:
     def _backward(self):
         m, man, ex = self.model, self.model.manifold, self.ex
         table = m.embeddings.embeds
-        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
-        weights = man.metric.weights if wsum else None
-        gw = weights.grad if wsum else None
         gs = m.scale.grad if m.scale.requires_grad else None
         b = self.batch_size
         if not self.accumulate_loss:
             self.loss.zero_()
+        if self.spd:
+            sel = self.arange + self.counter * b
+            torch.index_select(self.ids, 0, sel, out=self.ids_b)
+            torch.index_select(self.gd, 0, sel, out=self.gd_b)
+            ops.spd_loss_backward(table.data, self.ids_b, table.grad, graph_dist=self.gd_b, scale=m.scale.data,
+                                  scale_coef=m.scale_coef, loss_scale=1.0, loss=self.loss, grad_scale=gs, workspace=self.spd_ws)
+            return
+        wsum = man.metric.kind is MetricType.WEIGHTED_SUM
+        weights = man.metric.weights if wsum else None
+        gw = weights.grad if wsum else None
         if self.mode == "rows":
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,

@@ -7,6 +7,7 @@ collectives are device tensors, the kernels are the product's.
                                 sympa_amd.distributed.GradientExchange in `dense`, `rows` or `sharded` mode: rank r takes
                                 triplets r::world of the global batch, backward, exchange, clip + RiemannianSGD; rank 0 saves
                                 the resulting parameters
+    (exchange_spd / graphed_spd: the same for configs[4]'s model, spd n = 16, dense or sharded)
     graphed <mode> <out dir>    the same through sympa_amd.train_step.DistributedTrainStep (replayed graphs around the
                                 collective), three steps; graphed_det: with the deterministic local accumulation
     ddp <out dir>               the reference's own wrapper (train.py:59): DistributedDataParallel(Model) over RCCL at world
@@ -30,7 +31,12 @@ def toy_model(manifold, metric, dims, nodes, dev, seed=1):
     A.scale_coef, A.scale_init, A.train_scale = 2.0, 1.5, True
     m = Model(A)
     with torch.no_grad():
-        m.embeddings.embeds.data = data.trained_like_table(nodes, dims, model=manifold, seed=seed)
+        if manifold == "spd":
+            g = torch.Generator().manual_seed(seed)
+            a = torch.randn(nodes, dims, dims, generator=g, dtype=torch.float64) * 0.3
+            m.embeddings.embeds.data = torch.matrix_exp(0.5 * (a + a.transpose(-1, -2)))
+        else:
+            m.embeddings.embeds.data = data.trained_like_table(nodes, dims, model=manifold, seed=seed)
     return m.to(dev)
 
 
@@ -41,6 +47,7 @@ def global_batch(nodes, pairs, step=0):
 
 
 SHAPE = dict(manifold="upper", metric="wsum", dims=3, nodes=150, pairs=1024, lr=0.05, max_norm=0.7)
+SHAPE_SPD = dict(manifold="spd", metric="riem", dims=16, nodes=150, pairs=1024, lr=0.01, max_norm=0.7)     # configs[4]'s model
 
 
 def main():
@@ -57,6 +64,8 @@ def main():
         from sympa_amd.distributed import GradientExchange
         from sympa_amd.optim import RiemannianSGD
         S = SHAPE
+        if what.endswith("_spd"):
+            what, S = what[:-4], SHAPE_SPD
         if what in ("exchange", "graphed", "graphed_det"):
             mode, out = sys.argv[2], sys.argv[3]
             m = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
@@ -94,10 +103,11 @@ def main():
             dist.all_reduce(tot)                     # device tensor through the group's backend
             torch.cuda.synchronize()
             if rank == 0:
+                wts = m.manifold.metric.weights.detach().cpu() if S["manifold"] != "spd" else torch.zeros(1)
                 torch.save({"table": m.embeddings.embeds.detach().cpu(), "scale": m.scale.detach().cpu(),
-                            "weights": m.manifold.metric.weights.detach().cpu(), "loss": tot.cpu(), "world": world,
+                            "weights": wts, "loss": tot.cpu(), "world": world,
                             "steps": steps, "graphs_per_step": getattr(locals().get("st"), "graphs_per_step", None)},
-                           os.path.join(out, f"{what}_{mode}.pt"))
+                           os.path.join(out, f"{what}_{mode}{'_spd' if S is SHAPE_SPD else ''}.pt"))
         elif what == "ddp":
             out = sys.argv[2]
             from torch.nn.parallel import DistributedDataParallel

@@ -72,13 +72,13 @@ def test_bench_two_ranks_on_one_gpu_shard_rank_by_rank_and_merge_to_the_single_p
     ops.check_status(dev)
 
 
-def _single_process_step(mode_steps, dev):
+def _single_process_step(mode_steps, dev, spd=False):
     """What ONE process computes for the union batch: DDP's mean over 2 ranks of the per-rank loss sums = half the union's
     gradient (loss_scale 0.5), learning rate x 2 (train.py:136), clip + RiemannianSGD."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gpu_dist_worker as w
     from sympa_amd.optim import RiemannianSGD
-    S = w.SHAPE
+    S = w.SHAPE_SPD if spd else w.SHAPE
     m = w.toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
     opt = RiemannianSGD(m.parameters(), lr=S["lr"] * 2, weight_decay=0.0, stabilize=None)
     total = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -167,3 +167,20 @@ def test_reference_ddp_wrapper_around_the_mirrored_model(tmp_path):
     assert len(res) >= 3
     for name, err in res.items():
         assert err < 1e-12, (name, err)
+
+
+@pytest.mark.parametrize("what,mode", [("exchange_spd", "dense"), ("exchange_spd", "sharded"), ("graphed_spd", "dense"),
+                                       ("graphed_spd", "sharded")])
+def test_two_rank_spd_training_step_equals_the_single_process_step(tmp_path, what, mode):
+    """configs[4]'s model (spd, n = 16: the three-kernel backward with its workspace) through the data-parallel step in two
+    processes sharing cuda:0 over gloo -- GradientExchange directly and the replayed DistributedTrainStep (the batch of a step
+    gathered from the loaded shard by the device step counter) -- == the single-process step(s) on the union batch."""
+    _torchrun(2, [WORKER, what, mode, str(tmp_path)])
+    got = torch.load(os.path.join(str(tmp_path), f"{what[:-4]}_{mode}_spd.pt"))
+    assert got["world"] == 2
+    steps = got["steps"]
+    dev = torch.device("cuda:0")
+    m, loss = _single_process_step(steps, dev, spd=True)
+    assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-10)
+    assert _close(got["scale"], m.scale.detach().cpu(), 1e-10)
+    assert _close(got["loss"], loss.cpu(), 1e-10)

@@ -33,7 +33,10 @@ def fresh(manifold, metric, n, nodes):
     A.scale_coef, A.scale_init, A.train_scale = 1.0, 1.0, True
     m = Model(A)
     with torch.no_grad():
-        m.embeddings.embeds.data = data.trained_like_table(nodes, n, model=manifold, seed=1)
+        if manifold == "spd":
+            m.embeddings.embeds.data = data.spd_table(nodes, n, seed=1)
+        else:
+            m.embeddings.embeds.data = data.trained_like_table(nodes, n, model=manifold, seed=1)
     return m.to(dev)
 
 
@@ -50,7 +53,12 @@ def timed(step, trip, batch):
 
 
 for name, manifold, metric, n, nodes, batch in (("headline", "upper", "riem", 4, 5041, 65536),
-                                                ("cartesian", "upper", "riem", 8, 45500, 262144)):
+                                                ("cartesian", "upper", "riem", 8, 45500, 262144),
+                                                ("custom-spd", "spd", "riem", 16, 100000, 1048576)):
+    if os.environ.get("WORKLOADS") and name not in os.environ["WORKLOADS"].split(","):
+        continue
+    if name == "custom-spd":
+        steps = min(steps, 6)
     trip = torch.stack((torch.randint(0, nodes, (batch * steps,), generator=g), torch.randint(0, nodes, (batch * steps,), generator=g),
                         torch.randint(1, 9, (batch * steps,), generator=g)), 1).to(dev)
     rows = []
@@ -78,7 +86,7 @@ for name, manifold, metric, n, nodes, batch in (("headline", "upper", "riem", 4,
         rows.append((form, timed(st, trip, batch), ""))
     for mode, cap, det in (("dense", True, False), ("dense", False, False), ("dense", True, True), ("rows", False, False),
                            ("sharded", True, False), ("sharded", True, True)):
-        if det and n > 6:
+        if (det and (n > 6 or manifold == "spd")) or (manifold == "spd" and mode == "rows"):
             continue
         m = fresh(manifold, metric, n, nodes)
         opt = RiemannianSGD(m.parameters(), lr=1e-4)

@@ -63,7 +63,7 @@ def train(args, log=print):
     dstep = None
     if world > 1 or args.grad_exchange != "none":
         mode = "auto" if args.grad_exchange == "none" else args.grad_exchange
-        if args.graph_step and args.optim == "rsgd" and args.manifold in ("upper", "bounded"):
+        if args.graph_step and args.optim == "rsgd" and args.manifold in ("upper", "bounded", "spd") and mode != "rows":
             # round 4: the step with the exchange in the middle is replayed too -- backward graph, the collective on the same
             # stream (captured inside the graph where the backend enqueues it: RCCL), optimiser graph; an epoch's shard is
             # loaded once and addressed through the device step counter
