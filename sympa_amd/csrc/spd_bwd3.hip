@@ -18,11 +18,12 @@ int launch3(const SpdBwdArgs& a, void* workspace, int64_t workspace_bytes, hipSt
     hipLaunchKernelGGL(spd_bwd3_front_kernel<M>, dim3(grid), dim3(64), 0, s, a, rounds, ws);
     hipLaunchKernelGGL(spd_bwd3_eig_kernel<M>, dim3((unsigned)chunks), dim3(64), 0, s, a.b, ws, flags);
     hipLaunchKernelGGL(spd_bwd3_back_kernel<M>, dim3(grid), dim3(64), 0, s, a, rounds, ws, flags);
-    // the pairs of flagged chunks (a block of more than INVIT_KEEP + 1 close eigenvalues): the QL-with-vectors kernel on the
-    // same block -> pairs mapping; every other block leaves at once
+    // the pairs of flagged chunks (a block of more than INVIT_KEEP + 1 close eigenvalues): the QL-with-vectors kernel, ONE round per
+    // wave (a flagged chunk becomes sixteen waves of 75 us instead of one wave of 1.2 ms at the tail of the step); every other
+    // block leaves at once
     SpdBwdArgs m = a;
     m.only_if = flags;
-    hipLaunchKernelGGL(spd_coop_bwd_kernel<M>, dim3(grid), dim3(64), 0, s, m, rounds);
+    hipLaunchKernelGGL(spd_coop_bwd_kernel<M>, dim3((unsigned)((a.b + 3) / 4)), dim3(64), 0, s, m, 1);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

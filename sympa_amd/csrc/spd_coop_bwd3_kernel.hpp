@@ -153,7 +153,8 @@ __global__ __launch_bounds__(64) void spd_bwd3_eig_kernel(const int64_t b, doubl
     }
     out[W::DIST] = dist;
     out[W::DIST + 1] = (ok ? 1.0 : 0.0) + (conv ? 2.0 : 0.0);
-    const bool fallback = __ballot(live && !small_blocks) != 0ull;
+    // (dist = 0, y = x: every weight F_k, H_k is zero, so the vectors do not matter -- no reason to hand the chunk back)
+    const bool fallback = __ballot(live && !small_blocks && dist > 0.0) != 0ull;
     if (lane == 0) chunk_flags[blockIdx.x] = fallback ? 1 : 0;
 }
 

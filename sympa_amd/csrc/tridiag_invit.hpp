@@ -51,7 +51,7 @@ SYMPA_UNROLL
         const double hi = (i < M - 1) ? fabs(e[i]) : 0.0;
         onenrm = fmax(onenrm, fabs(d[i]) + lo + hi);
     }
-    onenrm = fmax(onenrm, 1e-300);
+    onenrm = fmax(onenrm, 1e-250);           // T = 0 (y = x): eps ||T|| must stay a normal number, its reciprocal finite
     const double ortol = 1e-3 * onenrm;
     const double pivtiny = EPS * onenrm;
     double prev[INVIT_KEEP][M];

@@ -86,9 +86,16 @@ class GradientExchange:
         if mode == "sharded":
             self.rows_per = (n_rows + self.world - 1) // self.world
             pad = (self.rows_per * self.world - n_rows) * table[0].numel()
-        total = sum(p.numel() for p in self.params) + pad
-        self.flat = torch.zeros(total, dtype=torch.float64, device=dev)
+        # every parameter's gradient view starts on a 256-byte boundary of the flat buffer: the table's 16 n^2-byte gradient rows
+        # then sit on cache-line boundaries like a tensor of their own (a one-element scale in front of the table had put
+        # every row 8 bytes off: the fp64-atomic scatter touched two lines per 128 bytes, spd n = 16 backward 7.6 -> 9.5 ms)
+        ALIGN = 32                                     # doubles
+
+        def up(k):
+            return -(-k // ALIGN) * ALIGN
         order = self.params if mode != "sharded" else [table] + [p for p in self.params if p is not table]
+        total = sum(up(p.numel() + (pad if p is table else 0)) for p in order)
+        self.flat = torch.zeros(total, dtype=torch.float64, device=dev)
         off = 0
         views = {}
         self._small = []           # (offset, numel) of everything but the table, for the "rows" / "sharded" modes
@@ -100,10 +107,10 @@ class GradientExchange:
             views[id(p)] = v
             if p is table:
                 self._table_span = (off, p.numel())
-                off += pad
+                off += up(p.numel() + pad)             # sharded: the padding rows (and the alignment gap) stay zero
             else:
                 self._small.append((off, p.numel()))
-            off += p.numel()
+                off += up(p.numel())
         self._views = [views[id(p)] for p in self.params]
         self.local_batch = int(local_batch)
         self.small = None
