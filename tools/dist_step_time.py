@@ -81,7 +81,7 @@ for name, manifold, metric, n, nodes, batch in (("headline", "upper", "riem", 4,
                 for _ in range(steps):
                     st(ids, gd)
                 torch.cuda.synchronize()
-                rows.append(("single-GPU classic graph (eight lanes per pair backward)", (time.perf_counter() - t0) / steps, ""))
+                rows.append(("single-GPU classic graph (one call per batch)", (time.perf_counter() - t0) / steps, ""))
             continue
         rows.append((form, timed(st, trip, batch), ""))
     for mode, cap, det in (("dense", True, False), ("dense", False, False), ("dense", True, True), ("rows", False, False),
