@@ -390,7 +390,7 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
                             double* loss, double* grad_x_rows, double* grad_y_rows, double* grad_scale, double* out,
                             int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 /* workspace (both backward entries; caller-owned device scratch, 16-byte aligned, may be NULL): with at least
- * sympa_spd_backward_workspace_bytes(b, n) bytes the THREE-PHASE kernel runs where it is built (n = 16, csrc/
+ * sympa_spd_backward_workspace_bytes(b, n) bytes the THREE-KERNEL backward runs where it is built (n = 9..16, csrc/
  * spd_coop_bwd3_kernel.hpp): Householder form sixteen lanes per pair, then eigenvalues (lockstep QL) and eigenvectors (inverse
  * iteration) ONE PAIR PER LANE with the vectors parked in the workspace, then the gradient rows sixteen lanes per pair again --
  * 3x the kernel that runs the QL with accumulated rotations in the sixteen-lanes layout; pairs with a block of more than four

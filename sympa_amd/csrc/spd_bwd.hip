@@ -194,7 +194,7 @@ int sympa_spd_backward_rows(const double* x, const double* y, int64_t num_rows, 
 }
 
 int64_t sympa_spd_backward_workspace_bytes(int64_t b, int n) {
-    if (b <= 0 || n != 16) return 0;                      // the three-phase kernel is instantiated for n = 16
+    if (b <= 0 || n < 9 || n > 16) return 0;               // the three-kernel backward is instantiated for n = 9..16
     return spd_bwd3_workspace_bytes(b, n);
 }
 

@@ -1,5 +1,5 @@
-// Three-phase SPD backward (spd_coop_bwd3_kernel.hpp): instantiations and the launcher.  One translation unit so that the
-// build compiles it beside the other spd units.
+// Three-kernel SPD backward (spd_coop_bwd3_kernel.hpp): instantiations n = 13..16 and the launcher (n = 9..12: spd_bwd3_lo.hip,
+// the same source with SYMPA_BWD3_LO, so that the build compiles the two halves in parallel).
 #include "spd_coop_bwd3_kernel.hpp"
 
 namespace sympa_hip {
@@ -30,11 +30,27 @@ int launch3(const SpdBwdArgs& a, void* workspace, int64_t workspace_bytes, hipSt
 }
 }  // namespace
 
+#ifndef SYMPA_BWD3_LO
+bool launch_spd_bwd3_lo(const SpdBwdArgs& a, int n, void* workspace, int64_t workspace_bytes, hipStream_t s, int* rc);
 bool launch_spd_bwd3(const SpdBwdArgs& a, int n, void* workspace, int64_t workspace_bytes, hipStream_t s, int* rc) {
     switch (n) {
+        case 13: *rc = launch3<13>(a, workspace, workspace_bytes, s); return true;
+        case 14: *rc = launch3<14>(a, workspace, workspace_bytes, s); return true;
+        case 15: *rc = launch3<15>(a, workspace, workspace_bytes, s); return true;
         case 16: *rc = launch3<16>(a, workspace, workspace_bytes, s); return true;
+        default: return launch_spd_bwd3_lo(a, n, workspace, workspace_bytes, s, rc);
+    }
+}
+#else
+bool launch_spd_bwd3_lo(const SpdBwdArgs& a, int n, void* workspace, int64_t workspace_bytes, hipStream_t s, int* rc) {
+    switch (n) {
+        case 9: *rc = launch3<9>(a, workspace, workspace_bytes, s); return true;
+        case 10: *rc = launch3<10>(a, workspace, workspace_bytes, s); return true;
+        case 11: *rc = launch3<11>(a, workspace, workspace_bytes, s); return true;
+        case 12: *rc = launch3<12>(a, workspace, workspace_bytes, s); return true;
         default: return false;
     }
 }
+#endif
 
 }  // namespace sympa_hip

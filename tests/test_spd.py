@@ -532,7 +532,7 @@ def test_gpu_spd16_three_kernel_backward_against_the_ql_kernel(monkeypatch):
     n = 16
     g = torch.Generator().manual_seed(2024)
     lib = _lib.load()
-    assert lib.sympa_spd_backward_workspace_bytes(1000, 16) > 0 and lib.sympa_spd_backward_workspace_bytes(1000, 12) == 0
+    assert lib.sympa_spd_backward_workspace_bytes(1000, 16) > 0 and lib.sympa_spd_backward_workspace_bytes(1000, 8) == 0
 
     monkeypatch.setenv("SYMPA_SPD_BWD_WORKSPACE_MIN", "1")        # (the binding keeps batches below 1 024 pairs on the old kernel)
 
@@ -599,3 +599,45 @@ def test_gpu_spd16_three_kernel_backward_against_the_ql_kernel(monkeypatch):
     torch.cuda.synchronize()
     assert float((grad - new[0]).abs().max()) < 1e-12 * big and abs(float(loss - new[1])) < 1e-12 * abs(float(new[1]))
     ops.check_status(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [9, 10, 11, 12, 13, 14, 15])
+def test_gpu_spd_three_kernel_backward_every_size(monkeypatch, n):
+    """Every other instantiation of the three-kernel backward (n = 9..15; lanes r >= n of a group are phantoms) against the
+    QL-with-vectors kernel: rows form with a y = c x pair and a y = x pair mixed in, and the in-kernel scatter."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("SYMPA_SPD_BWD_WORKSPACE_MIN", "1")
+    g = torch.Generator().manual_seed(300 + n)
+    b = 1500
+    x, y = spd_points(b, n, 0.4, g).to(dev), spd_points(b, n, 0.4, g).to(dev)
+    y[7] = 2.5 * x[7]
+    y[900] = x[900]
+    go = (torch.rand(b, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    rows_n, out_n = ops.spd_backward_rows(x, y, grad_out=go, want_out=True)
+    monkeypatch.setenv("SYMPA_SPD_BWD_NO_WORKSPACE", "1")
+    rows_o, out_o = ops.spd_backward_rows(x, y, grad_out=go, want_out=True)
+    monkeypatch.delenv("SYMPA_SPD_BWD_NO_WORKSPACE")
+    ops.check_status(dev)
+    assert rel_err(out_n.cpu(), out_o.cpu(), atol=1e-14) < 1e-10
+    scale_ = rows_o.abs().reshape(2 * b, -1).max(1).values.clamp_min(1e-300).cpu()
+    diff = (rows_n - rows_o).abs().reshape(2 * b, -1).max(1).values.cpu()
+    assert (diff / scale_).max() < 1e-8, float((diff / scale_).max())
+    assert float(out_n[900]) == 0.0 and float(rows_n[900].abs().max()) == 0.0
+    assert abs(float(out_n[7]) - np.sqrt(n) * np.log(2.5)) < 1e-12
+    table = spd_points(200, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, 200, (b,), generator=g), torch.randint(0, 200, (b,), generator=g)), 1).to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    res = []
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("SYMPA_SPD_BWD_NO_WORKSPACE", "1")
+        grad = torch.zeros_like(table)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.spd_loss_backward(table, trip, grad, graph_dist=gd, loss=loss)
+        res.append((grad, float(loss)))
+    monkeypatch.delenv("SYMPA_SPD_BWD_NO_WORKSPACE")
+    ops.check_status(dev)
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-10 * float(res[1][0].abs().max())
+    assert abs(res[0][1] - res[1][1]) < 1e-11 * abs(res[1][1])

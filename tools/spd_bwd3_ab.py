@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""SPD backward at n = 16: the three-phase kernel (eigenvectors one pair per lane by inverse iteration, vectors parked in a
+"""SPD backward (n = 16 by default): the three-kernel form (eigenvectors one pair per lane by inverse iteration, vectors parked in a
 caller-owned workspace; csrc/spd_coop_bwd3_kernel.hpp) against the kernel that runs the QL with accumulated rotations in the
 sixteen-lanes layout -- same inputs, gradients compared, both timed.
-    python tools/spd_bwd3_ab.py [pairs] [rows]"""
+    python tools/spd_bwd3_ab.py [pairs] [rows] [n = 9..16]"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ from sympa_amd import data, ops  # noqa: E402
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
-n = 16
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 dev = torch.device("cuda:0")
 table = data.spd_table(rows, n, seed=42).to(dev)
 trip = data.sample_pairs(rows, b, 0, 42).to(dev)
