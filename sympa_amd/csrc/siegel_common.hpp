@@ -21,6 +21,7 @@ constexpr int BLOCK = 256;
 #ifndef SYMPA_FWD_WAVE_BLOCK_FROM
 #define SYMPA_FWD_WAVE_BLOCK_FROM 5
 #endif
+constexpr int SYMPA_INTERNAL_FLAG_STAGGER = 0x4000;      // set by the forward launcher, never by callers (siegel_dist_kernel.hpp)
 constexpr int fwd_block(int n) { return n >= SYMPA_FWD_WAVE_BLOCK_FROM ? 64 : BLOCK; }
 
 struct DistArgs {

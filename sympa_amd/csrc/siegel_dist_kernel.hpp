@@ -14,8 +14,11 @@ namespace sympa_hip {
 // identical to the product kernel unless a variant is being measured.
 // dims 5..8: the bounded model gathers only the chunks that hold upper-triangle elements through three ring buffers, the
 // upper model whole rows through two (siegel_gather.hpp: measured per model)
+#ifndef SYMPA_FWD_MASK_UPPER
+#define SYMPA_FWD_MASK_UPPER 0
+#endif
 template <int MODEL>
-constexpr bool pass_masked() { return MODEL != sympa::MODEL_UPPER; }
+constexpr bool pass_masked() { return MODEL != sympa::MODEL_UPPER || SYMPA_FWD_MASK_UPPER; }
 
 template <int N, int MODEL, bool LOWLDS>
 struct BlockLds {
@@ -106,6 +109,18 @@ template <int N, int MODEL> constexpr int fwd_min_blocks() {
 template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
 __global__ __launch_bounds__(fwd_block(N), (fwd_min_blocks<N, MODEL>())) void siegel_dist_kernel(const DistArgs a) {
     __shared__ v2d lds[(fwd_block(N) / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
+    // Staggered first round (dims 7, 8 on tables that do not fit the L2s; the launcher sets the bit): a lone launch starts one wave
+    // on every SIMD at the same instant, all of them gather their 128 KB of rows at once, compute in step and come back for the
+    // next round together -- 134 MB bursts on a fabric that then idles.  CU j of every XCD (blocks 32 j .. 32 j + 31 of the first
+    // 1 024) starts j x 0.6 us late; the rounds stay out of step from there on.  Upper n = 8, 262 144 pairs, 45 500 rows:
+    // 151.1 -> 134.4 us (profiles/r04_fwd_stagger.txt); flat 133.5-134 us for every table from 16 MB up, equal at 10 MB,
+    // +4-8 % on L2-resident tables (hence the size test), no gain for the bounded model (more arithmetic per byte).
+    if constexpr (N >= 7) {
+        if ((a.flags & SYMPA_INTERNAL_FLAG_STAGGER) && blockIdx.x < 1024u) {
+            const int k = (int)((blockIdx.x >> 5) & 31u);
+            for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
+        }
+    }
     dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * fwd_block(N), lds);
 }
 
@@ -176,17 +191,22 @@ template <int N>
 int launch_n(const DistArgs& a, int model, hipStream_t s) {
     constexpr int FB = fwd_block(N);
     const unsigned grid = (unsigned)((a.b + FB - 1) / FB);
+    DistArgs st = a;
+    st.flags &= ~SYMPA_INTERNAL_FLAG_STAGGER;             // an internal bit: never taken from the caller
+    if (N >= 7 && model == SYMPA_MODEL_UPPER && a.idx1 != nullptr && a.ap_cols == 0 && grid >= 2048u &&
+        a.num_rows * (int64_t)(16 * N * N) >= ((int64_t)12 << 20) && !(a.flags & SYMPA_FLAG_ANY_ORDER))
+        st.flags |= SYMPA_INTERNAL_FLAG_STAGGER;          // two rounds or more of a table beyond the L2s: see the kernel
     // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
     const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256 * (BLOCK / FB));
     hipError_t e;
     if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
-        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, FB, a, s);
+        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, FB, st, s);
     } else if (model == SYMPA_MODEL_UPPER) {
-        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, FB, a, s);
-        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, FB, a, s);
+        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, FB, st, s);
+        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, FB, st, s);
     } else {
-        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>, grid, FB, a, s);
-        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>, grid, FB, a, s);
+        if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, true>, grid, FB, st, s);
+        else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_BOUNDED, false>, grid, FB, st, s);
     }
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
