@@ -117,8 +117,16 @@ __global__ __launch_bounds__(fwd_block(N), (fwd_min_blocks<N, MODEL>())) void si
     // +4-8 % on L2-resident tables (hence the size test), no gain for the bounded model (more arithmetic per byte).
     if constexpr (N >= 7) {
         if ((a.flags & SYMPA_INTERNAL_FLAG_STAGGER) && blockIdx.x < 1024u) {
-            const int k = (int)((blockIdx.x >> 5) & 31u);
-            for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
+#ifndef SYMPA_FWD_STAGGER_S
+#define SYMPA_FWD_STAGGER_S 20
+#endif
+#ifndef SYMPA_FWD_STAGGER_MAP
+#define SYMPA_FWD_STAGGER_MAP 0
+#endif
+            int k = (int)((blockIdx.x >> 5) & 31u);
+            if (SYMPA_FWD_STAGGER_MAP == 1) k = (int)(__builtin_bitreverse32((unsigned)k) >> 27);
+            if (SYMPA_FWD_STAGGER_MAP == 2) k = (k & 1) ? 31 - (k >> 1) : (k >> 1);            // 0, 31, 1, 30, ...
+            for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_FWD_STAGGER_S);
         }
     }
     dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * fwd_block(N), lds);
