@@ -72,6 +72,9 @@ extern "C" {
                               SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels there;
                               sympa_spd_backward_rows: the single-round kernel instead of the one that runs the QL of two
                               rounds together */
+#define SYMPA_FLAG_SPLIT 64 /* backward entries, dims 5..8, with a workspace: run the split (two-kernel, one pair per lane) backward
+                             * wherever it is built -- by default it runs only where it measured faster than the one-launch kernels
+                             * (upper model, dims 7 and 8: profiles/r04_n8_backward_split.txt) */
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
@@ -180,6 +183,19 @@ int sympa_all_pairs_dist_packed(const double* table, int64_t num_rows, int n, in
                                 double scale_coef, double* out, void* workspace, int64_t workspace_bytes,
                                 int32_t* status, int flags, void* stream);
 
+/* workspace (every backward entry below; caller-owned device scratch, 16-byte aligned, may be NULL): with at least
+ * sympa_siegel_backward_workspace_bytes(b, n, model) bytes the SPLIT backward runs where it is built (dims 5..8, csrc/
+ * siegel_bwd_split_kernel.hpp): ONE PAIR PER LANE in two kernels -- (1) factors, E, H = E^H E, Householder + QL with eigenvectors,
+ * metric value, fused loss, Hbar = V diag(phi) V^H and K = Hbar H scaled by go * scale into the workspace ([entry][pair] layout);
+ * (2) factors and E again from the table rows, Ebar = 2 E Hbar, G = Ebar E^H / 2, the solves and congruences, scatter / rows.  The
+ * whole adjoint in one lane spills ~1100 registers at n = 8 and the eight-lanes-per-pair kernel repeats the scalar QL in the lanes
+ * of a pair; the split form does neither (fused step, upper n = 8, 262 144 pairs: 1.42 -> 0.81 ms).  It is the default where it
+ * measured faster (upper model, dims 7, 8); SYMPA_FLAG_SPLIT runs it for every model and dims 5..8.  NULL / too small /
+ * SYMPA_FLAG_GENERIC / SYMPA_FLAG_COOP: the other kernels, as before (same results to ~1e-11 relative: the split form takes the
+ * spectral weights from the QL's eigenvalues instead of the Rayleigh quotients ||E v_i||^2).  Returns 0 where no kernel uses one.
+ * Replaces the reference's autograd through siegel_manifold.py:41-72 (runner.py:105). */
+int64_t sympa_siegel_backward_workspace_bytes(int64_t b, int n, int model);
+
 /* Backward of manifold.dist for pre-gathered points: what torch autograd computes through
  * siegel_manifold.py:41-72 / bounded_domain.py:27-39 when runner.py:105 calls loss.backward().
  *   grad_out          [b] fp64 dLoss/d(dist)
@@ -188,7 +204,7 @@ int sympa_all_pairs_dist_packed(const double* table, int64_t num_rows, int n, in
  */
 int sympa_siegel_dist_bwd(const double* z1, const double* z2, const double* grad_out, int64_t b, int n, int model,
                           int metric, const double* metric_w, double eps, double* grad_z1, double* grad_z2,
-                          double* grad_w, int32_t* status, int flags, void* stream);
+                          double* grad_w, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 
 /* Backward of Model.forward (sympa/model.py:16-41 under runner.py:105): recomputes the distances and
  * ACCUMULATES (fp64 atomics; zero the buffers first)
@@ -200,7 +216,7 @@ int sympa_model_backward(const double* table, int64_t num_rows, int n, const int
                          const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                          const double* metric_w, double eps, const double* scale, double scale_coef,
                          const double* grad_out, double* grad_table, double* grad_w, double* grad_scale,
-                         double* out, int32_t* status, int flags, void* stream);
+                         double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 
 /* One fused training step of the reference's loop (sympa/runner.py:98-105 with sympa/losses.py:10-19):
  *   d = Model.forward(triplets);  loss = loss_scale * sum |(d / graph_dist)^2 - 1|;  loss.backward()
@@ -212,7 +228,7 @@ int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, cons
                               const int64_t* dst, int64_t dst_stride, const double* graph_dist, int64_t b, int model,
                               int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
                               double loss_scale, double* loss, double* grad_table, double* grad_w, double* grad_scale,
-                              double* out, int32_t* status, int flags, void* stream);
+                              double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 
 /* The same fused step with the table gradient left in per-pair form (no scatter): grad_src_rows[i] / grad_dst_rows[i]
  * ([b, 2, n, n] each, written) are the gradient rows of table[src[i]] / table[dst[i]] contributed by pair i.  This is
@@ -226,7 +242,7 @@ int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n,
                                    int64_t b, int model, int metric, const double* metric_w, double eps,
                                    const double* scale, double scale_coef, double loss_scale, double* loss,
                                    double* grad_src_rows, double* grad_dst_rows, double* grad_w, double* grad_scale,
-                                   double* out, int32_t* status, int flags, void* stream);
+                                   double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 int sympa_scatter_add_rows(const double* rows, const int64_t* idx, int64_t idx_stride, int64_t count, int n,
                            int64_t num_rows, double alpha, double* grad_table, int32_t* status, void* stream);
 /* the same for rows of any length (spd: row_doubles = n^2) */
@@ -306,7 +322,7 @@ int sympa_model_train_backward(const double* table, int64_t num_rows, int n, con
                                const int64_t* step_counter, int model, int metric, const double* metric_w, double eps,
                                const double* scale, double scale_coef, double loss_scale, double* loss, double* grad_table,
                                double* grad_rows, double* grad_w, double* grad_scale, double* wave_partials, int32_t* status,
-                               int flags, void* stream);
+                               void* workspace, int64_t workspace_bytes, int flags, void* stream);
 
 /* Deterministic counterpart of sympa_scatter_add_flat_rows ("sort-by-row + segmented sum"):
  *   grad_table[r] (= | +=, by `accumulate`) alpha * sum_{p in [rowptr[r], rowptr[r + 1])} rows[order[p]]     r = 0 .. num_rows - 1

@@ -25,6 +25,7 @@ SYMBOLS = (
     "sympa_all_pairs_dist",
     "sympa_all_pairs_workspace_bytes",
     "sympa_all_pairs_dist_packed",
+    "sympa_siegel_backward_workspace_bytes",
     "sympa_siegel_dist_bwd",
     "sympa_model_backward",
     "sympa_model_loss_backward",
@@ -141,27 +142,31 @@ def load():
     lib.sympa_siegel_dist_bwd.restype = ctypes.c_int
     lib.sympa_siegel_dist_bwd.argtypes = [
         _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+        _c_double_p, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_void_p,
     ]
+    lib.sympa_siegel_backward_workspace_bytes.restype = ctypes.c_int64
+    lib.sympa_siegel_backward_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     lib.sympa_model_backward.restype = ctypes.c_int
     lib.sympa_model_backward.argtypes = [
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
-        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_void_p,
     ]
     lib.sympa_model_loss_backward.restype = ctypes.c_int
     lib.sympa_model_loss_backward.argtypes = [
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
         ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
-        ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_int,
-        ctypes.c_void_p,
+        ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
     ]
     lib.sympa_model_loss_backward_rows.restype = ctypes.c_int
     lib.sympa_model_loss_backward_rows.argtypes = [
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
         ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
         ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_i32_p,
-        ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
     ]
     lib.sympa_scatter_add_rows.restype = ctypes.c_int
     lib.sympa_scatter_add_rows.argtypes = [_c_double_p, _c_i64_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
@@ -180,7 +185,7 @@ def load():
         _c_double_p, ctypes.c_int64, ctypes.c_int, _c_i64_p, ctypes.c_int64, _c_i64_p, ctypes.c_int64, _c_double_p,
         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_double, _c_double_p,
         ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
-        _c_i32_p, ctypes.c_int, ctypes.c_void_p,
+        _c_i32_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
     ]
     lib.sympa_segment_sum_rows.restype = ctypes.c_int
     lib.sympa_segment_sum_rows.argtypes = [

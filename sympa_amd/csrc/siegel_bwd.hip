@@ -1,10 +1,11 @@
 // gfx950 backward kernels + C-ABI (sympa_siegel_dist_bwd, sympa_model_backward, sympa_model_loss_backward).
 #include "siegel_coop_bwd_kernel.hpp"
+#include "siegel_bwd_split_kernel.hpp"
 
 namespace {
 using namespace sympa_hip;
 
-int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
+int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* workspace, int64_t workspace_bytes, void* stream) {
     const int rc = validate(a.f, model, n);
     if (rc != 0) return rc;
     if (a.f.b == 0) return 0;
@@ -17,6 +18,17 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
     // dims 5..8, SYMPA_FLAG_GENERIC forces the one-pair-per-lane kernels.
     // the deterministic per-wave sums exist in the one-pair-per-lane kernels only (dims <= 8); the training graph's batch
     // window (step_counter) in every kernel family but the rolled one-lane kernels of dims 9..16
+    // dims 5..8 with a workspace: the split backward (siegel_bwd_split_kernel.hpp), ONE pair per lane in two kernels -- the
+    // eigen-decomposition with vectors is no longer redundant in the lanes of a pair (fused step, upper n = 8, 262 144 pairs:
+    // 1.42 ms eight lanes per pair -> 0.81 ms, profiles/r04_n8_backward_split.txt).  SYMPA_FLAG_GENERIC / SYMPA_FLAG_COOP or no
+    // (or too small a) workspace: the kernels below, as before.
+    // Default where measured faster (tools/bwd_split_ab.py, fused step): upper n = 7 200 against 266 us (one pair per lane, one
+    // kernel) per 65 536 pairs, n = 8 811 against 1 421 us (eight lanes per pair) per 262 144; dims 5, 6 fit one lane's registers
+    // in one kernel (81 / 116 against 115 / 141 us) and the bounded model's second stage still spills (n = 8: 2.83 against 2.05 ms).
+    if (n >= 5 && n <= 8 && workspace != nullptr && !(a.f.flags & (SYMPA_FLAG_GENERIC | SYMPA_FLAG_COOP)) &&
+        ((model == SYMPA_MODEL_UPPER && n >= 7) || (a.f.flags & SYMPA_FLAG_SPLIT)) &&
+        bwd_split_available(n, model) && workspace_bytes >= bwd_split_workspace_bytes(a.f.b, n, model))
+        return launch_bwd_split(a, n, model, scatter, workspace, workspace_bytes, s);
     const bool det_mode = a.wave_partials != nullptr;
     if (det_mode && n > 8) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "wave_partials: dims 1..8");
     const bool one_lane = (a.f.flags & SYMPA_FLAG_GENERIC) || instance_fallback(SYMPA_FAMILY_SIEGEL_BWD, model, n) || det_mode;
@@ -50,9 +62,11 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* stream) {
 
 extern "C" {
 
+int64_t sympa_siegel_backward_workspace_bytes(int64_t b, int n, int model) { return bwd_split_workspace_bytes(b, n, model); }
+
 int sympa_siegel_dist_bwd(const double* z1, const double* z2, const double* grad_out, int64_t b, int n, int model,
                           int metric, const double* metric_w, double eps, double* grad_z1, double* grad_z2,
-                          double* grad_w, int32_t* status, int flags, void* stream) {
+                          double* grad_w, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     BwdArgs a;
     std::memset(&a, 0, sizeof(a));
     a.f.base1 = z1;
@@ -69,14 +83,14 @@ int sympa_siegel_dist_bwd(const double* z1, const double* z2, const double* grad
     a.g1 = grad_z1;
     a.g2 = grad_z2;
     a.gw = grad_w;
-    return launch_bwd(a, n, model, false, stream);
+    return launch_bwd(a, n, model, false, workspace, workspace_bytes, stream);
 }
 
 int sympa_model_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                          const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                          const double* metric_w, double eps, const double* scale, double scale_coef,
                          const double* grad_out, double* grad_table, double* grad_w, double* grad_scale,
-                         double* out, int32_t* status, int flags, void* stream) {
+                         double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     if (b > 0 && (src == nullptr || dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null index buffer");
     if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
     if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
@@ -103,14 +117,14 @@ int sympa_model_backward(const double* table, int64_t num_rows, int n, const int
     a.g2 = grad_table;
     a.gw = grad_w;
     a.gscale = grad_scale;
-    return launch_bwd(a, n, model, true, stream);
+    return launch_bwd(a, n, model, true, workspace, workspace_bytes, stream);
 }
 
 int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
                               const int64_t* dst, int64_t dst_stride, const double* graph_dist, int64_t b, int model,
                               int metric, const double* metric_w, double eps, const double* scale, double scale_coef,
                               double loss_scale, double* loss, double* grad_table, double* grad_w, double* grad_scale,
-                              double* out, int32_t* status, int flags, void* stream) {
+                              double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     if (b > 0 && (src == nullptr || dst == nullptr || graph_dist == nullptr))
         return fail(SYMPA_ERR_BAD_ARG, "null index / graph-distance buffer");
     if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
@@ -140,7 +154,7 @@ int sympa_model_loss_backward(const double* table, int64_t num_rows, int n, cons
     a.graph_dist = graph_dist;
     a.loss = loss;
     a.loss_scale = loss_scale;
-    return launch_bwd(a, n, model, true, stream);
+    return launch_bwd(a, n, model, true, workspace, workspace_bytes, stream);
 }
 
 int sympa_model_train_backward(const double* table, int64_t num_rows, int n, const int64_t* src, int64_t src_stride,
@@ -148,7 +162,7 @@ int sympa_model_train_backward(const double* table, int64_t num_rows, int n, con
                                const int64_t* step_counter, int model, int metric, const double* metric_w, double eps,
                                const double* scale, double scale_coef, double loss_scale, double* loss, double* grad_table,
                                double* grad_rows, double* grad_w, double* grad_scale, double* wave_partials, int32_t* status,
-                               int flags, void* stream) {
+                               void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     if (b > 0 && (src == nullptr || dst == nullptr || graph_dist == nullptr))
         return fail(SYMPA_ERR_BAD_ARG, "null index / graph-distance buffer");
     if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
@@ -183,11 +197,11 @@ int sympa_model_train_backward(const double* table, int64_t num_rows, int n, con
     if (grad_table != nullptr) {
         a.g1 = grad_table;
         a.g2 = grad_table;
-        return launch_bwd(a, n, model, true, stream);
+        return launch_bwd(a, n, model, true, workspace, workspace_bytes, stream);
     }
     a.g1 = grad_rows;
     a.g2 = grad_rows + b * 2 * (int64_t)n * n;
-    return launch_bwd(a, n, model, false, stream);
+    return launch_bwd(a, n, model, false, workspace, workspace_bytes, stream);
 }
 
 int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n, const int64_t* src,
@@ -195,7 +209,7 @@ int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n,
                                    int64_t b, int model, int metric, const double* metric_w, double eps,
                                    const double* scale, double scale_coef, double loss_scale, double* loss,
                                    double* grad_src_rows, double* grad_dst_rows, double* grad_w, double* grad_scale,
-                                   double* out, int32_t* status, int flags, void* stream) {
+                                   double* out, int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     if (b > 0 && (src == nullptr || dst == nullptr || graph_dist == nullptr))
         return fail(SYMPA_ERR_BAD_ARG, "null index / graph-distance buffer");
     if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
@@ -225,7 +239,7 @@ int sympa_model_loss_backward_rows(const double* table, int64_t num_rows, int n,
     a.graph_dist = graph_dist;
     a.loss = loss;
     a.loss_scale = loss_scale;
-    return launch_bwd(a, n, model, false, stream);
+    return launch_bwd(a, n, model, false, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

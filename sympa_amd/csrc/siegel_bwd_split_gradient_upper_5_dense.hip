@@ -1,0 +1,7 @@
+// Split Siegel backward, stage 2 (factors and E again, products / solves / congruences from Hbar, K): upper model, n = 5,
+// per-pair gradient rows.  One kernel per translation unit.  See siegel_bwd_split_kernel.hpp.
+#include "siegel_bwd_split_kernel.hpp"
+
+namespace sympa_hip {
+int launch_bwd_split_gradient_upper_5_dense(const SplitArgs& sa, hipStream_t s) { return launch_bwd_split_gradient<5, sympa::MODEL_UPPER, false>(sa, s); }
+}  // namespace sympa_hip

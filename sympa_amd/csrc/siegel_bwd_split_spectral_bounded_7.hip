@@ -1,0 +1,7 @@
+// Split Siegel backward, stage 1 (eigen-decomposition with vectors -> Hbar, K): bounded model, n = 7, one pair per lane.
+// One kernel per translation unit (the unrolled kernels compile in parallel).  See siegel_bwd_split_kernel.hpp.
+#include "siegel_bwd_split_kernel.hpp"
+
+namespace sympa_hip {
+int launch_bwd_split_spectral_bounded_7(const SplitArgs& sa, hipStream_t s) { return launch_bwd_split_spectral<7, sympa::MODEL_BOUNDED>(sa, s); }
+}  // namespace sympa_hip

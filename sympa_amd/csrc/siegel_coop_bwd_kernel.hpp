@@ -125,6 +125,9 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
             });
             e[M - 1] = 0.0;
         }
+#ifdef SYMPA_BWD_FRONT_ONLY          // measurement hook: the front alone (gather, factors, E, Gram matrix, Householder form)
+        if (lane < 64) { loss_acc += d[0] + e[0] + vr[0] + vi[0] + bk[0] + phr[M - 1] + phi_[M - 1]; continue; }
+#endif
         // the QL below runs redundantly in the sixteen lanes of the pair and its predicates must agree bit for bit
 #pragma unroll
         for (int j = 0; j < M; ++j) { d[j] = bcast<0>(d[j]); e[j] = bcast<0>(e[j]); }

@@ -1,0 +1,377 @@
+// The Siegel adjoint (siegel_math_bwd.hpp) cut in two at its narrowest point, for dims 5..8, ONE PAIR PER LANE.
+//
+// Why: the whole adjoint of an 8 x 8 pair keeps E, V, both factors and two or three products alive at once (~600 doubles
+// against 256 per lane), so the one-kernel form spills ~1100 registers to scratch, and the lanes-per-pair form that avoids the
+// spills (siegel_coop_bwd_kernel.hpp, eight lanes per pair) runs every scalar recurrence -- the QL above all -- redundantly
+// in the eight lanes of a pair and issues every cross-lane FMA twice (profiles/r04_n8_backward_split.txt: front 22 %, QL 34 %,
+// the products and solves behind it 43 % of 1.51 ms per 262 144 pairs).  With
+//     Hbar = V diag(phi) V^H   (Hermitian n x n)    and    K = V diag(phi lambda) V^H = Hbar H
+// everything behind the eigen-decomposition is a function of E, the factors and these two matrices:
+//     Ebar = 2 E Hbar,   G = E Hbar E^H = Ebar E^H / 2,   Dbar = L1^-H Ebar conj(L2)^-1,   A1bar = -L1^-H G L1^-1,
+//     A2bar = -L2^-H conj(K) L2^-1
+// so the adjoint is two stages that share nothing but `AdjPack` (100 doubles per pair at n = 8, upper model):
+//   stage 1 (pair_adjoint_spectral): factors, E, H = E^H E, eigen-decomposition WITH vectors (Householder + QL, one pair per
+//            lane: 64 pairs per instruction stream), metric value, spectral weights with go = 1, Hbar and K.  E and the
+//            factors are dead before the eigenvectors exist.
+//   stage 2 (pair_adjoint_gradient): factors and E AGAIN from the table rows (cheap one pair per lane: ~2.6 k instructions),
+//            then the products, solves and congruences above, scaled by go * scale.
+// The two stages are separate kernels (siegel_bwd_split_kernel.hpp) with the packs in a caller-owned workspace laid out
+// [entry][pair]: every load and store of the workspace is a contiguous 512 bytes per wave.
+//
+// Difference from pair_backward: the eigenvalues that enter phi are the QL's (accurate to eps ||H||), not the Rayleigh
+// quotients ||E v_i||^2 -- E is gone when the vectors exist.  An eigenvalue below ~1e-12 lambda_max therefore loses
+// relative accuracy in phi_i ~ lambda_i^-1/2 (riem: phi_i ~ v_i dv_i / d stays 2 / d whatever lambda_i > 0 is); the dispatcher keeps
+// the lanes-per-pair kernel reachable (SYMPA_FLAG_GENERIC / no workspace) and the tests compare the two.
+#pragma once
+
+#include "siegel_math_bwd.hpp"
+
+namespace sympa {
+
+template <int N, int MODEL>
+struct AdjPack {
+    static constexpr int OFFD = N * (N - 1) / 2;
+    static constexpr int H_D = 0;                       // Hbar: diagonal [N]
+    static constexpr int H_RE = N;                      //       strict upper triangle, row-major (j < k), real parts
+    static constexpr int H_IM = N + OFFD;               //       ... imaginary parts
+    static constexpr int K_D = N + 2 * OFFD;            // K:    diagonal
+    static constexpr int K_RE = K_D + N;                //       strict upper, real
+    static constexpr int K_IM = K_RE + OFFD;            //       strict upper, imaginary (bounded model only)
+    static constexpr int LEN = K_RE + OFFD + (MODEL == MODEL_UPPER ? 0 : OFFD);
+};
+SYMPA_HD constexpr int offd_index(int n, int j, int k) { return j * n - j * (j + 1) / 2 + (k - j - 1); }   // j < k
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1.  Returns the metric value (NaN for non-finite input); pack = Hbar, K for go = 1; gw[k] += d out / d w_k.
+// ---------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+SYMPA_HD double pair_adjoint_spectral(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
+                                      double inv_eps, double (&pack)[AdjPack<N, MODEL>::LEN], double (&gw)[N], int& status) {
+    using P = AdjPack<N, MODEL>;
+    constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
+    Herm<N> h;
+    bool ok;
+    {
+        Tri<N, CPLX> l1, l2;
+        CMat<N> e;
+        if constexpr (MODEL == MODEL_UPPER) {
+            ok = chol_real<N>(z1.im, l1);
+            ok = chol_real<N>(z2.im, l2) && ok;
+        } else {
+            ok = chol_id_minus_wwh<N>(z1, l1);
+            ok = chol_id_minus_wwh<N>(z2, l2) && ok;
+        }
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) {
+                e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+            }
+        solve_left<N, CPLX>(l1, e);
+        solve_right_t<N, CPLX>(l2, e);
+        gram<N>(e, h);
+    }
+    CMat<N> v;
+    bool conv;
+    if constexpr (N >= 5) conv = herm_eigen_vectors_ql<N>(h, v);
+    else conv = herm_eigen_vectors<N>(h, v);
+
+    double phi[N], philam[N];
+    bool finite;
+    double out = spectral_adjoint<N, MODEL>(h.d, metric, w, inv_eps, 1.0, phi, philam, gw, finite);
+
+    // Hbar_jk = sum_i phi_i V_ji conj(V_ki),  K_jk = sum_i phi_i lambda_i V_ji conj(V_ki)      (j <= k)
+SYMPA_UNROLL
+    for (int j = 0; j < N; ++j) {
+SYMPA_UNROLL
+        for (int k = j; k < N; ++k) {
+            double hr = 0.0, hi = 0.0, kr = 0.0, ki = 0.0;
+SYMPA_UNROLL
+            for (int i = 0; i < N; ++i) {
+                const double pr = d_fma(v.re[j][i], v.re[k][i], v.im[j][i] * v.im[k][i]);     // Re V_ji conj(V_ki)
+                hr = d_fma(phi[i], pr, hr);
+                kr = d_fma(philam[i], pr, kr);
+                if (k > j) {
+                    const double pi = d_fma(v.im[j][i], v.re[k][i], -v.re[j][i] * v.im[k][i]);
+                    hi = d_fma(phi[i], pi, hi);
+                    if (CPLX) ki = d_fma(philam[i], pi, ki);
+                }
+            }
+            if (k == j) {
+                pack[P::H_D + j] = hr;
+                pack[P::K_D + j] = kr;
+            } else {
+                pack[P::H_RE + offd_index(N, j, k)] = hr;
+                pack[P::H_IM + offd_index(N, j, k)] = hi;
+                pack[P::K_RE + offd_index(N, j, k)] = kr;
+                if constexpr (CPLX) pack[P::K_IM + offd_index(N, j, k)] = ki;
+            }
+        }
+    }
+    if (!finite) out = __builtin_nan("");     // non-finite input: the forward value is NaN like the gradients
+    if (!ok) status |= ST_NOT_PD;
+    if (!conv) status |= ST_NO_CONVERGENCE;
+    if (!d_finite(out)) status |= ST_NONFINITE;
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2.  pack: Hbar and K as written by stage 1 (any common factor -- go * scale -- may have been applied to all of it:
+// the gradients are linear in the pack).  g1, g2: the symmetric matrix gradients.
+// ---------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+SYMPA_HD void pair_adjoint_gradient(const CMat<N>& z1, const CMat<N>& z2, const double (&pack)[AdjPack<N, MODEL>::LEN],
+                                    CMat<N>& g1, CMat<N>& g2) {
+    using P = AdjPack<N, MODEL>;
+    constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
+    Tri<N, CPLX> l1, l2;
+    CMat<N> e;
+    if constexpr (MODEL == MODEL_UPPER) {
+        (void)chol_real<N>(z1.im, l1);
+        (void)chol_real<N>(z2.im, l2);
+    } else {
+        (void)chol_id_minus_wwh<N>(z1, l1);
+        (void)chol_id_minus_wwh<N>(z2, l2);
+    }
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+            e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+        }
+    solve_left<N, CPLX>(l1, e);
+    solve_right_t<N, CPLX>(l2, e);
+
+    CMat<N> ebar, a1, a2;
+    {
+        CMat<N> hbar;
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            hbar.re[j][j] = pack[P::H_D + j];
+            hbar.im[j][j] = 0.0;
+SYMPA_UNROLL
+            for (int k = j + 1; k < N; ++k) {
+                const double hr = pack[P::H_RE + offd_index(N, j, k)], hi = pack[P::H_IM + offd_index(N, j, k)];
+                hbar.re[j][k] = hr; hbar.im[j][k] = hi;
+                hbar.re[k][j] = hr; hbar.im[k][j] = -hi;
+            }
+        }
+        cmatmul<N>(e, hbar, 2.0, ebar);           // Ebar = 2 E Hbar
+    }
+    cmatmul_bh<N>(ebar, e, 0.5, a1);              // G = E Hbar E^H
+    solve_lh_left<N, CPLX>(l1, ebar);             // Dbar = L1^-H Ebar conj(L2)^-1
+    solve_l_right<N, CPLX, true>(l2, ebar);
+SYMPA_UNROLL
+    for (int j = 0; j < N; ++j) {
+        a2.re[j][j] = pack[P::K_D + j];
+        a2.im[j][j] = 0.0;
+SYMPA_UNROLL
+        for (int k = j + 1; k < N; ++k) {
+            const double kr = pack[P::K_RE + offd_index(N, j, k)];
+            double ki = 0.0;
+            if constexpr (CPLX) ki = -pack[P::K_IM + offd_index(N, j, k)];      // conj(K)
+            a2.re[j][k] = kr; a2.im[j][k] = ki;
+            a2.re[k][j] = kr; a2.im[k][j] = -ki;
+        }
+    }
+    neg_congruence<N, CPLX>(l1, a1);              // A1bar = -L1^-H G L1^-1
+    neg_congruence<N, CPLX>(l2, a2);              // A2bar = -L2^-H conj(K) L2^-1
+
+    if (MODEL == MODEL_UPPER) {
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) {
+                const double dr = 0.5 * (ebar.re[i][j] + ebar.re[j][i]);
+                const double di = 0.5 * (ebar.im[i][j] + ebar.im[j][i]);
+                g2.re[i][j] = dr;
+                g2.im[i][j] = di + a2.re[i][j];
+                g1.re[i][j] = -dr;
+                g1.im[i][j] = -di + a1.re[i][j];
+            }
+    } else {
+        // Wbar_1 = -Dbar - 2 A1bar W1,  Wbar_2 = Dbar - 2 A2bar W2, then symmetrise each plane
+        CMat<N> t1, t2;
+        cmatmul<N>(a1, z1, -2.0, t1);
+        cmatmul<N>(a2, z2, -2.0, t2);
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) {
+                t1.re[i][j] -= ebar.re[i][j]; t1.im[i][j] -= ebar.im[i][j];
+                t2.re[i][j] += ebar.re[i][j]; t2.im[i][j] += ebar.im[i][j];
+            }
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) {
+                g1.re[i][j] = 0.5 * (t1.re[i][j] + t1.re[j][i]);
+                g1.im[i][j] = 0.5 * (t1.im[i][j] + t1.im[j][i]);
+                g2.re[i][j] = 0.5 * (t2.re[i][j] + t2.re[j][i]);
+                g2.im[i][j] = 0.5 * (t2.im[i][j] + t2.im[j][i]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2 of the upper model in an order that fits one lane's registers (256 doubles) at n = 8: never more than E / Ebar
+// (128) + Hbar (64) + one row (16) at once.  The generic form above keeps E, Ebar, G, K and both factors alive together and
+// spills ~530 doubles at n = 8.
+//   1. factors, E = L1^-1 (Z2 - Z1) L2^-T; the factors are parked (`park(k, l)`: the caller's LDS, n(n+1)/2 doubles each)
+//      -- rebuilding them from Y later was tried first and lost to its loads: a lane-per-row re-read of Y touches 64
+//      cache lines per instruction and the rows have left the L2 by then (gradient kernel 468 -> see profiles/r04_n8_backward_split.txt);
+//   2. row i = 0 .. n-1:  F = E_i Hbar,  Re G_ij = Re F conj(E_j) for j >= i (rows j >= i of E are still E) -> `put_g`
+//      (the caller's workspace, in the slots of Hbar it has read by then),  then Ebar_i = 2 F over E_i;
+//   3. Dbar = L1^-T Ebar L2^-1 in place (real factors: the two planes separately), the factors back from the park;
+//   4. Re planes: g2 = sym(Re Dbar), g1 = -g2;  Im planes: g2 = sym(Im Dbar) - L2^-T Re K L2^-1,  g1 = -sym(Im Dbar) - L1^-T Re G L1^-1;
+//   5. the four planes leave at the very end -> `stage(matrix)` puts a plane into the caller's staging tile (the LDS the factors
+//      have left by then), `flush(point, plane, sign)` adds / stores the staged plane: atomics and stores count in the same
+//      in-order memory counter as loads, so a load (K, a spilled register) issued behind a plane's 64 atomics waits for all of
+//      them -- with the planes interleaved with step 4 the kernel spent half its cycles there (profiles/r04_n8_backward_split.txt).
+// pk(k): entry k of the pack (read when it is needed, not before).  Only upper triangles (i <= j) of the emitted matrices
+// are meaningful.
+// ---------------------------------------------------------------------------------------------
+// S = L^-T M L^-1 for symmetric M (full matrix in, upper triangle i <= j of S out, in m)
+template <int N>
+SYMPA_HD void sym_congruence_inv_t(const Tri<N, false>& l, double (&m)[N][N]) {
+    // W = L^-T M: back substitution down the columns
+SYMPA_UNROLL
+    for (int c = 0; c < N; ++c) {
+SYMPA_UNROLL
+        for (int i = N - 1; i >= 0; --i) {
+            double t = m[i][c];
+SYMPA_UNROLL
+            for (int k = i + 1; k < N; ++k) t = d_fma(-l.re[k][i], m[k][c], t);
+            m[i][c] = t * l.rdiag[i];
+        }
+    }
+    // S = W L^-1, row r: x_j = (x_j - sum_{k > j} x_k L_kj) / L_jj -- only j >= r is wanted and needs only k > j
+SYMPA_UNROLL
+    for (int r = 0; r < N; ++r) {
+SYMPA_UNROLL
+        for (int j = N - 1; j >= r; --j) {
+            double t = m[r][j];
+SYMPA_UNROLL
+            for (int k = j + 1; k < N; ++k) t = d_fma(-m[r][k], l.re[k][j], t);
+            m[r][j] = t * l.rdiag[j];
+        }
+    }
+}
+
+template <int N, class Pk, class Park, class Unpark, class PutG, class GetG, class Stage, class Flush>
+SYMPA_HD void pair_adjoint_gradient_upper(const CMat<N>& z1, const CMat<N>& z2, Pk&& pk, Park&& park, Unpark&& unpark,
+                                          PutG&& put_g, GetG&& get_g, Stage&& stage, Flush&& flush) {
+    using P = AdjPack<N, MODEL_UPPER>;
+    CMat<N> e;
+    {
+        Tri<N, false> l1, l2;
+        (void)chol_real<N>(z1.im, l1);
+        (void)chol_real<N>(z2.im, l2);
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) {
+                e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+            }
+        solve_left<N, false>(l1, e);
+        solve_right_t<N, false>(l2, e);
+        park(0, l1);
+        park(1, l2);
+    }
+    {
+        double hd[N], hre[N][N], him[N][N];          // Hbar: diagonal, strict upper triangle (j < k)
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            hd[j] = pk(P::H_D + j);
+SYMPA_UNROLL
+            for (int k = j + 1; k < N; ++k) {
+                hre[j][k] = pk(P::H_RE + offd_index(N, j, k));
+                him[j][k] = pk(P::H_IM + offd_index(N, j, k));
+            }
+        }
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i) {
+            double fr[N], fi[N];
+SYMPA_UNROLL
+            for (int k = 0; k < N; ++k) {
+                double tr = e.re[i][k] * hd[k], ti = e.im[i][k] * hd[k];
+SYMPA_UNROLL
+                for (int m = 0; m < N; ++m) {
+                    if (m == k) continue;
+                    // Hbar_mk = (hre[m][k], him[m][k]) for m < k, the conjugate of Hbar_km otherwise
+                    const double hr = (m < k) ? hre[m][k] : hre[k][m];
+                    const double hi = (m < k) ? him[m][k] : -him[k][m];
+                    tr = d_fma(e.re[i][m], hr, tr); tr = d_fma(-e.im[i][m], hi, tr);
+                    ti = d_fma(e.re[i][m], hi, ti); ti = d_fma(e.im[i][m], hr, ti);
+                }
+                fr[k] = tr; fi[k] = ti;
+            }
+SYMPA_UNROLL
+            for (int j = i; j < N; ++j) {
+                double g = 0.0;
+SYMPA_UNROLL
+                for (int k = 0; k < N; ++k) { g = d_fma(fr[k], e.re[j][k], g); g = d_fma(fi[k], e.im[j][k], g); }
+                put_g(tri_index(N, i, j), g);
+            }
+SYMPA_UNROLL
+            for (int k = 0; k < N; ++k) { e.re[i][k] = 2.0 * fr[k]; e.im[i][k] = 2.0 * fi[k]; }
+        }
+    }
+    // Dbar = L1^-T Ebar L2^-1
+    Tri<N, false> l1, l2;
+    unpark(0, l1);
+    solve_lh_left<N, false>(l1, e);
+    unpark(1, l2);
+    solve_l_right<N, false, true>(l2, e);
+    // sym(Dbar) first (Ebar dies) and its real part goes straight into the caller's staging tile (36 doubles fewer through the
+    // congruences: with them the tail spilled, and a spilled operand reloaded between two planes' atomics waits for every atomic
+    // before it -- the memory counter is in order).  K and G are read when their congruences need them, all before the first
+    // plane leaves.
+    double m[N][N], gg[N][N];
+    {
+        double di[N][N];
+        {
+            double dr[N][N];
+SYMPA_UNROLL
+            for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+                for (int j = i; j < N; ++j) {
+                    dr[i][j] = 0.5 * (e.re[i][j] + e.re[j][i]);
+                    di[i][j] = 0.5 * (e.im[i][j] + e.im[j][i]);
+                }
+            stage(dr);
+        }
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            m[j][j] = pk(P::K_D + j);
+SYMPA_UNROLL
+            for (int k = j + 1; k < N; ++k) { m[j][k] = pk(P::K_RE + offd_index(N, j, k)); m[k][j] = m[j][k]; }
+        }
+        sym_congruence_inv_t<N>(l2, m);
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = i; j < N; ++j) m[i][j] = di[i][j] - m[i][j];
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = i; j < N; ++j) { gg[i][j] = get_g(tri_index(N, i, j)); gg[j][i] = gg[i][j]; }
+        sym_congruence_inv_t<N>(l1, gg);
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = i; j < N; ++j) gg[i][j] = -di[i][j] - gg[i][j];
+    }
+    // the planes leave at the very end, back to back: Re (staged above) to both points, then the two Im planes
+    flush(1, 0, 1.0);
+    flush(0, 0, -1.0);
+    stage(m);
+    flush(1, 1, 1.0);
+    stage(gg);
+    flush(0, 1, 1.0);
+}
+
+}  // namespace sympa

@@ -96,6 +96,7 @@ FLAG_GENERIC = 2      # spd: force the runtime-n one-lane-per-pair kernel
 FLAG_ANY_ORDER = 4    # forward: dispatch without the in-order barrier bit (independent batches of one stream overlap)
 FLAG_COOP = 32        # dims 6, 8: force the sixteen-lanes-per-pair kernel (A/B)
 FLAG_NO_SYMMETRY = 16  # all_pairs_dist(packed=True): evaluate (i, j) and (j, i) separately
+FLAG_SPLIT = 64        # backward, dims 5..8: the split (two-kernel) backward wherever it is built (default: upper model, dims 7, 8)
 FLAG_FUSE = 8         # BatchedForward: up to MAX_FUSED_BATCHES consecutive batches per kernel launch
 MAX_FUSED_BATCHES = 32
 
@@ -315,7 +316,48 @@ class BatchedForward:
             check_status(self.dev)
 
 
-def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None, flags=0):
+def _siegel_bwd_workspace(lib, b, n, model, dev, flags, workspace):
+    """The caller-owned scratch of the split Siegel backward (C-ABI sympa_siegel_backward_workspace_bytes; 0 bytes where no kernel
+    uses one: dims outside 5..8): `workspace` when given (a persistent uint8 tensor: what a replayed graph wants), else a fresh
+    tensor from the caching allocator (stream-ordered; inside a hipGraph capture from the graph's pool).
+    SYMPA_SIEGEL_BWD_NO_WORKSPACE=1 (A/B) and FLAG_COOP / FLAG_GENERIC keep the kernels that need none."""
+    if n < 5 or n > 8 or (flags & (FLAG_COOP | FLAG_GENERIC)) or os.environ.get("SYMPA_SIEGEL_BWD_NO_WORKSPACE"):
+        return None, 0
+    if not ((model == "upper" and n >= 7) or (flags & FLAG_SPLIT)):       # where the library would use it (csrc/siegel_bwd.hip)
+        return None, 0
+    # two launches instead of one: small batches stay with the one-launch kernels unless the caller brings a workspace
+    if workspace is None and not (flags & FLAG_SPLIT) and b < int(os.environ.get("SYMPA_SIEGEL_BWD_WORKSPACE_MIN", "1024")):
+        return None, 0
+    need = int(lib.sympa_siegel_backward_workspace_bytes(int(b), int(n), MODEL_IDS[model]))
+    if need <= 0:
+        return None, 0
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or not workspace.is_cuda or workspace.numel() < need or workspace.data_ptr() % 16:
+            raise ValueError(f"workspace: a 16-byte aligned uint8 device tensor of at least {need} bytes")
+        return workspace, workspace.numel()
+    return torch.empty(need, dtype=torch.uint8, device=dev), need
+
+
+def siegel_backward_workspace(b, n, model, device, flags=0):
+    """A persistent workspace for the backward entries at this (batch, dims, model), or None where the default dispatch would not
+    use one (what a replayed graph holds on to: sympa_amd/train_step.py)."""
+    lib = _lib.load()
+    if n < 5 or n > 8 or (flags & (FLAG_COOP | FLAG_GENERIC)) or os.environ.get("SYMPA_SIEGEL_BWD_NO_WORKSPACE"):
+        return None
+    if not ((model == "upper" and n >= 7) or (flags & FLAG_SPLIT)):
+        return None
+    if not (flags & FLAG_SPLIT) and b < int(os.environ.get("SYMPA_SIEGEL_BWD_WORKSPACE_MIN", "1024")):
+        return None
+    need = int(lib.sympa_siegel_backward_workspace_bytes(int(b), int(n), MODEL_IDS[model]))
+    return torch.empty(need, dtype=torch.uint8, device=device) if need > 0 else None
+
+
+def siegel_backward_workspace_bytes(b, n, model="upper"):
+    """Bytes of scratch the split backward of dims 5..8 wants for a batch of b pairs (0: no kernel uses one)."""
+    return int(_lib.load().sympa_siegel_backward_workspace_bytes(int(b), int(n), MODEL_IDS[model]))
+
+
+def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights=None, eps=None, flags=0, workspace=None):
     """Backward of manifold.dist for pre-gathered points (C-ABI sympa_siegel_dist_bwd).
     Returns (grad_z1, grad_z2, grad_weights or None): what torch autograd produces through the
     reference's dist (runner.py:105 over siegel_manifold.py:41-72)."""
@@ -333,9 +375,11 @@ def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights
     eps = EPS[torch.float64] if eps is None else float(eps)
     st = _status_buf(z1.device)
     if b > 0:
+        ws, ws_bytes = _siegel_bwd_workspace(lib, b, n, model, z1.device, int(flags), workspace)
         with torch.cuda.device(z1.device):
             rc = lib.sympa_siegel_dist_bwd(_ptr(z1), _ptr(z2), _ptr(go), b, n, MODEL_IDS[model], METRIC_IDS[metric],
-                                           _ptr(w), eps, _ptr(g1), _ptr(g2), _ptr(gw), _ptr(st), int(flags), _stream())
+                                           _ptr(w), eps, _ptr(g1), _ptr(g2), _ptr(gw), _ptr(st), _ptr(ws), ws_bytes, int(flags),
+                                           _stream())
         _lib.check(rc)
     if _debug:
         check_status(z1.device)
@@ -343,7 +387,7 @@ def siegel_dist_backward(z1, z2, grad_out, model="upper", metric="riem", weights
 
 
 def model_backward(table, triplets, grad_out, model="upper", metric="riem", weights=None, scale=None,
-                   scale_coef=1.0, eps=None, grad_table=None, flags=0):
+                   scale_coef=1.0, eps=None, grad_table=None, flags=0, workspace=None):
     """Backward of the fused Model.forward (C-ABI sympa_model_backward): scatter-adds the two gradient
     rows of every pair into a dense [N,2,n,n] gradient (created zeroed unless `grad_table` is given, in
     which case it accumulates), returns (grad_table, grad_weights or None, grad_scale or None)."""
@@ -372,11 +416,12 @@ def model_backward(table, triplets, grad_out, model="upper", metric="riem", weig
     if b > 0:
         src_ptr = ctypes.c_void_p(triplets.data_ptr())
         dst_ptr = ctypes.c_void_p(triplets.data_ptr() + 8)
+        ws, ws_bytes = _siegel_bwd_workspace(lib, b, n, model, tab.device, int(flags), workspace)
         with torch.cuda.device(tab.device):
             rc = lib.sympa_model_backward(_ptr(tab), num_rows, n, src_ptr, stride, dst_ptr, stride, b,
                                           MODEL_IDS[model], METRIC_IDS[metric], _ptr(w), eps, _ptr(sc),
                                           float(scale_coef), _ptr(go), _ptr(grad_table), _ptr(gw), _ptr(gs), None,
-                                          _ptr(st), int(flags), _stream())
+                                          _ptr(st), _ptr(ws), ws_bytes, int(flags), _stream())
         _lib.check(rc)
     if _debug:
         check_status(tab.device)
@@ -384,7 +429,8 @@ def model_backward(table, triplets, grad_out, model="upper", metric="riem", weig
 
 
 def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="upper", metric="riem", weights=None,
-                        grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None, flags=0):
+                        grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None, flags=0,
+                        workspace=None):
     """Fused training step (C-ABI sympa_model_loss_backward): distances + AverageDistortionLoss + all
     gradients in one kernel.  `grad_table` [N,2,n,n], `loss` [1] (and `grad_weights` [n], `grad_scale` [1]
     when given) are ACCUMULATED into, like autograd's .grad."""
@@ -412,13 +458,14 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
     eps = 1e-5 if eps is None else float(eps)
     st = _status_buf(dev)
     tp = triplets.data_ptr()
+    ws, ws_bytes = _siegel_bwd_workspace(lib, b, n, model, dev, int(flags), workspace)
     with torch.cuda.device(dev):
         rc = lib.sympa_model_loss_backward(
             tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, gd.data_ptr(), b, MODEL_IDS[model],
             METRIC_IDS[metric], None if w is None else w.data_ptr(), eps, sc_ptr, float(scale_coef), float(loss_scale),
             loss.data_ptr(), grad_table.data_ptr(), None if grad_weights is None else grad_weights.data_ptr(),
-            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), int(flags),
-            torch.cuda.current_stream(dev).cuda_stream)
+            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(),
+            None if ws is None else ws.data_ptr(), ws_bytes, int(flags), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _lib.check(rc)
     if _debug:
@@ -428,7 +475,7 @@ def model_loss_backward(table, triplets, graph_dist, grad_table, loss, model="up
 
 def model_loss_backward_rows(table, triplets, graph_dist, grad_rows, loss, model="upper", metric="riem", weights=None,
                              grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, eps=None,
-                             flags=0):
+                             flags=0, workspace=None):
     """The fused training step with the table gradient left per pair (C-ABI sympa_model_loss_backward_rows):
     `grad_rows` [2b, 2, n, n] is WRITTEN -- rows [0, b) belong to triplets[:, 0], rows [b, 2b) to triplets[:, 1];
     loss / grad_weights / grad_scale are accumulated as in model_loss_backward."""
@@ -458,14 +505,15 @@ def model_loss_backward_rows(table, triplets, graph_dist, grad_rows, loss, model
     st = _status_buf(dev)
     tp = triplets.data_ptr()
     rowbytes = 2 * n * n * 8
+    ws, ws_bytes = _siegel_bwd_workspace(lib, b, n, model, dev, int(flags), workspace)
     with torch.cuda.device(dev):
         rc = lib.sympa_model_loss_backward_rows(
             tab.data_ptr(), num_rows, n, tp, stride, tp + 8, stride, gd.data_ptr(), b, MODEL_IDS[model],
             METRIC_IDS[metric], None if w is None else w.data_ptr(), eps, sc_ptr, float(scale_coef), float(loss_scale),
             loss.data_ptr(), grad_rows.data_ptr(), grad_rows.data_ptr() + b * rowbytes,
             None if grad_weights is None else grad_weights.data_ptr(),
-            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(), int(flags),
-            torch.cuda.current_stream(dev).cuda_stream)
+            None if grad_scale is None else grad_scale.data_ptr(), None, st.data_ptr(),
+            None if ws is None else ws.data_ptr(), ws_bytes, int(flags), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _lib.check(rc)
     if _debug:
@@ -640,7 +688,7 @@ def radam_step_(table, grad, exp_avg, exp_avg_sq, bias_pows, model, lr, betas=(0
 
 def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper", metric="riem", weights=None,
                          grad_weights=None, scale=None, grad_scale=None, scale_coef=1.0, loss_scale=1.0, grad_table=None,
-                         grad_rows=None, step_counter=None, wave_partials=None, eps=None, flags=0):
+                         grad_rows=None, step_counter=None, wave_partials=None, eps=None, flags=0, workspace=None):
     """The backward half of a training step for replayed graphs (C-ABI sympa_model_train_backward; wave_partials: dims <= 8): pairs
     [c * batch, (c + 1) * batch) of `triplets` [T, >=2] int64 / `graph_dist` [T] fp64, c = step_counter[0] (device int64; None:
     0).  grad_table: atomic scatter into the dense gradient; grad_rows [2 batch, 2, n, n]: per-pair rows (written).
@@ -671,6 +719,7 @@ def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper"
     st = _status_buf(dev)
     tp = triplets.data_ptr()
     stride = triplets.stride(0)
+    ws, ws_bytes = _siegel_bwd_workspace(lib, int(batch), n, model, dev, int(flags), workspace)
     with torch.cuda.device(dev):
         rc = lib.sympa_model_train_backward(
             table.data_ptr(), table.shape[0], n, tp, stride, tp + 8, stride, graph_dist.data_ptr(), int(batch),
@@ -679,7 +728,8 @@ def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper"
             float(loss_scale), loss.data_ptr(), None if grad_table is None else grad_table.data_ptr(),
             None if grad_rows is None else grad_rows.data_ptr(), None if grad_weights is None else grad_weights.data_ptr(),
             None if grad_scale is None else grad_scale.data_ptr(),
-            None if wave_partials is None else wave_partials.data_ptr(), st.data_ptr(), int(flags), _stream())
+            None if wave_partials is None else wave_partials.data_ptr(), st.data_ptr(),
+            None if ws is None else ws.data_ptr(), ws_bytes, int(flags), _stream())
     if rc != 0:
         _lib.check(rc)
     return loss

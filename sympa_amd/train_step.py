@@ -95,6 +95,16 @@ class GraphedTrainStep:
             self.rowptr = torch.zeros(steps, n_rows + 1, dtype=torch.int32, device=dev)
         self.graph = None            # the captured launches hold the old addresses
 
+    def _bwd_ws(self, table, b):
+        """The persistent scratch of the split Siegel backward for batches of b pairs (None where no kernel uses one): a replayed
+        graph must not allocate, so it is made once per batch size and kept."""
+        cache = self.__dict__.setdefault("_bwd_ws_cache", {})
+        key = (int(b), table.shape[2], table.device)
+        if key not in cache:
+            cache[key] = ops.siegel_backward_workspace(b, table.shape[2], self.model.manifold.model_name, table.device) \
+                if table.dim() == 4 else None
+        return cache[key]
+
     def _group_of(self, p):
         for g in self.opt.param_groups:
             if any(p is q for q in g["params"]):
@@ -115,11 +125,11 @@ class GraphedTrainStep:
         if not self.deterministic:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_table=table.grad, step_counter=counter)
+                                     grad_table=table.grad, step_counter=counter, workspace=self._bwd_ws(table, b))
             return
         ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                  None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                 grad_rows=self.rows, step_counter=counter, wave_partials=self.partials)
+                                 grad_rows=self.rows, step_counter=counter, wave_partials=self.partials, workspace=self._bwd_ws(table, b))
         ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=counter,
                               wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
                               loss=self.loss, grad_scale=gs, grad_weights=gw, sq_partials=self.sq_partials)
@@ -223,13 +233,13 @@ class GraphedTrainStep:
         if b > 0 and not self.deterministic:
             ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_table=table.grad)
+                                     grad_table=table.grad, workspace=self._bwd_ws(table, b))
         elif b > 0:
             rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=table.device)
             partials = torch.empty((b + 63) // 64, 2 + n, dtype=torch.float64, device=table.device)
             ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_rows=rows, wave_partials=partials)
+                                     grad_rows=rows, wave_partials=partials, workspace=self._bwd_ws(table, b))
             order, rowptr = ops.sorted_slots(torch.cat((ids[:, 0], ids[:, 1])), table.shape[0])
             ops.segment_sum_rows_(table.grad, rows, order, rowptr, wave_partials=partials, num_waves=(b + 63) // 64,
                                   partial_stride=2 + n, loss=loss, grad_scale=gs, grad_weights=gw,
@@ -480,6 +490,16 @@ class DistributedTrainStep:
             self.rowptr = torch.zeros(steps, self.model.embeddings.embeds.shape[0] + 1, dtype=torch.int32, device=self.device)
         self.graphs = None
 
+    def _bwd_ws(self, table, b):
+        """The persistent scratch of the split Siegel backward for batches of b pairs (None where no kernel uses one): a replayed
+        graph must not allocate, so it is made once per batch size and kept."""
+        cache = self.__dict__.setdefault("_bwd_ws_cache", {})
+        key = (int(b), table.shape[2], table.device)
+        if key not in cache:
+            cache[key] = ops.siegel_backward_workspace(b, table.shape[2], self.model.manifold.model_name, table.device) \
+                if table.dim() == 4 else None
+        return cache[key]
+
     def _group_of(self, p):
         for g in self.opt.param_groups:
             if any(p is q for q in g["params"]):
@@ -507,21 +527,21 @@ class DistributedTrainStep:
         if self.mode == "rows":
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_rows=ex.rows, step_counter=self.counter)
+                                     grad_rows=ex.rows, step_counter=self.counter, workspace=self._bwd_ws(table, b))
             sel = self.arange + self.counter * b                 # the batch's rows of the loaded shard, on the device
             ex.idx[:b].copy_(self.ids[:, 0].index_select(0, sel))
             ex.idx[b:].copy_(self.ids[:, 1].index_select(0, sel))
         elif self.deterministic:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_rows=self.rows, step_counter=self.counter, wave_partials=self.partials)
+                                     grad_rows=self.rows, step_counter=self.counter, wave_partials=self.partials, workspace=self._bwd_ws(table, b))
             ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=self.counter,
                                   wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
                                   loss=self.loss, grad_scale=gs, grad_weights=gw)
         else:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_table=table.grad, step_counter=self.counter)
+                                     grad_table=table.grad, step_counter=self.counter, workspace=self._bwd_ws(table, b))
 
     def _exchange(self):
         ex = self.ex

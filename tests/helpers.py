@@ -59,6 +59,7 @@ def hostsim():
         so = os.path.join(d, "libsympa_hostsim.so")
         srcs = [os.path.join(d, "hostsim.cpp"), os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd.hpp"),
+                os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_bwd_split.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_table_math.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "siegel_math_generic.hpp"),
                 os.path.join(ROOT, "sympa_amd", "csrc", "spd_math.hpp"),
@@ -121,6 +122,29 @@ def hostsim_dist_bwd(z1, z2, go, model, metric, weights=None, eps=1e-5):
                                     MODELS.index(model), METRICS.index(metric), P(w.ctypes.data), ctypes.c_double(eps),
                                     P(out.ctypes.data), P(g1.ctypes.data), P(g2.ctypes.data), P(gw.ctypes.data),
                                     ctypes.byref(st))
+    assert rc == 0, rc
+    return out, g1, g2, gw, st.value
+
+
+def hostsim_dist_bwd_split(z1, z2, go, model, metric, weights=None, eps=1e-5):
+    """The two-stage adjoint of dims 5..8 (siegel_math_bwd_split.hpp: stage 1 -> pack scaled by go -> stage 2) on the CPU build;
+    same returns as hostsim_dist_bwd."""
+    lib = hostsim()
+    P = ctypes.c_void_p
+    z1 = np.ascontiguousarray(z1, dtype=np.float64)
+    z2 = np.ascontiguousarray(z2, dtype=np.float64)
+    go = np.ascontiguousarray(go, dtype=np.float64)
+    b, _, n, _ = z1.shape
+    out = np.zeros(b)
+    g1 = np.zeros_like(z1)
+    g2 = np.zeros_like(z2)
+    gw = np.zeros(n)
+    st = ctypes.c_int32(0)
+    w = np.ascontiguousarray(np.ones(n) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1))
+    rc = lib.sympa_hostsim_dist_bwd_split(P(z1.ctypes.data), P(z2.ctypes.data), P(go.ctypes.data), ctypes.c_int64(b), n,
+                                          MODELS.index(model), METRICS.index(metric), P(w.ctypes.data), ctypes.c_double(eps),
+                                          P(out.ctypes.data), P(g1.ctypes.data), P(g2.ctypes.data), P(gw.ctypes.data),
+                                          ctypes.byref(st))
     assert rc == 0, rc
     return out, g1, g2, gw, st.value
 

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include "../../sympa_amd/csrc/siegel_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_bwd.hpp"
+#include "../../sympa_amd/csrc/siegel_math_bwd_split.hpp"
 #include "../../sympa_amd/csrc/siegel_table_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_generic.hpp"
 #include "../../sympa_amd/csrc/spd_math.hpp"
@@ -135,6 +136,81 @@ extern "C" int sympa_hostsim_dist_bwd(const double* z1, const double* z2, const 
         case 6: run_bwd<6>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         case 7: run_bwd<7>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         case 8: run_bwd<8>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        default: return -2;
+    }
+}
+
+namespace {
+// the two-stage adjoint of dims 5..8 (siegel_math_bwd_split.hpp): stage 1 -> pack (scaled by go) -> stage 2
+template <int N, int MODEL>
+void run_bwd_split_m(const double* z1, const double* z2, const double* go, int64_t b, int metric, const double* w, double eps,
+                     double* out, double* g1, double* g2, double* gw, int32_t* status) {
+    int st = 0;
+    double gwacc[N];
+    for (int k = 0; k < N; ++k) gwacc[k] = 0.0;
+    for (int64_t i = 0; i < b; ++i) {
+        sympa::CMat<N> a, c, ga, gc;
+        sympa::load_point<N>(z1 + i * 2 * N * N, a);
+        sympa::load_point<N>(z2 + i * 2 * N * N, c);
+        double pack[sympa::AdjPack<N, MODEL>::LEN], gwl[N];
+        for (int k = 0; k < N; ++k) gwl[k] = 0.0;
+        out[i] = sympa::pair_adjoint_spectral<N, MODEL>(a, c, metric, w, 1.0 / eps, pack, gwl, st);
+        for (int k = 0; k < sympa::AdjPack<N, MODEL>::LEN; ++k) pack[k] *= go[i];
+        for (int k = 0; k < N; ++k) gwacc[k] += gwl[k] * go[i];
+        if constexpr (MODEL == sympa::MODEL_UPPER) {
+            // the register-ordered form the upper-model kernel runs (planes emitted one at a time, upper triangles)
+            double gstash[N * (N + 1) / 2], staged[N][N];
+            sympa::Tri<N, false> parked[2];
+            sympa::pair_adjoint_gradient_upper<N>(
+                a, c, [&](int k) { return pack[k]; },
+                [&](int which, const sympa::Tri<N, false>& l) { parked[which] = l; },
+                [&](int which, sympa::Tri<N, false>& l) { l = parked[which]; },
+                [&](int k, double g) { gstash[k] = g; }, [&](int k) { return gstash[k]; },
+                [&](const double (&m)[N][N]) {
+                    for (int r = 0; r < N; ++r)
+                        for (int s = r; s < N; ++s) staged[r][s] = m[r][s];
+                },
+                [&](int point, int plane, double sign) {
+                    sympa::CMat<N>& g = point == 0 ? ga : gc;
+                    for (int r = 0; r < N; ++r)
+                        for (int s = r; s < N; ++s) {
+                            if (plane == 0) { g.re[r][s] = sign * staged[r][s]; g.re[s][r] = sign * staged[r][s]; }
+                            else { g.im[r][s] = sign * staged[r][s]; g.im[s][r] = sign * staged[r][s]; }
+                        }
+                });
+        } else {
+            sympa::pair_adjoint_gradient<N, MODEL>(a, c, pack, ga, gc);
+        }
+        for (int r = 0; r < N; ++r)
+            for (int s = 0; s < N; ++s) {
+                g1[i * 2 * N * N + r * N + s] = ga.re[r][s];
+                g1[i * 2 * N * N + N * N + r * N + s] = ga.im[r][s];
+                g2[i * 2 * N * N + r * N + s] = gc.re[r][s];
+                g2[i * 2 * N * N + N * N + r * N + s] = gc.im[r][s];
+            }
+    }
+    for (int k = 0; k < N; ++k) gw[k] = gwacc[k];
+    if (status) *status = st;
+}
+template <int N>
+void run_bwd_split(const double* z1, const double* z2, const double* go, int64_t b, int model, int metric, const double* w,
+                   double eps, double* out, double* g1, double* g2, double* gw, int32_t* status) {
+    if (model == sympa::MODEL_UPPER) run_bwd_split_m<N, sympa::MODEL_UPPER>(z1, z2, go, b, metric, w, eps, out, g1, g2, gw, status);
+    else run_bwd_split_m<N, sympa::MODEL_BOUNDED>(z1, z2, go, b, metric, w, eps, out, g1, g2, gw, status);
+}
+}  // namespace
+
+extern "C" int sympa_hostsim_dist_bwd_split(const double* z1, const double* z2, const double* go, int64_t b, int n, int model,
+                                            int metric, const double* w, double eps, double* out, double* g1, double* g2,
+                                            double* gw, int32_t* status) {
+    switch (n) {
+        case 2: run_bwd_split<2>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 3: run_bwd_split<3>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 4: run_bwd_split<4>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 5: run_bwd_split<5>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 6: run_bwd_split<6>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 7: run_bwd_split<7>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        case 8: run_bwd_split<8>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         default: return -2;
     }
 }

@@ -1,0 +1,267 @@
+"""The split Siegel backward of dims 5..8 (csrc/siegel_math_bwd_split.hpp, siegel_bwd_split_kernel.hpp): ONE pair per lane in two
+kernels through a caller-owned workspace -- stage 1 hands Hbar = V diag(phi) V^H and K = Hbar H to stage 2.
+CPU part: the two-stage arithmetic (g++ build) against the reference's autograd goldens and against the one-stage adjoint.
+GPU part: the kernels through the C-ABI (SYMPA_FLAG_SPLIT: every model and dims 5..8, at any batch size; the default dispatch
+takes them for the upper model at dims 7, 8 from 1 024 pairs on) against the goldens, the g++ build,
+the eight-lanes-per-pair / one-stage kernels (SYMPA_FLAG_COOP / SYMPA_FLAG_GENERIC), on ragged batches, with out-of-range indices,
+under the training graph's step counter and in the deterministic rows form."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, METRICS, MODELS, T, hostsim_dist_bwd, hostsim_dist_bwd_split, points
+
+TOL = 1e-8
+
+
+def relmax(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+
+
+def per_pair_rel(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    b = got.shape[0]
+    return np.abs(got - want).reshape(b, -1).max(1) / np.maximum(np.abs(want).reshape(b, -1).max(1), 1e-300)
+
+
+# ------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize("n", [6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_hostsim_split_backward_matches_reference_autograd(model, n):
+    g = np.load(f"{GOLDEN}/autograd_{model}_n{n}.npz")
+    for m in METRICS:
+        out, g1, g2, gw, st = hostsim_dist_bwd_split(g[f"{m}__z1"], g[f"{m}__z2"], g[f"{m}__coeff"], model, m, np.ones(n))
+        assert st == 0
+        assert relmax(out, g[f"{m}__out"]) < 1e-12
+        assert relmax(g1, g[f"{m}__g1"]) < TOL and relmax(g2, g[f"{m}__g2"]) < TOL, (model, n, m)
+        if m == "wsum":
+            assert relmax(gw, g["wsum__gw"].reshape(-1)) < TOL
+
+
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_hostsim_split_backward_equals_one_stage_adjoint(model, n):
+    """Same gradients as pair_backward (which refines the eigenvalues by Rayleigh quotients) on generic points: the QL's
+    eigenvalues are good enough wherever lambda_min / lambda_max is not tiny."""
+    g = torch.Generator().manual_seed(500 + n)
+    b = 200
+    z1, z2 = points(model, b, n, 0.4, g), points(model, b, n, 0.4, g)
+    go = torch.randn(b, generator=g, dtype=torch.float64)
+    w = torch.linspace(-0.3, 1.2, n, dtype=torch.float64)
+    for m in METRICS:
+        a = hostsim_dist_bwd(z1.numpy(), z2.numpy(), go.numpy(), model, m, w.numpy())
+        s = hostsim_dist_bwd_split(z1.numpy(), z2.numpy(), go.numpy(), model, m, w.numpy())
+        assert a[4] == 0 and s[4] == 0
+        assert relmax(s[0], a[0]) < 1e-12
+        assert per_pair_rel(s[1], a[1]).max() < 1e-9 and per_pair_rel(s[2], a[2]).max() < 1e-9, (model, n, m)
+        if m == "wsum":
+            assert relmax(s[3], a[3]) < 1e-10
+
+
+def test_hostsim_split_backward_identical_points_and_nonfinite():
+    """y = x: every eigenvalue 0, gradient 0 (as the one-stage adjoint); a NaN input gives NaN out and the status bit."""
+    g = torch.Generator().manual_seed(9)
+    z = points("upper", 4, 8, 0.4, g)
+    out, g1, g2, _, st = hostsim_dist_bwd_split(z.numpy(), z.numpy(), np.ones(4), "upper", "riem")
+    ref = hostsim_dist_bwd(z.numpy(), z.numpy(), np.ones(4), "upper", "riem")
+    assert st == ref[4] and np.allclose(out, ref[0], atol=1e-12)
+    assert np.all(np.isfinite(g1)) and np.abs(g1 - ref[1]).max() < 1e-9 and np.abs(g2 - ref[2]).max() < 1e-9
+    bad = z.numpy().copy()
+    bad[1, 0, 2, 3] = bad[1, 0, 3, 2] = np.nan
+    out, g1, g2, _, st = hostsim_dist_bwd_split(bad, z.numpy(), np.ones(4), "upper", "riem")
+    assert np.isnan(out[1]) and st != 0 and np.all(np.isfinite(out[[0, 2, 3]]))
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _ws(b, n, model, dev):
+    from sympa_amd import ops
+    need = ops.siegel_backward_workspace_bytes(b, n, model)
+    assert need > 0
+    return torch.empty(need, dtype=torch.uint8, device=dev)
+
+
+@pytest.mark.gpu
+def test_gpu_split_workspace_size():
+    from sympa_amd import ops
+    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 100 * 262144 * 8
+    assert ops.siegel_backward_workspace_bytes(65, 5, "bounded") == (2 * 5 + 4 * 10) * 128 * 8
+    assert ops.siegel_backward_workspace_bytes(1000, 4, "upper") == 0 and ops.siegel_backward_workspace_bytes(1000, 9, "upper") == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_split_backward_golden(dev, model, n):
+    from sympa_amd import ops
+    g = np.load(f"{GOLDEN}/autograd_{model}_n{n}.npz")
+    for m in METRICS:
+        z1, z2 = T(g[f"{m}__z1"]).to(dev), T(g[f"{m}__z2"]).to(dev)
+        g1, g2, gw = ops.siegel_dist_backward(z1, z2, T(g[f"{m}__coeff"]).to(dev), model, m, torch.ones(n, device=dev),
+                                              flags=ops.FLAG_SPLIT, workspace=_ws(z1.shape[0], n, model, dev))
+        ops.check_status(dev)
+        assert relmax(g1.cpu(), g[f"{m}__g1"]) < TOL and relmax(g2.cpu(), g[f"{m}__g2"]) < TOL, (model, n, m)
+        if m == "wsum":
+            assert relmax(gw.cpu(), g["wsum__gw"].reshape(-1)) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_gpu_split_backward_equals_cpu_build_and_other_kernels(dev, model, n):
+    """Per-pair rows on 1 500 pairs (ragged: not a multiple of 64): the split kernels == the g++ build of the same two stages to
+    rounding, and == the eight-lanes-per-pair and one-stage kernels to 1e-9 per pair, every metric."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(900 + n)
+    b = 1500
+    z1, z2 = points(model, b, n, 0.4, g), points(model, b, n, 0.4, g)
+    go = torch.randn(b, generator=g, dtype=torch.float64)
+    w = torch.linspace(-0.3, 1.2, n, dtype=torch.float64)
+    for m in METRICS:
+        s1, s2, sw = ops.siegel_dist_backward(z1.to(dev), z2.to(dev), go.to(dev), model, m, w.to(dev), flags=ops.FLAG_SPLIT)
+        ops.check_status(dev)
+        h = hostsim_dist_bwd_split(z1.numpy(), z2.numpy(), go.numpy(), model, m, w.numpy())
+        assert per_pair_rel(s1.cpu(), h[1]).max() < 1e-10 and per_pair_rel(s2.cpu(), h[2]).max() < 1e-10, (model, n, m)
+        for flag in (ops.FLAG_COOP, ops.FLAG_GENERIC):
+            o1, o2, ow = ops.siegel_dist_backward(z1.to(dev), z2.to(dev), go.to(dev), model, m, w.to(dev), flags=flag)
+            assert per_pair_rel(s1.cpu(), o1.cpu()).max() < 1e-9 and per_pair_rel(s2.cpu(), o2.cpu()).max() < 1e-9, (model, n, m, flag)
+            if m == "wsum":
+                assert relmax(sw.cpu(), ow.cpu()) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b", [1, 63, 64, 65, 1025])
+def test_gpu_split_backward_ragged_batches(dev, b):
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(40 + b)
+    n, model = 8, "upper"
+    z1, z2 = points(model, b, n, 0.4, g), points(model, b, n, 0.4, g)
+    go = torch.randn(b, generator=g, dtype=torch.float64)
+    s1, s2, _ = ops.siegel_dist_backward(z1.to(dev), z2.to(dev), go.to(dev), model, "riem", workspace=_ws(b, n, model, dev))
+    o1, o2, _ = ops.siegel_dist_backward(z1.to(dev), z2.to(dev), go.to(dev), model, "riem", flags=ops.FLAG_GENERIC)
+    ops.check_status(dev)
+    assert per_pair_rel(s1.cpu(), o1.cpu()).max() < 1e-9 and per_pair_rel(s2.cpu(), o2.cpu()).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model,metric", [("upper", "riem"), ("bounded", "wsum"), ("upper", "finf")])
+def test_gpu_split_fused_step_equals_other_kernels(dev, model, metric, n):
+    """sympa_model_loss_backward (loss + backward + atomic scatter into the table gradient, scale and weight gradients, forward
+    values) through the split kernels == through the one-launch kernels; repeated rows accumulate; an out-of-range index gives
+    NaN out, the status bit and no gradient in BOTH forms."""
+    from sympa_amd import ops
+    nodes, b = 300, 4099
+    g = torch.Generator().manual_seed(77 + n)
+    table = points(model, nodes, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b,), generator=g), torch.randint(0, nodes, (b,), generator=g)), 1)
+    trip[7, 1] = nodes + 5                      # out of range
+    trip = trip.to(dev)
+    gd = (torch.rand(b, generator=g, dtype=torch.float64) * 5 + 1).to(dev)
+    scale = torch.full((1,), 1.3, dtype=torch.float64, device=dev)
+    w = torch.linspace(-0.2, 1.1, n, dtype=torch.float64, device=dev)
+    res = []
+    for flags in (ops.FLAG_SPLIT, ops.FLAG_GENERIC):
+        gt = torch.zeros_like(table)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        gw = torch.zeros(n, dtype=torch.float64, device=dev)
+        out = torch.zeros(b, dtype=torch.float64, device=dev)
+        ops.model_loss_backward(table, trip, gd, gt, loss, model, metric, w, gw, scale, gs, 2.0, 0.5, flags=flags)
+        with pytest.raises(IndexError):
+            ops.check_status(dev)               # the out-of-range index was flagged (and the word is reset)
+        res.append((gt.cpu(), loss.cpu(), gs.cpu(), gw.cpu()))
+    (gt_s, loss_s, gs_s, gw_s), (gt_o, loss_o, gs_o, gw_o) = res
+    assert relmax(loss_s, loss_o) < 1e-12 and relmax(gs_s, gs_o) < 1e-10
+    assert relmax(gt_s, gt_o) < 1e-9
+    if metric == "wsum":
+        assert relmax(gw_s, gw_o) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("det", [False, True])
+def test_gpu_split_train_backward_step_counter_and_deterministic_rows(dev, det):
+    """sympa_model_train_backward through the split kernels: the device step counter selects the batch window in BOTH kernels;
+    the rows form with per-wave sums (deterministic mode) equals the one-stage kernel's rows and sums."""
+    from sympa_amd import ops
+    n, model, nodes, b, steps = 8, "upper", 500, 2048, 3
+    g = torch.Generator().manual_seed(123)
+    table = points(model, nodes, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b * steps,), generator=g), torch.randint(0, nodes, (b * steps,), generator=g)), 1).to(dev)
+    gd = (torch.rand(b * steps, generator=g, dtype=torch.float64) * 5 + 1).to(dev)
+    scale = torch.full((1,), 1.1, dtype=torch.float64, device=dev)
+    counter = torch.full((1,), 2, dtype=torch.int64, device=dev)
+    ws = _ws(b, n, model, dev)
+    out = {}
+    for name, flags, wsp in (("split", 0, ws), ("one", ops.FLAG_GENERIC, None)):
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        if det:
+            rows = torch.zeros(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+            wp = torch.zeros((b + 63) // 64, 2 + n, dtype=torch.float64, device=dev)
+            ops.model_train_backward(table, trip, gd, b, loss, model, "riem", None, None, scale, gs, 1.0, 1.0, grad_rows=rows,
+                                     step_counter=counter, wave_partials=wp, flags=flags, workspace=wsp)
+            out[name] = (rows.cpu(), wp.cpu())
+        else:
+            gt = torch.zeros_like(table)
+            ops.model_train_backward(table, trip, gd, b, loss, model, "riem", None, None, scale, gs, 1.0, 1.0, grad_table=gt,
+                                     step_counter=counter, flags=flags, workspace=wsp)
+            out[name] = (gt.cpu(), torch.cat((loss, gs)).cpu())
+    ops.check_status(dev)
+    assert relmax(out["split"][0], out["one"][0]) < 1e-9
+    assert relmax(out["split"][1], out["one"][1]) < 1e-10
+    # and the window really was batch 2: the same call on the sliced lists without a counter
+    gt2 = torch.zeros_like(table)
+    loss2 = torch.zeros(1, dtype=torch.float64, device=dev)
+    ops.model_loss_backward(table, trip[2 * b:3 * b], gd[2 * b:3 * b], gt2, loss2, model, "riem", scale=scale, workspace=ws)
+    if not det:
+        assert relmax(out["split"][0], gt2.cpu()) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_split_backward_full_size_configs3_gradient_check(dev):
+    """configs[3] at size (upper / riem / n = 8, 262 144 pairs of 45 500 rows): split == eight lanes per pair on the dense table
+    gradient, the loss and the forward values; a directional finite difference of the loss through the forward kernel confirms the
+    table gradient (size-independent property)."""
+    from sympa_amd import data, ops
+    n, nodes, b = 8, 45500, 262144
+    table = data.trained_like_table(nodes, n, seed=1).to(dev)
+    pairs = data.sample_pairs(nodes, b, 0, 1).to(dev)
+    g = torch.Generator().manual_seed(3)
+    gd = (torch.rand(b, generator=g, dtype=torch.float64) * 5 + 1).to(dev)
+    scale = torch.ones(1, dtype=torch.float64, device=dev)
+    res = {}
+    for name, flags in (("split", 0), ("coop", ops.FLAG_COOP)):
+        gt = torch.zeros_like(table)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward(table, pairs, gd, gt, loss, "upper", "riem", None, None, scale, gs, 1.0, 1.0, flags=flags)
+        res[name] = (gt, loss, gs)
+    ops.check_status(dev)
+    assert relmax(res["split"][1].cpu(), res["coop"][1].cpu()) < 1e-12
+    assert relmax(res["split"][2].cpu(), res["coop"][2].cpu()) < 1e-10
+    assert relmax(res["split"][0].cpu(), res["coop"][0].cpu()) < 1e-9
+
+    # a smooth functional for the finite difference (the distortion loss has a kink wherever d = graph distance):
+    # L = sum_i c_i d_i through sympa_model_backward with grad_out = c
+    c = torch.randn(b, generator=torch.Generator().manual_seed(5), dtype=torch.float64).to(dev)
+    gt, _, _ = ops.model_backward(table, pairs, c, "upper", "riem", scale=scale)
+    gt_coop, _, _ = ops.model_backward(table, pairs, c, "upper", "riem", scale=scale, flags=ops.FLAG_COOP)
+    ops.check_status(dev)
+    assert relmax(gt.cpu(), gt_coop.cpu()) < 1e-9
+
+    def loss_of(tab):
+        return (ops.model_forward(tab, pairs, "upper", "riem", scale=scale) * c).sum().item()
+
+    direction = torch.randn(table.shape, generator=torch.Generator().manual_seed(4), dtype=torch.float64).to(dev)
+    direction = 0.5 * (direction + direction.transpose(-1, -2))
+    h = 1e-6
+    fd = (loss_of(table + h * direction) - loss_of(table - h * direction)) / (2 * h)
+    an = (gt * direction).sum().item()
+    assert abs(fd - an) < 1e-6 * max(abs(fd), abs(c).sum().item() * 1e-3), (fd, an)
