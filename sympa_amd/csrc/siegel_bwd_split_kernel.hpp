@@ -57,6 +57,14 @@ __device__ __forceinline__ void flush_plane_atomic(const double sign, const int 
     const int lane = threadIdx.x & 63;
     constexpr int CHUNK = 8;
     if constexpr (NN == 64) {
+        // Consecutive pairs with the SAME row are summed in registers and leave as ONE instruction: a batch sorted by its first
+        // column (sympa_amd/train_step.py sorts every batch it loads; the order inside a batch is free) has ~6 pairs per source
+        // row at configs[3], which takes the source side from 128 to ~25 atomic instructions per pair-row.  The memory side
+        // retires these atomics at ~2.8 G instructions/s whatever their lane mask (tools/microbench/atomic_rate.hip: 369 us for the
+        // 1 M plane-instructions of 262 144 pairs -- more than this kernel's arithmetic), so every instruction saved counts.
+        // The rows are scalars (v_readlane) and the comparison a scalar branch; dead pairs repeat the last live row with zeros.
+        int prev = __builtin_amdgcn_readlane(row, 0);
+        double acc = 0.0;
 SYMPA_UNROLL
         for (int t0 = 0; t0 < 64; t0 += CHUNK) {
             double val[CHUNK];
@@ -65,12 +73,22 @@ SYMPA_UNROLL
 SYMPA_UNROLL
             for (int u = 0; u < CHUNK; ++u) {
                 const int r = __builtin_amdgcn_readlane(row, t0 + u);
-                double* base = grad + (int64_t)r * ROWD;
-                // opaque scalar: otherwise the compiler folds the lane offset into a vector base, keeps all 64 row addresses
-                // for the next plane of the same rows and spills them
-                asm volatile("" : "+s"(base));
-                global_add_f64(base, (unsigned)lane * 8u, sign * val[u]);      // global_atomic_add_f64 v_off, v_data, s[base]
+                if (r != prev) {                                  // wave-uniform
+                    double* base = grad + (int64_t)prev * ROWD;
+                    // opaque scalar: otherwise the compiler folds the lane offset into a vector base, keeps all 64 row addresses
+                    // for the next plane of the same rows and spills them
+                    asm volatile("" : "+s"(base));
+                    global_add_f64(base, (unsigned)lane * 8u, sign * acc);      // global_atomic_add_f64 v_off, v_data, s[base]
+                    acc = 0.0;
+                }
+                prev = r;
+                acc += val[u];
             }
+        }
+        {
+            double* base = grad + (int64_t)prev * ROWD;
+            asm volatile("" : "+s"(base));
+            global_add_f64(base, (unsigned)lane * 8u, sign * acc);
         }
     } else {
         constexpr int TOTAL = NN;                           // instructions: 64 planes x NN doubles / 64 lanes

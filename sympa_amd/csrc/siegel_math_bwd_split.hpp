@@ -25,6 +25,14 @@
 #pragma once
 
 #include "siegel_math_bwd.hpp"
+#include "tridiag_invit.hpp"
+
+// SYMPA_PIN(x): the value x exists in a register at this point of the program order of side effects (device build); nothing on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SYMPA_PIN(x) asm volatile("" ::"v"(x))
+#else
+#define SYMPA_PIN(x) ((void)(x))
+#endif
 
 namespace sympa {
 
@@ -40,6 +48,87 @@ struct AdjPack {
     static constexpr int LEN = K_RE + OFFD + (MODEL == MODEL_UPPER ? 0 : OFFD);
 };
 SYMPA_HD constexpr int offd_index(int n, int j, int k) { return j * n - j * (j + 1) / 2 + (k - j - 1); }   // j < k
+
+// ---------------------------------------------------------------------------------------------
+// Eigen-decomposition of the Hermitian h for stage 1, n >= 5: Householder form (reflectors kept), eigenvalues by the forward's
+// lockstep eigenvalue-only QL (siegel_math.hpp: ~30 instructions per element-sweep, no per-lane block bookkeeping), eigenvectors of
+// the real tridiagonal T by inverse iteration (tridiag_invit.hpp: O(n) per vector, modified Gram-Schmidt inside clusters of close
+// eigenvalues), then V = Q Phi Z.  herm_eigen_vectors_ql's QL WITH accumulated rotations sweeps the whole static index range
+// with selects and updates 2 n doubles of Z per element: ~11 k of the 28 k instructions of the spectral kernel at n = 8 against
+// ~2.5 k + ~2.5 k here.  A pair with a cluster of more than INVIT_KEEP + 1 close eigenvalues (y = c x: every eigenvalue equal) sends
+// its WHOLE WAVE through the QL with vectors instead (wave-uniform branch; a generic batch never takes it).
+// MEASURED AND NOT ADOPTED (-DSYMPA_SPLIT_EIGEN_INVIT): fused step, upper n = 8, 262 144 pairs 818 -> 850 us.  The instruction
+// count does drop, but both routes have to be in the kernel (24 k static instructions = 190 KB of straight-line code that every
+// wave fetches once, against 17 k), and the inverse iteration's LU / solve / Gram-Schmidt temporaries next to the reflectors spill
+// 832 bytes where the QL form spills 24.  Equal results (tests/test_backward_split.py runs both on the CPU build).
+// Eigenvalues into h.d (ascending on the inverse-iteration route), eigenvectors into the columns of v.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+SYMPA_HD bool herm_eigen_vectors_invit(Herm<N>& h, CMat<N>& v) {
+    double a[N], e[N], phr[N], phi[N], beta[N];
+    CMat<N> refl;
+    herm_tridiagonalize_keep<N>(h, a, e, phr, phi, refl, beta);
+    double lam[N];
+    bool ok;
+    {
+        double d[N], e2[N];
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i) { d[i] = a[i]; e2[i] = e[i] * e[i]; }
+        ok = tridiag_ql_lockstep<N>(d, e2);
+        sort_ascending<N>(d);
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i) lam[i] = d[i];
+    }
+    double z[N][N];
+    const bool small_blocks = tridiag_eigvecs_invit<N>(a, e, lam, [&](auto IC, const double (&x)[N]) {
+        constexpr int c = decltype(IC)::value;
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) z[j][c] = x[j];
+    });
+    if (!wave_all(small_blocks)) {
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) z[i][j] = (i == j) ? 1.0 : 0.0;
+        ok = tridiag_ql_vectors<N>(a, e, z);
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i) lam[i] = a[i];
+    }
+    // W = Phi Z,  Phi_0 = 1,  Phi_{j+1} = Phi_j * phase(T[j+1][j]):  T = Phi T_real Phi^H
+    double fr = 1.0, fi = 0.0;
+SYMPA_UNROLL
+    for (int j = 0; j < N; ++j) {
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i) { v.re[j][i] = fr * z[j][i]; v.im[j][i] = fi * z[j][i]; }
+        if (j < N - 1) {
+            const double nr = fr * phr[j] - fi * phi[j];
+            const double ni = fr * phi[j] + fi * phr[j];
+            fr = nr; fi = ni;
+        }
+    }
+    // V = P_0 P_1 ... P_{N-3} W,  P_k = I - beta_k v_k v_k^H on the rows k+1 .. N-1
+SYMPA_UNROLL
+    for (int k = N - 3; k >= 0; --k) {
+SYMPA_UNROLL
+        for (int c = 0; c < N; ++c) {
+            double tr = 0.0, ti = 0.0;     // tau = beta * v^H w
+SYMPA_UNROLL
+            for (int i = k + 1; i < N; ++i) {
+                tr = d_fma(refl.re[i][k], v.re[i][c], d_fma(refl.im[i][k], v.im[i][c], tr));
+                ti = d_fma(refl.re[i][k], v.im[i][c], d_fma(-refl.im[i][k], v.re[i][c], ti));
+            }
+            tr *= beta[k]; ti *= beta[k];
+SYMPA_UNROLL
+            for (int i = k + 1; i < N; ++i) {
+                v.re[i][c] = d_fma(-tr, refl.re[i][k], d_fma(ti, refl.im[i][k], v.re[i][c]));
+                v.im[i][c] = d_fma(-tr, refl.im[i][k], d_fma(-ti, refl.re[i][k], v.im[i][c]));
+            }
+        }
+    }
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i) h.d[i] = lam[i];
+    return ok;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1.  Returns the metric value (NaN for non-finite input); pack = Hbar, K for go = 1; gw[k] += d out / d w_k.
@@ -74,7 +163,11 @@ SYMPA_UNROLL
     }
     CMat<N> v;
     bool conv;
+#ifdef SYMPA_SPLIT_EIGEN_INVIT      // A/B: eigenvalue-only QL + inverse iteration (herm_eigen_vectors_invit above; measured slower)
+    if constexpr (N >= 5) conv = herm_eigen_vectors_invit<N>(h, v);
+#else
     if constexpr (N >= 5) conv = herm_eigen_vectors_ql<N>(h, v);
+#endif
     else conv = herm_eigen_vectors<N>(h, v);
 
     double phi[N], philam[N];
@@ -365,7 +458,14 @@ SYMPA_UNROLL
 SYMPA_UNROLL
             for (int j = i; j < N; ++j) gg[i][j] = -di[i][j] - gg[i][j];
     }
-    // the planes leave at the very end, back to back: Re (staged above) to both points, then the two Im planes
+    // the planes leave at the very end, back to back: Re (staged above) to both points, then the two Im planes.  "At the very end"
+    // has to be enforced: the first flush reads only the staging tile, so the compiler is free to sink the two congruences above
+    // behind its atomics (it did: their spilled operands then waited for 128 atomics each) -- the empty volatile statements below
+    // consume the finished planes and, like the atomics, are not reordered with respect to each other.
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = i; j < N; ++j) { SYMPA_PIN(m[i][j]); SYMPA_PIN(gg[i][j]); }
     flush(1, 0, 1.0);
     flush(0, 0, -1.0);
     stage(m);

@@ -18,7 +18,7 @@ Two graph shapes:
   loss + backward kernel, squared norms, the RSGD kernel(s), the scale's step -- round 2's graph."""
 import torch
 
-from sympa_amd import ops
+from sympa_amd import data, ops
 from sympa_amd.manifolds.metrics import MetricType
 
 
@@ -371,6 +371,7 @@ class GraphedTrainStep:
         steps = total // b
         if total > self.capacity:
             self._alloc_epoch(total)
+        triplets = data.sort_batches_by_source(triplets, b)        # the order inside a batch is free: equal source rows adjacent
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
         if self.deterministic and steps > 0:
@@ -631,6 +632,7 @@ class DistributedTrainStep:
         total = triplets.shape[0]
         if total > self.capacity:
             self._alloc(total)
+        triplets = data.sort_batches_by_source(triplets, self.batch_size)   # the order inside a batch is free
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
         steps = total // self.batch_size

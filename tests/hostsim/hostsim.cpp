@@ -2,6 +2,7 @@
 // per-pair arithmetic the gfx950 kernels run can be checked against the oracle and the golden
 // vectors in a container without a GPU.  Nothing in sympa_amd/ loads this library; the product
 // path fails loudly when the HIP library is missing.
+#include <cmath>
 #include <cstdint>
 #include "../../sympa_amd/csrc/siegel_math.hpp"
 #include "../../sympa_amd/csrc/siegel_math_bwd.hpp"
@@ -211,6 +212,67 @@ extern "C" int sympa_hostsim_dist_bwd_split(const double* z1, const double* z2, 
         case 6: run_bwd_split<6>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         case 7: run_bwd_split<7>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
         case 8: run_bwd_split<8>(z1, z2, go, b, model, metric, w, eps, out, g1, g2, gw, status); return 0;
+        default: return -2;
+    }
+}
+
+namespace {
+// both eigenvector routes of stage 1 on H = E^H E of upper-model pairs: err[0] = max |Hbar_ql - Hbar_invit| / max |Hbar_ql| for the
+// spectral function phi = 1 / (1 + lambda), err[1] = max |V^H V - I| of the inverse-iteration route, err[2] = max |lambda_ql - lambda_invit| (sorted) / lambda_max
+template <int N>
+void run_eig_routes(const double* z1, const double* z2, int64_t b, double* err) {
+    err[0] = err[1] = err[2] = 0.0;
+    for (int64_t p = 0; p < b; ++p) {
+        sympa::CMat<N> a, c, e;
+        sympa::load_point<N>(z1 + p * 2 * N * N, a);
+        sympa::load_point<N>(z2 + p * 2 * N * N, c);
+        sympa::Tri<N, false> l1, l2;
+        sympa::chol_real<N>(a.im, l1);
+        sympa::chol_real<N>(c.im, l2);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) { e.re[i][j] = c.re[i][j] - a.re[i][j]; e.im[i][j] = c.im[i][j] - a.im[i][j]; }
+        sympa::solve_left<N, false>(l1, e);
+        sympa::solve_right_t<N, false>(l2, e);
+        sympa::Herm<N> h1, h2;
+        sympa::gram<N>(e, h1);
+        h2 = h1;
+        sympa::CMat<N> v1, v2, hb1, hb2;
+        sympa::herm_eigen_vectors_ql<N>(h1, v1);
+        sympa::herm_eigen_vectors_invit<N>(h2, v2);
+        double p1[N], p2[N], l1s[N], l2s[N], lmax = 1e-300;
+        for (int i = 0; i < N; ++i) { p1[i] = 1.0 / (1.0 + h1.d[i]); p2[i] = 1.0 / (1.0 + h2.d[i]); l1s[i] = h1.d[i]; l2s[i] = h2.d[i]; }
+        sympa::sort_ascending<N>(l1s);
+        sympa::sort_ascending<N>(l2s);
+        for (int i = 0; i < N; ++i) lmax = std::fmax(lmax, std::fabs(l1s[i]));
+        for (int i = 0; i < N; ++i) err[2] = std::fmax(err[2], std::fabs(l1s[i] - l2s[i]) / lmax);
+        sympa::herm_from_eig<N>(v1, p1, hb1);
+        sympa::herm_from_eig<N>(v2, p2, hb2);
+        double mx = 1e-300, df = 0.0;
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                mx = std::fmax(mx, std::fmax(std::fabs(hb1.re[i][j]), std::fabs(hb1.im[i][j])));
+                df = std::fmax(df, std::fmax(std::fabs(hb1.re[i][j] - hb2.re[i][j]), std::fabs(hb1.im[i][j] - hb2.im[i][j])));
+            }
+        err[0] = std::fmax(err[0], df / mx);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                double tr = 0.0, ti = 0.0;
+                for (int k = 0; k < N; ++k) {
+                    tr += v2.re[k][i] * v2.re[k][j] + v2.im[k][i] * v2.im[k][j];
+                    ti += v2.re[k][i] * v2.im[k][j] - v2.im[k][i] * v2.re[k][j];
+                }
+                err[1] = std::fmax(err[1], std::fmax(std::fabs(tr - (i == j ? 1.0 : 0.0)), std::fabs(ti)));
+            }
+    }
+}
+}  // namespace
+
+extern "C" int sympa_hostsim_eig_routes(const double* z1, const double* z2, int64_t b, int n, double* err) {
+    switch (n) {
+        case 5: run_eig_routes<5>(z1, z2, b, err); return 0;
+        case 6: run_eig_routes<6>(z1, z2, b, err); return 0;
+        case 7: run_eig_routes<7>(z1, z2, b, err); return 0;
+        case 8: run_eig_routes<8>(z1, z2, b, err); return 0;
         default: return -2;
     }
 }

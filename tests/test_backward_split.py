@@ -73,6 +73,27 @@ def test_hostsim_split_backward_identical_points_and_nonfinite():
     assert np.isnan(out[1]) and st != 0 and np.all(np.isfinite(out[[0, 2, 3]]))
 
 
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+def test_hostsim_eigenvector_routes_agree(n):
+    """Stage 1's two eigenvector routes (QL with accumulated rotations: the default; eigenvalue-only QL + inverse iteration: built
+    with -DSYMPA_SPLIT_EIGEN_INVIT, measured slower on the GPU) give the same spectral function Hbar = V phi(lambda) V^H, the same
+    eigenvalues and orthonormal vectors -- on generic pairs and on pairs with clustered eigenvalues (y close to a multiple of x)."""
+    import ctypes
+    from tests.helpers import hostsim
+    lib = hostsim()
+    g = torch.Generator().manual_seed(70 + n)
+    z1, z2 = points("upper", 300, n, 0.4, g), points("upper", 300, n, 0.4, g)
+    z2[:20, 0] = z1[:20, 0]                        # same real part, Y2 = c Y1 (+ a small perturbation): clustered eigenvalues
+    z2[:20, 1] = 1.7 * z1[:20, 1]
+    z2[10:20, 1] += 1e-9 * (z2[10:20, 1] @ z2[10:20, 1])
+    a, c = np.ascontiguousarray(z1.numpy()), np.ascontiguousarray(z2.numpy())
+    err = np.zeros(3)
+    rc = lib.sympa_hostsim_eig_routes(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(c.ctypes.data), ctypes.c_int64(300), n,
+                                      ctypes.c_void_p(err.ctypes.data))
+    assert rc == 0
+    assert err[0] < 1e-11 and err[1] < 1e-12 and err[2] < 1e-13, err
+
+
 # ------------------------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def dev():
@@ -265,3 +286,34 @@ def test_gpu_split_backward_full_size_configs3_gradient_check(dev):
     fd = (loss_of(table + h * direction) - loss_of(table - h * direction)) / (2 * h)
     an = (gt * direction).sum().item()
     assert abs(fd - an) < 1e-6 * max(abs(fd), abs(c).sum().item() * 1e-3), (fd, an)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["by_source", "by_target", "one_source"])
+def test_gpu_split_scatter_merges_equal_rows(dev, order):
+    """The n = 8 scatter adds consecutive pairs with the same row as ONE atomic instruction (flush_plane_atomic): batches sorted by
+    either column, and a batch whose pairs all share one source row (a single atomic per plane and wave), give the gradient of the
+    one-stage kernels; so does the ragged tail of a wave (dead pairs repeat the last live row with zeros)."""
+    from sympa_amd import ops
+    n, nodes, b = 8, 40, 4099                       # ~100 pairs per row: long runs of equal rows once sorted
+    g = torch.Generator().manual_seed(17)
+    table = points("upper", nodes, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b,), generator=g), torch.randint(0, nodes, (b,), generator=g)), 1)
+    if order == "by_source":
+        trip = trip[torch.argsort(trip[:, 0], stable=True)]
+    elif order == "by_target":
+        trip = trip[torch.argsort(trip[:, 1], stable=True)]
+    else:
+        trip[:, 0] = 7
+    trip = trip.contiguous().to(dev)
+    gd = (torch.rand(b, generator=g, dtype=torch.float64) * 5 + 1).to(dev)
+    scale = torch.full((1,), 1.2, dtype=torch.float64, device=dev)
+    res = []
+    for flags in (0, ops.FLAG_GENERIC):
+        gt = torch.zeros_like(table)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward(table, trip, gd, gt, loss, "upper", "riem", None, None, scale, gs, 1.0, 1.0, flags=flags)
+        res.append((gt.cpu(), loss.cpu(), gs.cpu()))
+    ops.check_status(dev)
+    assert relmax(res[0][0], res[1][0]) < 1e-10 and relmax(res[0][1], res[1][1]) < 1e-12 and relmax(res[0][2], res[1][2]) < 1e-10

@@ -314,3 +314,20 @@ def test_riemannian_adam_follows_changed_betas_and_loads_the_old_state_format():
     ours.step()
     loaded.step()
     assert torch.allclose(a.detach(), c.detach(), rtol=1e-12, atol=1e-14)
+
+
+def test_sort_batches_by_source():
+    """data.sort_batches_by_source: inside every FULL batch the pairs are ordered by their first column (stable), every batch keeps
+    its own triplets, the ragged tail is untouched."""
+    import torch
+    from sympa_amd import data
+    g = torch.Generator().manual_seed(3)
+    t = torch.stack((torch.randint(0, 50, (1030,), generator=g), torch.randint(0, 50, (1030,), generator=g),
+                     torch.randint(1, 9, (1030,), generator=g)), 1)
+    out = data.sort_batches_by_source(t, 256)
+    assert out.shape == t.shape and torch.equal(out[1024:], t[1024:])
+    for k in range(4):
+        a, b = t[k * 256:(k + 1) * 256], out[k * 256:(k + 1) * 256]
+        assert bool((b[1:, 0] >= b[:-1, 0]).all())
+        assert torch.equal(b, a[torch.argsort(a[:, 0], stable=True)])
+    assert torch.equal(data.sort_batches_by_source(t[:100], 256), t[:100])

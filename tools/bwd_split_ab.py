@@ -19,6 +19,8 @@ for model in models:
         nodes, b = (45500, 262144) if n == 8 else (5000, 65536)
         table = data.trained_like_table(nodes, n, seed=1, model=model).to(dev)
         pairs = data.sample_pairs(nodes, b, 0, 1).to(dev)
+        if "--sorted" in sys.argv:              # the batch sorted by its first column (what sympa_amd/train_step.py loads)
+            pairs = pairs[torch.argsort(pairs[:, 0], stable=True)].contiguous()
         gd = torch.rand(b, dtype=torch.float64, device=dev) * 5 + 1
         scale = torch.ones(1, dtype=torch.float64, device=dev)
         res = {}
