@@ -358,6 +358,7 @@ SYMPA_HD void pair_adjoint_gradient_upper(const CMat<N>& z1, const CMat<N>& z2, 
                                           PutG&& put_g, GetG&& get_g, Stage&& stage, Flush&& flush) {
     using P = AdjPack<N, MODEL_UPPER>;
     CMat<N> e;
+    double hd[N], hre[N][N], him[N][N];          // Hbar: diagonal, strict upper triangle (j < k)
     {
         Tri<N, false> l1, l2;
         (void)chol_real<N>(z1.im, l1);
@@ -370,12 +371,9 @@ SYMPA_UNROLL
                 e.im[i][j] = z2.im[i][j] - z1.im[i][j];
             }
         solve_left<N, false>(l1, e);
-        solve_right_t<N, false>(l2, e);
         park(0, l1);
-        park(1, l2);
-    }
-    {
-        double hd[N], hre[N][N], him[N][N];          // Hbar: diagonal, strict upper triangle (j < k)
+        // Hbar is asked for HERE, one solve ahead of its first use: one wave per SIMD has nothing else to hide the ~2 us of a
+        // workspace read behind (E, L2 and Hbar together still fit: 236 doubles)
 SYMPA_UNROLL
         for (int j = 0; j < N; ++j) {
             hd[j] = pk(P::H_D + j);
@@ -385,6 +383,10 @@ SYMPA_UNROLL
                 him[j][k] = pk(P::H_IM + offd_index(N, j, k));
             }
         }
+        solve_right_t<N, false>(l2, e);
+        park(1, l2);
+    }
+    {
 SYMPA_UNROLL
         for (int i = 0; i < N; ++i) {
             double fr[N], fi[N];
@@ -419,11 +421,11 @@ SYMPA_UNROLL
     solve_lh_left<N, false>(l1, e);
     unpark(1, l2);
     solve_l_right<N, false, true>(l2, e);
+    double m[N][N], gg[N][N];
     // sym(Dbar) first (Ebar dies) and its real part goes straight into the caller's staging tile (36 doubles fewer through the
     // congruences: with them the tail spilled, and a spilled operand reloaded between two planes' atomics waits for every atomic
     // before it -- the memory counter is in order).  K and G are read when their congruences need them, all before the first
     // plane leaves.
-    double m[N][N], gg[N][N];
     {
         double di[N][N];
         {

@@ -12,12 +12,46 @@ using namespace sympa_hip;
 
 // OP 0: out = projx(z).   OP 1: table <- retr(table, -lr * egrad2rgrad(table, grad + wd * table)) in place.
 // sum of squares of `count` doubles, accumulated into acc[0] (the total gradient norm of clip_grad_norm_)
+// Four independent 16-byte loads in flight per lane and four partial sums: the one-load-at-a-time form (a dependent load -> fma chain,
+// 22 trips per lane over the 46.6 MB gradient of configs[3]) ran at 0.8 TB/s, 58 us of a 0.82 ms training step; this one at the
+// copy rate.  (The order of summation is not fixed either way: the blocks add their sums with an atomic.)  A first version of
+// this rewrite with 2 048 blocks and one atomic per wave was SLOWER (105 us): see the block-level sum at the end.
 __global__ __launch_bounds__(BLOCK) void sqnorm_kernel(const double* __restrict__ x, int64_t count, double* acc) {
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * BLOCK) s = fma(x[i], x[i], s);
+    const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x, nth = (int64_t)gridDim.x * BLOCK;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        const v2d* __restrict__ x2 = reinterpret_cast<const v2d*>(x);
+        const int64_t n2 = count >> 1;
+        int64_t i = tid;
+        for (; i + 3 * nth < n2; i += 4 * nth) {
+            const v2d a = x2[i], b = x2[i + nth], c = x2[i + 2 * nth], d = x2[i + 3 * nth];
+            s0 = fma(a.x, a.x, fma(a.y, a.y, s0));
+            s1 = fma(b.x, b.x, fma(b.y, b.y, s1));
+            s2 = fma(c.x, c.x, fma(c.y, c.y, s2));
+            s3 = fma(d.x, d.x, fma(d.y, d.y, s3));
+        }
+        for (; i < n2; i += nth) {
+            const v2d a = x2[i];
+            s0 = fma(a.x, a.x, fma(a.y, a.y, s0));
+        }
+        if (tid == 0 && (count & 1)) s1 = fma(x[count - 1], x[count - 1], s1);
+    } else {
+        for (int64_t i = tid; i < count; i += nth) s0 = fma(x[i], x[i], s0);
+    }
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(acc, s);
+    // ONE atomic per block: the 4 096 per-wave atomics of the old form all hit the same word and serialise there (~12 ns each:
+    // that, not the 46.6 MB read, was most of the 58 us)
+    __shared__ double part[BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) t += part[w];
+        if (t != 0.0) atomicAdd(acc, t);
+    }
 }
 
 // p <- p - lr * (coef * grad + wd * p), coef = min(1, max_norm / (sqrt(total_sqnorm) + 1e-6)): the plain SGD step of the
@@ -242,8 +276,8 @@ int sympa_sqnorm_accum(const double* x, int64_t count, double* acc, void* stream
     if (count < 0) return fail(SYMPA_ERR_BAD_ARG, "negative count");
     if (count == 0) return 0;
     if (x == nullptr || acc == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
-    const int64_t want = (count + BLOCK - 1) / BLOCK;
-    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+    const int64_t want = (count / 8 + BLOCK - 1) / BLOCK;          // one trip of the four-loads loop per lane, up to 2 blocks per CU
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 512 ? want : 512));
     hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x, count, acc);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));

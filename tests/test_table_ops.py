@@ -340,3 +340,19 @@ def test_gpu_sgd_step_of_a_parameter_without_manifold(dev):
         coef = 1.0 if max_norm is None else min(1.0, max_norm / (float((gr * gr).sum().sqrt()) + 1e-6))
         want = p0 - 0.03 * (coef * gr + 0.01 * p0)
         assert relmax(p.cpu(), want) < 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [1, 7, 1000, 100003, 5824000])
+def test_gpu_sqnorm_accum_sizes_and_alignment(count):
+    """sympa_sqnorm_accum (the gradient norm of clip_grad_norm_, runner.py:108): 16-byte loads four at a time with a scalar tail,
+    one atomic per block; an 8-byte aligned (not 16) buffer takes the scalar route; the result ACCUMULATES."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(count)
+    x = torch.randn(count + 1, generator=g, dtype=torch.float64).to(dev)
+    for view in (x[:count], x[1:]):
+        acc = torch.full((1,), 2.5, dtype=torch.float64, device=dev)
+        ops.sqnorm_accum_(view, acc)
+        want = 2.5 + float((view.cpu() ** 2).sum())
+        assert abs(float(acc) - want) < 1e-11 * want
