@@ -182,6 +182,19 @@ __global__ __launch_bounds__(64, SYMPA_BWD3_BACK_WAVES) void spd_bwd3_back_kerne
     }
     int st = 0, nflag = 0;
     double loss_acc = 0.0, gscale_acc = 0.0;
+    // the pending source-row gradient of the wave (see the scatter below): nn doubles, lane l owns l, l + 64, ...
+    constexpr int PEND_PER_LANE = (nn + 63) / 64;
+    __shared__ double pend[PEND_PER_LANE * 64];
+    int pend_row = -1;
+    auto pend_flush = [&](const int row) {
+        double* base = a.gtab + (int64_t)row * nn;
+#pragma unroll
+        for (int k = 0; k < PEND_PER_LANE; ++k) {
+            const int idx = lane + 64 * k;
+            const double v = (idx < nn) ? pend[idx] : 0.0;
+            if (idx < nn && v != 0.0) atomicAdd(base + idx, v);
+        }
+    };
     for (int t = 0; t < rounds; ++t) {
         const int64_t first = ((int64_t)blockIdx.x * rounds + t) * 4;
         if (first >= a.b) break;
@@ -244,8 +257,34 @@ __global__ __launch_bounds__(64, SYMPA_BWD3_BACK_WAVES) void spd_bwd3_back_kerne
         congruence_inv_t_rows(py_, l, rd, tbuf, r);
         congruence_inv_t_rows(px_, l, rd, tbuf, r);
         if (a.gtab != nullptr) {
-            scatter_plane<M>(px_, tbuf, a.gtab + r1 * nn, r, live && !bad);
-            scatter_plane<M>(py_, tbuf, a.gtab + r2 * nn, r, live && !bad);
+            // SOURCE side through the wave's pending tile: consecutive pairs with the same source row (a batch sorted by its first
+            // column: sympa_amd/data.py::sort_batches_by_source, ~10 pairs per source row at configs[4]) are summed in the LDS and
+            // leave as ONE run of full-width atomic instructions when the row changes -- the memory side retires fp64 atomics by
+            // the 128-byte line (tools/microbench/atomic_rate.hip), and the scatter was 4.3 of the 8.6 GB this kernel moves per
+            // 1 M pairs.  The four pairs of a round are taken in order (wave-uniform loop, rows are scalars); dead pairs repeat the
+            // last live row with zeros.
+            const bool on = live && !bad;
+            wave_lds_fence();
+            if (r < M) sfor<0, M>([&](auto J) { tbuf[r * M + J] = on ? px_[J] : 0.0; });
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row_q = __builtin_amdgcn_readlane((int)r1, q * 16);
+                const double* tq = tbuf_all + q * TBUF;
+                pend_row = __builtin_amdgcn_readfirstlane(pend_row);         // a scalar, and the compiler shall know it
+                if (row_q != pend_row) {
+                    if (pend_row >= 0) pend_flush(pend_row);
+                    pend_row = row_q;
+#pragma unroll
+                    for (int k = 0; k < PEND_PER_LANE; ++k)
+                        if (lane + 64 * k < nn) pend[lane + 64 * k] = tq[lane + 64 * k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PEND_PER_LANE; ++k)
+                        if (lane + 64 * k < nn) pend[lane + 64 * k] += tq[lane + 64 * k];
+                }
+            }
+            scatter_plane<M>(py_, tbuf, a.gtab + r2 * nn, r, on);
         } else if (live && r < M) {
             double* ox = a.gx + i * nn + r * M;
             double* oy = a.gy + i * nn + r * M;
@@ -266,6 +305,11 @@ __global__ __launch_bounds__(64, SYMPA_BWD3_BACK_WAVES) void spd_bwd3_back_kerne
                 nflag += (s != 0) ? 1 : 0;
             }
         }
+    }
+    pend_row = __builtin_amdgcn_readfirstlane(pend_row);
+    if (a.gtab != nullptr && pend_row >= 0) {
+        wave_lds_fence();
+        pend_flush(pend_row);
     }
     double v = (r == 0) ? loss_acc : 0.0;
     double w2 = (r == 0) ? gscale_acc : 0.0;

@@ -641,3 +641,41 @@ def test_gpu_spd_three_kernel_backward_every_size(monkeypatch, n):
     ops.check_status(dev)
     assert float((res[0][0] - res[1][0]).abs().max()) < 1e-10 * float(res[1][0].abs().max())
     assert abs(res[0][1] - res[1][1]) < 1e-11 * abs(res[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [9, 16])
+@pytest.mark.parametrize("order", ["by_source", "one_source", "random"])
+def test_gpu_spd_three_kernel_scatter_merges_equal_source_rows(monkeypatch, n, order):
+    """The three-kernel backward's scatter keeps the SOURCE-row gradient of consecutive pairs with the same source row in a pending
+    LDS tile and adds it once when the row changes (spd_coop_bwd3_kernel.hpp): batches sorted by source row (long runs, crossing the
+    rounds and waves), one source row for the whole batch, an unsorted batch and an out-of-range index all give the gradient of the
+    QL-with-vectors kernel (no pending tile), at a batch size that leaves the last wave ragged."""
+    from sympa_amd import ops
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("SYMPA_SPD_BWD_WORKSPACE_MIN", "1")
+    g = torch.Generator().manual_seed(77 + n)
+    nodes, b = 37, 2051
+    table = spd_points(nodes, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b,), generator=g), torch.randint(0, nodes, (b,), generator=g)), 1)
+    if order == "by_source":
+        trip = trip[torch.argsort(trip[:, 0], stable=True)]
+    elif order == "one_source":
+        trip[:, 0] = 5
+    trip = trip.contiguous().to(dev)
+    gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
+    sc = torch.full((1,), 1.3, dtype=torch.float64, device=dev)
+    res = []
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("SYMPA_SPD_BWD_NO_WORKSPACE", "1")
+        grad = torch.zeros_like(table)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, grad_scale=gs)
+        res.append((grad, float(loss), float(gs)))
+    monkeypatch.delenv("SYMPA_SPD_BWD_NO_WORKSPACE")
+    ops.check_status(dev)
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-10 * float(res[1][0].abs().max())
+    assert abs(res[0][1] - res[1][1]) < 1e-11 * abs(res[1][1]) and abs(res[0][2] - res[1][2]) < 1e-10 * abs(res[1][2])
+    assert float((res[0][0] - res[0][0].transpose(-1, -2)).abs().max()) < 1e-10 * float(res[1][0].abs().max())

@@ -18,23 +18,30 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 dev = torch.device("cuda:0")
 table = data.spd_table(rows, n, seed=42).to(dev)
 trip = data.sample_pairs(rows, b, 0, 42).to(dev)
+if os.environ.get("SORTED_BATCH"):           # the batch sorted by its first column (sympa_amd/data.py::sort_batches_by_source)
+    trip = data.sort_batches_by_source(trip, b)
 g = torch.Generator().manual_seed(1)
 gd = torch.randint(1, 9, (b,), generator=g).to(torch.float64).to(dev)
 sc = torch.ones(1, dtype=torch.float64, device=dev)
 
 
 def run(flags, reps=5):
+    # a persistent workspace, as the replayed training step holds one (sympa_amd/train_step.py): a fresh 3.4 GB tensor per call
+    # makes the timing depend on the caching allocator's mood (7.6 .. 29 ms measured for the same kernels)
+    need = 0 if os.environ.get("SYMPA_SPD_BWD_NO_WORKSPACE") else ops._lib.load().sympa_spd_backward_workspace_bytes(b, n)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev) if need > 0 else None
     grad = torch.zeros_like(table)
     loss = torch.zeros(1, dtype=torch.float64, device=dev)
     gs = torch.zeros(1, dtype=torch.float64, device=dev)
-    out = ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, grad_scale=gs, want_out=True, flags=flags)
+    out = ops.spd_loss_backward(table, trip, grad, graph_dist=gd, scale=sc, loss=loss, grad_scale=gs, want_out=True, flags=flags,
+                                workspace=ws)
     ops.check_status(dev)
     torch.cuda.synchronize()
     scratch = torch.zeros_like(table)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.spd_loss_backward(table, trip, scratch, graph_dist=gd, scale=sc, loss=loss.clone(), flags=flags)
+        ops.spd_loss_backward(table, trip, scratch, graph_dist=gd, scale=sc, loss=loss.clone(), flags=flags, workspace=ws)
     e1.record()
     torch.cuda.synchronize()
     return grad, loss, gs, out, e0.elapsed_time(e1) / reps
