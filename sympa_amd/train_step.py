@@ -16,10 +16,26 @@ Two graph shapes:
   same bits, like the reference's CPU autograd.
 * **classic** (everything else: dims 7..16, spd, other optimisers' parameters): zero (one multi-tensor launch), the fused
   loss + backward kernel, squared norms, the RSGD kernel(s), the scale's step -- round 2's graph."""
+import os
+
 import torch
 
 from sympa_amd import data, ops
 from sympa_amd.manifolds.metrics import MetricType
+
+
+def batches_want_source_order(model):
+    """True where the backward's scatter merges consecutive pairs with the same source row -- the split backward of the upper
+    model at dims 8 (csrc/siegel_bwd_split_kernel.hpp) and the three-kernel spd backward at dims 9..16 (spd_coop_bwd3_kernel.hpp):
+    there a batch sorted by its first column (data.sort_batches_by_source) is 10-15 % faster.  Everywhere else the sorted order puts
+    the atomics of neighbouring lanes on the SAME rows and is slower (headline two-kernel step 62 -> 71 us, dims 7 fused step 200 ->
+    228 us per 65 536 pairs), so the batches are left in the sampler's order."""
+    man = model.manifold
+    dims = int(model.embeddings.embeds.shape[-1])
+    name = getattr(man, "model_name", "")
+    if os.environ.get("SYMPA_NO_BATCH_SORT"):
+        return False
+    return (name == "upper" and dims == 8) or (name == "spd" and 9 <= dims <= 16)
 
 
 class GraphedTrainStep:
@@ -371,7 +387,8 @@ class GraphedTrainStep:
         steps = total // b
         if total > self.capacity:
             self._alloc_epoch(total)
-        triplets = data.sort_batches_by_source(triplets, b)        # the order inside a batch is free: equal source rows adjacent
+        if batches_want_source_order(self.model):      # the order inside a batch is free: equal source rows adjacent
+            triplets = data.sort_batches_by_source(triplets, b)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
         if self.deterministic and steps > 0:
@@ -632,7 +649,8 @@ class DistributedTrainStep:
         total = triplets.shape[0]
         if total > self.capacity:
             self._alloc(total)
-        triplets = data.sort_batches_by_source(triplets, self.batch_size)   # the order inside a batch is free
+        if batches_want_source_order(self.model):      # the order inside a batch is free
+            triplets = data.sort_batches_by_source(triplets, self.batch_size)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
         steps = total // self.batch_size

@@ -54,6 +54,23 @@ def test_graphed_step_equals_eager_step(dims):
     assert h_graph[-1][2] < 0.9 * h_graph[0][2]
 
 
+def test_graphed_step_with_the_split_backward_equals_eager_step(monkeypatch):
+    """dims 8, upper model, batches of 2 048 pairs: the replayed step takes the split backward (two kernels, persistent workspace
+    held by the step, batches sorted by source row) -- inside the captured graph and in the eager ragged batch -- and trains like
+    the same harness on the one-launch kernels (SYMPA_SIEGEL_BWD_NO_WORKSPACE=1): same distortion history to rounding."""
+    import train_siegel
+    common = ["--graph", "grid3d-125", "--manifold", "upper", "--metric", "riem", "--dims", "8", "--epochs", "6",
+              "--batch_size", "2048", "--val_every", "2", "--learning_rate", "0.02", "--burnin", "2"]
+    _, h_split = train_siegel.train(train_siegel.parser().parse_args(common), log=lambda *_: None)
+    monkeypatch.setenv("SYMPA_SIEGEL_BWD_NO_WORKSPACE", "1")
+    _, h_one = train_siegel.train(train_siegel.parser().parse_args(common), log=lambda *_: None)
+    assert len(h_split) == len(h_one) == 3
+    for a, b in zip(h_split, h_one):
+        assert a[0] == b[0]
+        assert abs(a[1] - b[1]) < 1e-7 * abs(b[1]) and abs(a[2] - b[2]) < 1e-7 * abs(b[2]), (a, b)
+    assert h_split[-1][2] < h_split[0][2]
+
+
 @pytest.mark.parametrize("mode", ["dense", "rows", "sharded"])
 def test_gradient_exchange_step_equals_plain_step(mode):
     """The data-parallel step (persistent flat gradient buffer; dense all-reduce, touched-row exchange with the rows

@@ -15,7 +15,7 @@ import torch.distributed as dist  # noqa: E402
 from sympa_amd import data, ops  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
 from sympa_amd.optim import RiemannianSGD  # noqa: E402
-from sympa_amd.train_step import DistributedTrainStep, GraphedTrainStep  # noqa: E402
+from sympa_amd.train_step import DistributedTrainStep, GraphedTrainStep, batches_want_source_order  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 dev = torch.device("cuda:0")
@@ -73,7 +73,10 @@ for name, manifold, metric, n, nodes, batch in (("headline", "upper", "riem", 4,
             # dims 7, 8: the classic graph (zero, fused loss + backward, norms, RSGD, scale step), one call per batch
             if "atomic" in form:
                 st = GraphedTrainStep(m, opt, batch, 50.0, dev, two_kernels=False)
-                ids, gd = trip[:batch, :2].contiguous(), trip[:batch, 2].to(torch.float64)
+                first = trip[:batch]
+                if batches_want_source_order(m):        # what load_epoch does for the replayed steps below (sympa_amd/data.py)
+                    first = data.sort_batches_by_source(first, batch)
+                ids, gd = first[:, :2].contiguous(), first[:, 2].to(torch.float64)
                 for _ in range(3):
                     st(ids, gd)
                 torch.cuda.synchronize()

@@ -73,5 +73,19 @@ echo "== round 4: spd n = 16 backward, three kernels (eigenvectors one pair per 
 { timeout 600 python3 tools/spd_bwd3_ab.py 1048576 2>&1 | grep -v amdgpu.ids | tail -2; timeout 300 python3 tools/spd_bwd3_ab.py 65536 2>&1 | grep -v amdgpu.ids | tail -2; } | tee $OUT/spd_bwd3_ab.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_spd_bwd3 -- python3 tools/spd_bwd3_ab.py 1048576 > $OUT/prof_spd_bwd3.log 2>&1
 find $OUT/prof_spd_bwd3 -name "*kernel_stats.csv" | head -1 | xargs -r head -7 | cut -c1-220
+echo "== round 4 (second session): split Siegel backward of dims 7, 8 (one pair per lane, two kernels), merged source rows, atomic rate"
+{
+  timeout 600 python3 tools/bwd_split_ab.py 2>&1 | grep "^upper\|^bounded"
+  echo "# batches sorted by source row (sympa_amd/data.py::sort_batches_by_source):"
+  timeout 300 python3 tools/bwd_split_ab.py --dims 7,8 --models upper --sorted 2>&1 | grep "^upper"
+  echo "# per-pair rows form:"
+  timeout 300 python3 tools/bwd_split_ab.py --dims 7,8 --models upper --rows 2>&1 | grep "^upper"
+} | tee $OUT/split_ab.txt
+( cd tools/microbench && hipcc --offload-arch=gfx950 -O3 -o atomic_rate atomic_rate.hip > /dev/null 2>&1 ); timeout 120 ./tools/microbench/atomic_rate 2>&1 | tee $OUT/atomic_rate.txt
+WORKLOADS=cartesian timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_cartesian -- python3 tools/train_step_time.py 20 > $OUT/prof_train_cartesian.log 2>&1
+find $OUT/prof_train_cartesian -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | cut -c1-200 | tee $OUT/train_cartesian_kernel_stats_head.txt
+WORKLOADS=custom-spd timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_spd -- python3 tools/train_step_time.py 10 > $OUT/prof_train_spd.log 2>&1
+find $OUT/prof_train_spd -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | cut -c1-200 | tee $OUT/train_spd_kernel_stats_head.txt
+timeout 900 bash tools/split_pmc.sh $TAG > $OUT/split_pmc.log 2>&1; tail -75 $OUT/split_pmc.log | cut -c1-160
 echo "== gpu_check status: FAIL=$FAIL"
 exit $FAIL

@@ -4,7 +4,7 @@ TAG=${1:-a}
 OUT=gpurun_out/split_pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="tools/bwd_split_ab.py --dims 8 --models upper"
+CMD="tools/bwd_split_ab.py --dims 8 --models upper --sorted"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq1 -- python3 $CMD > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_SALU --output-format csv -d $OUT/sq2 -- python3 $CMD > $OUT/sq2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_IFETCH --output-format csv -d $OUT/sq3 -- python3 $CMD > $OUT/sq3.log 2>&1

@@ -22,6 +22,7 @@ import torch.distributed as dist  # noqa: E402
 from sympa_amd import data, ops  # noqa: E402
 from sympa_amd.distributed import GradientExchange, shard_triplets  # noqa: E402
 from sympa_amd.data import sort_batches_by_source  # noqa: E402
+from sympa_amd.train_step import batches_want_source_order  # noqa: E402
 from sympa_amd.model import Model  # noqa: E402
 from sympa_amd.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
 from sympa_amd.train_step import DistributedTrainStep, GraphedTrainStep  # noqa: E402
@@ -86,7 +87,8 @@ def train(args, log=print):
             stepper = None
     for epoch in range(1, args.epochs + 1):
         mine = shard_triplets(trip, rank, world, epoch=epoch, seed=0).to(dev)
-        mine = sort_batches_by_source(mine, batch)      # inside every batch: pairs with the same source row adjacent (free for SGD)
+        if batches_want_source_order(model):             # inside every batch: pairs with the same source row adjacent (free for SGD)
+            mine = sort_batches_by_source(mine, batch)
         t0 = time.perf_counter()
         lr = args.learning_rate * world / (10.0 if epoch < args.burnin else 1.0)   # runner.py:162-170
         for g in opt.param_groups:
