@@ -27,7 +27,8 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* workspace
     // in one kernel (81 / 116 against 115 / 141 us) and the bounded model's second stage still spills (n = 8: 2.83 against 2.05 ms).
     if (n >= 5 && n <= 8 && workspace != nullptr && !(a.f.flags & (SYMPA_FLAG_GENERIC | SYMPA_FLAG_COOP)) &&
         ((model == SYMPA_MODEL_UPPER && n >= 7) || (a.f.flags & SYMPA_FLAG_SPLIT)) &&
-        bwd_split_available(n, model) && workspace_bytes >= bwd_split_workspace_bytes(a.f.b, n, model))
+        bwd_split_available(n, model) && workspace_bytes >= bwd_split_workspace_bytes(a.f.b, n, model) &&
+        a.f.b < ((int64_t)1 << 29) - 64)          // its kernels address a pair inside a workspace entry with a 32-bit byte offset
         return launch_bwd_split(a, n, model, scatter, workspace, workspace_bytes, s);
     const bool det_mode = a.wave_partials != nullptr;
     if (det_mode && n > 8) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "wave_partials: dims 1..8");

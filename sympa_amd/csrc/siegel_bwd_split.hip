@@ -50,6 +50,8 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
     if (workspace == nullptr || workspace_bytes < bwd_split_workspace_bytes(a.f.b, n, model))
         return fail(SYMPA_ERR_BAD_ARG, "split backward: workspace smaller than sympa_siegel_backward_workspace_bytes(b, n, model)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(SYMPA_ERR_BAD_ARG, "split backward: workspace must be 16-byte aligned");
+    // the kernels address a pair inside a workspace entry with a 32-bit byte offset
+    if (padded(a.f.b) >= ((int64_t)1 << 29)) return fail(SYMPA_ERR_BAD_ARG, "split backward: at most 2^29 - 64 pairs per call");
     static_assert(sympa::AdjPack<8, sympa::MODEL_UPPER>::LEN == 2 * 8 + 3 * 28, "pack_len out of step with AdjPack");
     static_assert(sympa::AdjPack<5, sympa::MODEL_BOUNDED>::LEN == 2 * 5 + 4 * 10, "pack_len out of step with AdjPack");
     SplitArgs sa;
