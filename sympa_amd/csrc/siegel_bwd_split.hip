@@ -58,6 +58,10 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
     sa.a = a;
     sa.ws = static_cast<double*>(workspace);
     sa.ws_stride = padded(a.f.b);
+    // the spectral kernel staggers its first round of gathers like the dims 7, 8 forward: two rounds or more of a table beyond the L2s
+    sa.a.f.flags &= ~SYMPA_INTERNAL_FLAG_STAGGER;
+    if (a.f.idx1 != nullptr && a.f.b >= 2048 * 64 && a.f.num_rows * (int64_t)(16 * n * n) >= ((int64_t)12 << 20))
+        sa.a.f.flags |= SYMPA_INTERNAL_FLAG_STAGGER;
     const bool upper = model == SYMPA_MODEL_UPPER;
     int rc;
     switch (n) {

@@ -136,10 +136,18 @@ __device__ __forceinline__ void flush_plane_rows(const double sign, double* __re
 #define SYMPA_SPLIT_STAGGER_STEPS_GRAD 24
 #endif
 #ifndef SYMPA_SPLIT_STAGGER_STEPS_SPEC
-#define SYMPA_SPLIT_STAGGER_STEPS_SPEC 0
+#define SYMPA_SPLIT_STAGGER_STEPS_SPEC -40
 #endif
 template <int STEPS>
 __device__ __forceinline__ void split_stagger(const bool on) {
+    // STEPS < 0: the forward's scheme (siegel_dist_kernel.hpp) -- CU j of every XCD (blocks 32 j .. 32 j + 31 of the first 1 024) starts
+    // j x s_sleep(-STEPS) late: what spreads a GATHER burst (the spectral kernel: 703 -> 689 us fused step at -40; -20: 698, -60: 708)
+    if constexpr (STEPS < 0) {
+        if (on && blockIdx.x < 1024u) {
+            const int k = (int)((blockIdx.x >> 5) & 31u);
+            for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(-STEPS);
+        }
+    }
     if constexpr (STEPS > 0) {
         if (on && blockIdx.x < 1024u) {
             const int k = (int)((blockIdx.x * 5u) % (unsigned)STEPS);
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64, 1) void siegel_bwd_spectral_kernel(const SplitA
     using P = sympa::AdjPack<N, MODEL>;
     constexpr int WAVE_SLOTS = PassTile<N, false>::WAVE_SLOTS;
     __shared__ v2d lds[WAVE_SLOTS];
-    split_stagger<SYMPA_SPLIT_STAGGER_STEPS_SPEC>(gridDim.x >= 2048u);
+    split_stagger<SYMPA_SPLIT_STAGGER_STEPS_SPEC>((sa.a.f.flags & SYMPA_INTERNAL_FLAG_STAGGER) != 0);      // set by launch_bwd_split
     const BwdArgs& a = sa.a;
     DistArgs f = a.f;
     const double* graph_dist = a.graph_dist;
