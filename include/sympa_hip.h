@@ -189,7 +189,7 @@ int sympa_all_pairs_dist_packed(const double* table, int64_t num_rows, int n, in
  * metric value, fused loss, Hbar = V diag(phi) V^H and K = Hbar H scaled by go * scale into the workspace ([entry][pair] layout);
  * (2) factors and E again from the table rows, Ebar = 2 E Hbar, G = Ebar E^H / 2, the solves and congruences, scatter / rows.  The
  * whole adjoint in one lane spills ~1100 registers at n = 8 and the eight-lanes-per-pair kernel repeats the scalar QL in the lanes
- * of a pair; the split form does neither (fused step, upper n = 8, 262 144 pairs: 1.42 -> 0.81 ms).  It is the default where it
+ * of a pair; the split form does neither (fused step, upper n = 8, 262 144 pairs: 1.42 -> 0.81 ms, 0.68 ms on batches sorted by source row).  It is the default where it
  * measured faster (upper model, dims 7, 8); SYMPA_FLAG_SPLIT runs it for every model and dims 5..8.  NULL / too small /
  * SYMPA_FLAG_GENERIC / SYMPA_FLAG_COOP: the other kernels, as before (same results to ~1e-11 relative: the split form takes the
  * spectral weights from the QL's eigenvalues instead of the Rayleigh quotients ||E v_i||^2).  Returns 0 where no kernel uses one.

@@ -20,7 +20,7 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* workspace
     // window (step_counter) in every kernel family but the rolled one-lane kernels of dims 9..16
     // dims 5..8 with a workspace: the split backward (siegel_bwd_split_kernel.hpp), ONE pair per lane in two kernels -- the
     // eigen-decomposition with vectors is no longer redundant in the lanes of a pair (fused step, upper n = 8, 262 144 pairs:
-    // 1.42 ms eight lanes per pair -> 0.81 ms, profiles/r04_n8_backward_split.txt).  SYMPA_FLAG_GENERIC / SYMPA_FLAG_COOP or no
+    // 1.42 ms eight lanes per pair -> 0.81 ms (0.68 ms on batches sorted by source row), profiles/r04_n8_backward_split.txt).  SYMPA_FLAG_GENERIC / SYMPA_FLAG_COOP or no
     // (or too small a) workspace: the kernels below, as before.
     // Default where measured faster (tools/bwd_split_ab.py, fused step): upper n = 7 200 against 266 us (one pair per lane, one
     // kernel) per 65 536 pairs, n = 8 811 against 1 421 us (eight lanes per pair) per 262 144; dims 5, 6 fit one lane's registers
