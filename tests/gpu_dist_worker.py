@@ -7,7 +7,8 @@ collectives are device tensors, the kernels are the product's.
                                 sympa_amd.distributed.GradientExchange in `dense`, `rows` or `sharded` mode: rank r takes
                                 triplets r::world of the global batch, backward, exchange, clip + RiemannianSGD; rank 0 saves
                                 the resulting parameters
-    (exchange_spd / graphed_spd: the same for configs[4]'s model, spd n = 16, dense or sharded)
+    (exchange_spd / graphed_spd: the same for configs[4]'s model, spd n = 16, dense or sharded;
+     exchange_n8 / graphed_n8: configs[3]'s model, upper n = 8 at 2 048 pairs per rank: the split backward)
     graphed <mode> <out dir>    the same through sympa_amd.train_step.DistributedTrainStep (replayed graphs around the
                                 collective), three steps; graphed_det: with the deterministic local accumulation
     ddp <out dir>               the reference's own wrapper (train.py:59): DistributedDataParallel(Model) over RCCL at world
@@ -48,6 +49,9 @@ def global_batch(nodes, pairs, step=0):
 
 SHAPE = dict(manifold="upper", metric="wsum", dims=3, nodes=150, pairs=1024, lr=0.05, max_norm=0.7)
 SHAPE_SPD = dict(manifold="spd", metric="riem", dims=16, nodes=150, pairs=1024, lr=0.01, max_norm=0.7)     # configs[4]'s model
+# configs[3]'s model: 2 048 pairs per rank, so every rank takes the split backward (two kernels, workspace held by the step,
+# batches sorted by source row)
+SHAPE_N8 = dict(manifold="upper", metric="riem", dims=8, nodes=150, pairs=4096, lr=0.02, max_norm=0.7)
 
 
 def main():
@@ -66,6 +70,8 @@ def main():
         S = SHAPE
         if what.endswith("_spd"):
             what, S = what[:-4], SHAPE_SPD
+        elif what.endswith("_n8"):
+            what, S = what[:-3], SHAPE_N8
         if what in ("exchange", "graphed", "graphed_det"):
             mode, out = sys.argv[2], sys.argv[3]
             m = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
@@ -103,11 +109,12 @@ def main():
             dist.all_reduce(tot)                     # device tensor through the group's backend
             torch.cuda.synchronize()
             if rank == 0:
-                wts = m.manifold.metric.weights.detach().cpu() if S["manifold"] != "spd" else torch.zeros(1)
+                wts = getattr(getattr(m.manifold, "metric", None), "weights", None)      # only the wsum metric has weights
+                wts = wts.detach().cpu() if wts is not None else torch.zeros(1)
                 torch.save({"table": m.embeddings.embeds.detach().cpu(), "scale": m.scale.detach().cpu(),
                             "weights": wts, "loss": tot.cpu(), "world": world,
                             "steps": steps, "graphs_per_step": getattr(locals().get("st"), "graphs_per_step", None)},
-                           os.path.join(out, f"{what}_{mode}{'_spd' if S is SHAPE_SPD else ''}.pt"))
+                           os.path.join(out, f"{what}_{mode}{'_spd' if S is SHAPE_SPD else ('_n8' if S is SHAPE_N8 else '')}.pt"))
         elif what == "ddp":
             out = sys.argv[2]
             from torch.nn.parallel import DistributedDataParallel

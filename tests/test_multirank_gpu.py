@@ -72,13 +72,13 @@ def test_bench_two_ranks_on_one_gpu_shard_rank_by_rank_and_merge_to_the_single_p
     ops.check_status(dev)
 
 
-def _single_process_step(mode_steps, dev, spd=False):
+def _single_process_step(mode_steps, dev, spd=False, shape=None):
     """What ONE process computes for the union batch: DDP's mean over 2 ranks of the per-rank loss sums = half the union's
     gradient (loss_scale 0.5), learning rate x 2 (train.py:136), clip + RiemannianSGD."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gpu_dist_worker as w
     from sympa_amd.optim import RiemannianSGD
-    S = w.SHAPE_SPD if spd else w.SHAPE
+    S = shape if shape is not None else (w.SHAPE_SPD if spd else w.SHAPE)
     m = w.toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
     opt = RiemannianSGD(m.parameters(), lr=S["lr"] * 2, weight_decay=0.0, stabilize=None)
     total = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -181,6 +181,23 @@ def test_two_rank_spd_training_step_equals_the_single_process_step(tmp_path, wha
     steps = got["steps"]
     dev = torch.device("cuda:0")
     m, loss = _single_process_step(steps, dev, spd=True)
+    assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-10)
+    assert _close(got["scale"], m.scale.detach().cpu(), 1e-10)
+    assert _close(got["loss"], loss.cpu(), 1e-10)
+
+
+@pytest.mark.parametrize("what,mode", [("exchange_n8", "dense"), ("graphed_n8", "dense"), ("graphed_n8", "sharded")])
+def test_two_rank_dims8_training_step_with_the_split_backward_equals_the_single_process_step(tmp_path, what, mode):
+    """configs[3]'s model (upper, n = 8) at 2 048 pairs per rank: both ranks take the split backward (two kernels through a workspace
+    the step holds; DistributedTrainStep.load_epoch sorts every batch of the shard by source row) -- GradientExchange directly and
+    the replayed step in two processes sharing cuda:0 over gloo == the single-process step(s) on the union batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_dist_worker as w
+    _torchrun(2, [WORKER, what, mode, str(tmp_path)])
+    got = torch.load(os.path.join(str(tmp_path), f"{what[:-3]}_{mode}_n8.pt"))
+    assert got["world"] == 2
+    dev = torch.device("cuda:0")
+    m, loss = _single_process_step(got["steps"], dev, shape=w.SHAPE_N8)
     assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-10)
     assert _close(got["scale"], m.scale.detach().cpu(), 1e-10)
     assert _close(got["loss"], loss.cpu(), 1e-10)
