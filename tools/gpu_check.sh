@@ -80,6 +80,8 @@ echo "== round 4 (second session): split Siegel backward of dims 7, 8 (one pair 
   timeout 300 python3 tools/bwd_split_ab.py --dims 7,8 --models upper --sorted 2>&1 | grep "^upper"
   echo "# per-pair rows form:"
   timeout 300 python3 tools/bwd_split_ab.py --dims 7,8 --models upper --rows 2>&1 | grep "^upper"
+  echo "# soak against the one-stage kernels:"
+  timeout 300 python3 tools/fuzz_split_bwd.py 120 2>&1 | tail -1
 } | tee $OUT/split_ab.txt
 ( cd tools/microbench && hipcc --offload-arch=gfx950 -O3 -o atomic_rate atomic_rate.hip > /dev/null 2>&1 ); timeout 120 ./tools/microbench/atomic_rate 2>&1 | tee $OUT/atomic_rate.txt
 WORKLOADS=cartesian timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_cartesian -- python3 tools/train_step_time.py 20 > $OUT/prof_train_cartesian.log 2>&1
