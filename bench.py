@@ -278,6 +278,10 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not start the two rocprofv3 --pmc child runs that measure roofline.traffic live (N = 1 only); the "
                          "record then carries the committed counter pass of profiles/pmc_latest.json")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is repeated this many times (each repetition: barrier + synchronize, EXACTLY "
+                         "K steps, synchronize; the same warm-up in front of the first); ms_per_step / value are those of the MEDIAN "
+                         "repetition (max over ranks per repetition), ms_per_step_min / _max / _all are in the record")
     ap.add_argument("--distinct-batches", type=int, default=16)
     ap.add_argument("--graph-nodes", type=int, default=128,
                     help="kernel launches (= steps) captured per hipGraph")
@@ -342,8 +346,6 @@ def main():
     model, metric, n, nodes, batch = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    # pairs of one GLOBAL step and of this rank's shard of it
-    global_pairs = batch * world if args.scaling == "weak" else batch
     if model == "spd":
         table_cpu = data.spd_table(nodes, n, seed=args.seed)
     else:
@@ -351,48 +353,25 @@ def main():
                      else data.init_table(nodes, n, seed=args.seed))
     if args.table == "init" and model == "bounded":
         raise SystemExit("init table is defined for the upper model")
-    table = table_cpu.to(dev)
-    scale = torch.ones(1, dtype=torch.float64, device=dev)
-    # global batch j has `global_pairs` pairs; this rank takes the interleave rank::world of it
-    nb = max(1, min(args.distinct_batches, args.steps))
-    batches = []
-    if args.pairs == "sampled":
-        for j in range(nb):
-            glob = data.sample_pairs(nodes, global_pairs, j, args.seed)
-            batches.append(glob[rank::world].contiguous().to(dev))
-    else:
-        if args.workload not in GRAPH_OF:
-            raise SystemExit(f"--pairs {args.pairs}: no graph for workload {args.workload} (configs[3], [4] sample their pairs, "
-                             "SURVEY 8d)")
-        trip_all, id2node = data.graph_triplets(data.named_graph(GRAPH_OF[args.workload]))
-        assert len(id2node) == nodes
-        if args.pairs == "graph-shuffled":    # the order DistributedSampler(world 1, epoch 0) feeds the training loop
-            order = torch.tensor(data.distributed_sampler_indices(trip_all.shape[0], 1, 0, epoch=0, seed=args.seed))
-            trip_all = trip_all[order]
-        total = trip_all.shape[0]
-        for j in range(nb):                   # global batch j = triplets [j G, (j+1) G), wrapping around the split
-            rows = (torch.arange(global_pairs) + j * global_pairs) % total
-            batches.append(trip_all[rows][rank::world].contiguous().to(dev))
-    my_pairs = batches[0].shape[0]
-    outs = [torch.empty(my_pairs, dtype=torch.float64, device=dev) for _ in range(nb)]
     if args.launch == "fused" and (model == "spd" or n > 8):
         args.launch = "graph"          # no fused kernel for the sixteen-lanes-per-pair models
     if args.launch in ("direct", "fused"):
         args.streams = 1
     spl = max(1, min(args.steps_per_launch, ops.MAX_FUSED_BATCHES))
-    if args.streams <= 0:
-        # a launch of < 1 wave per SIMD (65 536 pairs) leaves SIMDs idle: more launches in flight
-        args.streams = 4 if my_pairs >= 65536 else 8
-    flags = ops.FLAG_LOW_LDS if (args.streams > 1 and not os.environ.get('SYMPA_BENCH_FULL_LDS')) else 0
-    flags |= int(os.environ.get('SYMPA_BENCH_FLAGS', '0'), 0)
+    nb = max(1, min(args.distinct_batches, args.steps))
 
-    def step(i, fl=None, dst=None):
-        o = (outs if dst is None else dst)[i % nb]
-        if model == "spd":
-            ops.spd_model_forward(table, batches[i % nb], scale, 1.0, out=o)
-            return
-        ops.model_forward(table, batches[i % nb], model, metric, None, scale, 1.0, out=o,
-                          flags=flags if fl is None else fl)
+    # the mirrored reference API: a Model whose table is the synthetic one; the fused timed region hands the K batches to
+    # Model.forward_batches as ONE list (plan built on first use, cached on the model)
+    class _A:       # the args object Model reads (model.py:8-14)
+        manifold, dims, num_points = model, n, nodes
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+    _A.metric = metric
+    net = Model(_A)
+    with torch.no_grad():
+        net.embeddings.embeds.data = table_cpu.clone()
+    net = net.to(dev)
+    table = net.embeddings.embeds.data      # the single-step kernels below read the same table
+    scale = net.scale.data
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -400,134 +379,128 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # ---- launch plan: K steps = K kernel launches, either direct or replayed from hipGraphs whose nodes are
-    # the launches themselves (a step is still exactly one kernel over one batch): a long graph (--graph-nodes
-    # launches) plus exact-size graphs for what is left of K and of W, so no step is launched from Python.
-    def capture(nodes_, streams=None, fl=None, dst=None):
-        streams = args.streams if streams is None else streams
-        g_ = torch.cuda.CUDAGraph()
-        side = [torch.cuda.Stream(device=dev) for _ in range(max(0, streams - 1))]
-        # thread_local: with N > 1 the RCCL watchdog thread polls events while we capture; only THIS thread's calls
-        # belong to the capture
-        with torch.cuda.graph(g_, capture_error_mode="thread_local"):
-            main_s = torch.cuda.current_stream()
-            for st in side:
-                st.wait_stream(main_s)                     # fork
-            for i in range(nodes_):
-                k = i % streams
-                if k == 0:
-                    step(i, fl, dst)
-                else:
-                    with torch.cuda.stream(side[k - 1]):
-                        step(i, fl, dst)
-            for st in side:
-                main_s.wait_stream(st)                     # join
-        return g_
+    class Region:
+        """The K steps of one scaling mode: this rank's shards of `nb` distinct global batches, their outputs, and the launch
+        plan (fused list / hipGraphs / direct calls) that runs k steps with no per-step host work."""
 
-    graphs = []          # [(nodes, graph)], longest first
-    gn = nb
-    if args.launch == "graph":
-        for i in range(nb):
-            step(i)            # warm (allocates the status word etc. outside capture)
-        torch.cuda.synchronize(dev)
-        gn = max(1, min(args.graph_nodes, args.steps))
-        graphs.append((gn, capture(gn)))
-        for rem in sorted({args.steps % gn, args.warmup % gn} - {0, gn}, reverse=True):
-            graphs.append((rem, capture(rem)))
+        def __init__(self, scaling):
+            self.scaling = scaling
+            # pairs of one GLOBAL step and of this rank's shard of it
+            self.global_pairs = batch * world if scaling == "weak" else batch
+            gp = self.global_pairs
+            self.batches = []
+            if args.pairs == "sampled":
+                for j in range(nb):     # global batch j has `gp` pairs; this rank takes the interleave rank::world of it
+                    glob = data.sample_pairs(nodes, gp, j, args.seed)
+                    self.batches.append(glob[rank::world].contiguous().to(dev))
+            else:
+                if args.workload not in GRAPH_OF:
+                    raise SystemExit(f"--pairs {args.pairs}: no graph for workload {args.workload} (configs[3], [4] sample their "
+                                     "pairs, SURVEY 8d)")
+                trip_all, id2node = data.graph_triplets(data.named_graph(GRAPH_OF[args.workload]))
+                assert len(id2node) == nodes
+                if args.pairs == "graph-shuffled":    # the order DistributedSampler(world 1, epoch 0) feeds the training loop
+                    order = torch.tensor(data.distributed_sampler_indices(trip_all.shape[0], 1, 0, epoch=0, seed=args.seed))
+                    trip_all = trip_all[order]
+                total = trip_all.shape[0]
+                for j in range(nb):                   # global batch j = triplets [j G, (j+1) G), wrapping around the split
+                    rows = (torch.arange(gp) + j * gp) % total
+                    self.batches.append(trip_all[rows][rank::world].contiguous().to(dev))
+            self.my_pairs = self.batches[0].shape[0]
+            self.outs = [torch.empty(self.my_pairs, dtype=torch.float64, device=dev) for _ in range(nb)]
+            self.streams = args.streams
+            if self.streams <= 0:
+                # a launch of < 1 wave per SIMD (65 536 pairs) leaves SIMDs idle: more launches in flight
+                self.streams = 4 if self.my_pairs >= 65536 else 8
+            self.flags = ops.FLAG_LOW_LDS if (self.streams > 1 and not os.environ.get('SYMPA_BENCH_FULL_LDS')) else 0
+            self.flags |= int(os.environ.get('SYMPA_BENCH_FLAGS', '0'), 0)
+            # ---- launch plan: K steps = K kernel launches, either direct or replayed from hipGraphs whose nodes are
+            # the launches themselves (a step is still exactly one kernel over one batch): a long graph (--graph-nodes
+            # launches) plus exact-size graphs for what is left of K and of W, so no step is launched from Python.
+            self.graphs = []          # [(nodes, graph)], longest first
+            self.gn = nb
+            for i in range(nb):
+                self.step(i)          # warm (allocates the status word etc. outside any capture)
+            torch.cuda.synchronize(dev)
+            if args.launch == "graph":
+                self.gn = max(1, min(args.graph_nodes, args.steps))
+                self.graphs.append((self.gn, self.capture(self.gn)))
+                for rem in sorted({args.steps % self.gn, args.warmup % self.gn} - {0, self.gn}, reverse=True):
+                    self.graphs.append((rem, self.capture(rem)))
+            self.lists, self.plans = {}, {}
 
-    fused = None
-    if args.launch == "fused":
-        for i in range(nb):
-            step(i)            # warm (allocates the status word)
-        torch.cuda.synchronize(dev)
+        def step(self, i, fl=None, dst=None):
+            o = (self.outs if dst is None else dst)[i % nb]
+            if model == "spd":
+                ops.spd_model_forward(table, self.batches[i % nb], scale, 1.0, out=o)
+                return
+            ops.model_forward(table, self.batches[i % nb], model, metric, None, scale, 1.0, out=o,
+                              flags=self.flags if fl is None else fl)
 
-        # the mirrored reference API: a Model whose table is the synthetic one; the timed region hands the K batches to
-        # Model.forward_batches as ONE list (plan built on first use, cached on the model)
-        class _A:       # the args object Model reads (model.py:8-14)
-            manifold, dims, num_points = model, n, nodes
-            scale_coef, scale_init, train_scale = 1.0, 1.0, False
-        _A.metric = metric
-        net = Model(_A)
-        with torch.no_grad():
-            net.embeddings.embeds.data = table_cpu.clone()
-        net = net.to(dev)
-        table = net.embeddings.embeds.data      # the single-step kernels below read the same table
-        scale = net.scale.data
+        def capture(self, nodes_, streams=None, fl=None, dst=None):
+            streams = self.streams if streams is None else streams
+            g_ = torch.cuda.CUDAGraph()
+            side = [torch.cuda.Stream(device=dev) for _ in range(max(0, streams - 1))]
+            # thread_local: with N > 1 the RCCL watchdog thread polls events while we capture; only THIS thread's calls
+            # belong to the capture
+            with torch.cuda.graph(g_, capture_error_mode="thread_local"):
+                main_s = torch.cuda.current_stream()
+                for st in side:
+                    st.wait_stream(main_s)                     # fork
+                for i in range(nodes_):
+                    k = i % streams
+                    if k == 0:
+                        self.step(i, fl, dst)
+                    else:
+                        with torch.cuda.stream(side[k - 1]):
+                            self.step(i, fl, dst)
+                for st in side:
+                    main_s.wait_stream(st)                     # join
+            return g_
 
-        class Fused:
-            """K steps = ceil(K / spl) launches of up to spl consecutive steps each (step i reads batches[i % nb],
-            writes dst[i % nb]).  spl = 32: Model.forward_batches(list of K batches), one C call; another spl (A/B
-            only): ops.BatchedForward ranges."""
-            def __init__(self, dst):
-                self.lists = {}
-                self.plans = {}
-                self.dst = dst
-
-            def lists_for(self, k):
-                if k not in self.lists:
-                    self.lists[k] = ([batches[i % nb] for i in range(k)], [self.dst[i % nb] for i in range(k)])
-                return self.lists[k]
-
-            def run(self, k):
-                bl, ol = self.lists_for(k)
-                if spl == ops.MAX_FUSED_BATCHES:
-                    # the mirrored API: the list is validated and its pointer arrays built ONCE (Model.prepare_batches, what a
-                    # caller with a fixed evaluation split does -- Model.evaluate keeps its plan the same way); a call is
-                    # then one C call.  (Handing the raw lists to forward_batches every time costs ~5 us more per call:
-                    # the identity key over 2 K tensors.)
-                    if k not in self.plans:
-                        self.plans[k] = net.prepare_batches(bl, ol)
-                    net.forward_batches(self.plans[k])
-                    return
+        def run_fused(self, k):
+            """K steps = ceil(K / spl) launches of up to spl consecutive steps each (step i reads batches[i % nb], writes
+            outs[i % nb]).  spl = 32: Model.forward_batches(list of K batches), one C call; another spl (A/B only):
+            ops.BatchedForward ranges."""
+            if k not in self.lists:
+                self.lists[k] = ([self.batches[i % nb] for i in range(k)], [self.outs[i % nb] for i in range(k)])
+            bl, ol = self.lists[k]
+            if spl == ops.MAX_FUSED_BATCHES:
+                # the mirrored API: the list is validated and its pointer arrays built ONCE (Model.prepare_batches, what a
+                # caller with a fixed evaluation split does -- Model.evaluate keeps its plan the same way); a call is
+                # then one C call.  (Handing the raw lists to forward_batches every time costs ~5 us more per call:
+                # the identity key over 2 K tensors.)
                 if k not in self.plans:
-                    self.plans[k] = ops.BatchedForward(table, bl, ol, model, metric, None, scale, 1.0,
-                                                       flags=ops.FLAG_FUSE)
-                p = self.plans[k]
-                p.set_streams(None)
-                for i0 in range(0, k, spl):
-                    p.run(i0, min(spl, k - i0))
+                    self.plans[k] = net.prepare_batches(bl, ol)
+                net.forward_batches(self.plans[k])
+                return
+            if k not in self.plans:
+                self.plans[k] = ops.BatchedForward(table, bl, ol, model, metric, None, scale, 1.0, flags=ops.FLAG_FUSE)
+            p = self.plans[k]
+            p.set_streams(None)
+            for i0 in range(0, k, spl):
+                p.run(i0, min(spl, k - i0))
 
-        fused = Fused(outs)
+        def run_steps(self, k):
+            if args.launch == "fused":
+                if k > 0:
+                    self.run_fused(k)
+                return
+            done = 0
+            for nodes_, g_ in self.graphs:
+                while k - done >= nodes_ and (nodes_ == self.gn or k - done == nodes_):
+                    g_.replay()
+                    done += nodes_
+            while done < k:
+                self.step(done)
+                done += 1
 
-    def run_steps(k):
-        if fused is not None:
-            if k > 0:
-                fused.run(k)
-            return
-        done = 0
-        for nodes_, g_ in graphs:
-            while k - done >= nodes_ and (nodes_ == gn or k - done == nodes_):
-                g_.replay()
-                done += nodes_
-        while done < k:
-            step(done)
-            done += 1
-
-    # clock / cache pre-warm (not part of the W warmup steps or the K timed steps): ~0.2 s of the same launches,
-    # so that a GPU coming out of idle has reached its sustained clock before the contractually timed region
-    prewarm_s = float(os.environ.get("SYMPA_BENCH_PREWARM_S", "0.2"))
-    pre_graph = None
-    if args.launch == "graph" and gn < args.graph_nodes and os.environ.get("SYMPA_BENCH_PREWARM_LONG"):
-        pre_graph = capture(args.graph_nodes)
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < prewarm_s:
-        if pre_graph is not None:
-            pre_graph.replay()
-        elif fused is not None:
-            run_steps(args.steps if args.steps <= 4 * spl else 4 * spl)     # launches of the timed region's shape
-        else:
-            run_steps(max(gn, nb))
-        torch.cuda.synchronize(dev)
-    run_steps(args.warmup)          # the W contractual warmup steps
-    if not os.environ.get("SYMPA_BENCH_NO_HOT_REPLAY"):
-        run_steps(args.steps)       # one more untimed pass of the exact launch plan of the timed region (hot graphs)
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0      # this rank's K steps; the MAX over ranks is taken below
-    sync_all()                              # closing barrier + synchronize (N > 1: an RCCL all-reduce of ~30 us -- the
-    #                                         clock is read before it, the slowest rank still sets the reported time)
+        def time(self, repeats):
+            """Pre-warm, the W warm-up steps, one untimed pass of the exact launch plan, then `repeats` repetitions of the
+            contractually timed region: barrier + synchronize, EXACTLY K steps, synchronize.  Returns this rank's elapsed
+            seconds per repetition."""
+            t_primary = over_ranks(primary.time(args.repeats))
+    elapsed = t_primary["elapsed"]
     timed_out0 = outs[0].clone()            # what the TIMED launches wrote for batch 0: the parity object checks this copy
     if os.environ.get("SYMPA_BENCH_DUMP"):
         os.makedirs(os.environ["SYMPA_BENCH_DUMP"], exist_ok=True)
@@ -545,12 +518,20 @@ def main():
     ops.check_status(dev)
     ranks_seen = 1
     if use_dist:
-        t = torch.tensor([elapsed, device_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([device_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, device_ms = float(t[0].item()), float(t[1].item())
+        device_ms = float(t[0].item())
         ones = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)       # every rank that took part in the timed region counts itself
         ranks_seen = int(ones.item())
+    # N > 1: the OTHER scaling mode in the same command -- `--scaling weak` (the default: B pairs per GPU per step) holds
+    # ">= 6x at 8 GPUs" by construction, the strong figure (the workload's B pairs per step in total, rank r takes r::N: the
+    # reference's semantics, train.py:105-110, per-process batch = batch / n_procs) is the one that shows scaling
+    t_other, other = None, None
+    if use_dist and not os.environ.get("SYMPA_BENCH_ONE_SCALING"):
+        other = Region("strong" if args.scaling == "weak" else "weak")
+        t_other = over_ranks(other.time(args.repeats))
+        ops.check_status(dev)
 
     # ---- every output of the timed variant against a strictly sequential pass of the default kernel form
     # (different instantiation when the timed region ran the minimum-LDS form): same arithmetic => bit-identical
@@ -698,7 +679,14 @@ def main():
                             else f"pairwise Siegel distances/sec ({model}, {metric}, n={n})"),
             "value": value, "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup,
+            # the MEDIAN of `repetitions` repetitions of the K-step timed region (each: barrier + synchronize, exactly K steps,
+            # synchronize; max over ranks per repetition); the spread and the first repetition are beside it
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_min": t_primary["min"] / args.steps * 1e3, "ms_per_step_max": t_primary["max"] / args.steps * 1e3,
+            "ms_per_step_first": t_primary["first"] / args.steps * 1e3,
+            "ms_per_step_all": [x / args.steps * 1e3 for x in t_primary["all"]], "repetitions": len(t_primary["all"]),
+            # fastest and slowest rank of the median repetition (K steps, milliseconds)
+            "elapsed_ranks_ms": {"min": t_primary["rank_min_of_median"] * 1e3, "max": t_primary["rank_max_of_median"] * 1e3},
             # HIP events on the launch stream around an identical repetition of the K steps (max over ranks): what the GPU
             # side of the timed region takes, launch latency of the first graph included
             "ms_per_step_device": device_ms / args.steps,
@@ -731,6 +719,17 @@ def main():
             "throughput_frac_of_hbm_roof": (value / world) * bpp / (HBM_PEAK_GBS * 1e9),
         }
         rec["config"]["steps_per_launch"] = min(spl, args.steps) if fused is not None else 1
+        rec["value_" + args.scaling] = value
+        rec["ms_per_step_" + args.scaling] = rec["ms_per_step"]
+        if t_other is not None:
+            o = other.scaling
+            rec["value_" + o] = other.global_pairs * args.steps / t_other["elapsed"]
+            rec["ms_per_step_" + o] = t_other["elapsed"] / args.steps * 1e3
+            rec["ms_per_step_" + o + "_min"] = t_other["min"] / args.steps * 1e3
+            rec["ms_per_step_" + o + "_max"] = t_other["max"] / args.steps * 1e3
+            rec["elapsed_ranks_ms_" + o] = {"min": t_other["rank_min_of_median"] * 1e3, "max": t_other["rank_max_of_median"] * 1e3}
+            rec["config"]["pairs_per_gpu_per_step_" + o] = other.my_pairs
+            rec["config"]["global_pairs_per_step_" + o] = other.global_pairs
         if default_kernel != timed_kernel:
             rec["roofline_default_kernel"] = roof(
                 default_kernel, k_default, my_pairs,

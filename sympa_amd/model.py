@@ -41,21 +41,43 @@ class Model(nn.Module):
                                         requires_grad=args.train_scale)
 
     def _forward_cache(self):
-        """(table, scale, wsum weights or None, model name, metric name): the attribute chains of forward() resolved once
-        -- nn.Module attribute lookups cost ~0.5 us each and a forward call is a 7 us kernel.  The Parameter objects are
-        stable (`.to(device)` and `embeds.data = ...` keep them), so the tuple is valid for the model's lifetime."""
+        """(table, scale, wsum weights or None, model name, metric name, + the owners the entries were read from): the
+        attribute chains of forward() resolved once -- nn.Module attribute lookups cost ~0.5 us each and a forward call is a
+        7 us kernel.  `.to(device)` and `embeds.data = ...` keep the Parameter objects; REPLACING one (`model.embeddings.embeds =
+        nn.Parameter(...)`, a new manifold or metric module) is seen by `_forward_cache_valid` (plain dict lookups on the owning
+        modules, ~0.2 us together) and the tuple is rebuilt, so forward() never runs on stale tensors while forward_batches /
+        distortion read the live attributes."""
         man = self.manifold
-        wsum = man.model_name != "spd" and man.metric.kind is MetricType.WEIGHTED_SUM
-        c = (self.embeddings.embeds, self.scale, man.metric.weights if wsum else None, man.model_name,
-             None if man.model_name == "spd" else man.metric.kind.value)
+        emb = self.embeddings
+        spd = man.model_name == "spd"
+        metric = None if spd else man.metric
+        wsum = (not spd) and metric.kind is MetricType.WEIGHTED_SUM
+        c = (emb.embeds, self.scale, metric.weights if wsum else None, man.model_name,
+             None if spd else metric.kind.value, emb, man, metric)
         self.__dict__["_fwd"] = c
         return c
+
+    def _forward_cache_valid(self, c):
+        emb, man, metric = c[5], c[6], c[7]
+        mods = self._modules
+        if mods.get("embeddings") is not emb or mods.get("manifold") is not man or self._parameters.get("scale") is not c[1]:
+            return False
+        if emb._parameters.get("embeds") is not c[0]:
+            return False
+        if metric is not None:
+            if man._modules.get("metric", man.__dict__.get("metric")) is not metric or metric.kind.value != c[4]:
+                return False
+            if c[2] is not None and metric._parameters.get("weights") is not c[2]:
+                return False
+        return True
 
     def forward(self, input_triplet):
         """input_triplet: int64 [b, 2|3] (src_id, dst_id[, graph_distance]) -> b distances * scale
         (model.py:16-30)."""
-        c = self.__dict__.get("_fwd") or self._forward_cache()
-        table, scale, weights, model_name, metric_name = c
+        c = self.__dict__.get("_fwd")
+        if c is None or not self._forward_cache_valid(c):
+            c = self._forward_cache()
+        table, scale, weights, model_name, metric_name = c[:5]
         if model_name == "spd":
             return sa.spd_model_forward(table, input_triplet, scale, self.scale_coef)
         if torch.is_grad_enabled() and (table.requires_grad or scale.requires_grad or
@@ -63,6 +85,14 @@ class Model(nn.Module):
             return sa.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
         # no autograd graph to build (Runner.evaluate / build_distance_matrix run under no_grad): straight to the binding
         return ops.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
+
+    def _metric_key(self):
+        """What a cached plan bakes in of the metric: its kind and the address of the wsum weights."""
+        man = self.manifold
+        if man.model_name == "spd":
+            return None
+        k = man.metric.kind
+        return (k.value, man.metric.weights.data_ptr() if k is MetricType.WEIGHTED_SUM else 0)
 
     # ---- lists of batches: the consumer is Runner.evaluate's loop (runner.py:124-135), one forward() per batch ----
     def prepare_batches(self, batches, outs=None):
@@ -100,7 +130,7 @@ class Model(nn.Module):
         if isinstance(batches, (list, tuple)):
             table = self.embeddings.embeds
             key = (tuple(map(id, batches)), None if outs is None else tuple(map(id, outs)),
-                   table.data_ptr(), self.scale.data_ptr())
+                   table.data_ptr(), self.scale.data_ptr(), self._metric_key())
             cache = self.__dict__.setdefault("_batch_plans", {})
             plan = cache.get(key)
             if plan is None:
@@ -123,7 +153,7 @@ class Model(nn.Module):
         if total == 0:
             raise ValueError("evaluate() over an empty split (statistics.mean raises in the reference too)")
         table = self.embeddings.embeds
-        key = (ids.data_ptr(), total, int(batch_size), table.data_ptr(), self.scale.data_ptr())
+        key = (ids.data_ptr(), total, int(batch_size), table.data_ptr(), self.scale.data_ptr(), self._metric_key())
         ev = self.__dict__.get("_eval_plan")
         if ev is None or ev[0] != key:
             out = torch.empty(total, dtype=torch.float64, device=table.device)

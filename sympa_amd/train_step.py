@@ -24,18 +24,26 @@ from sympa_amd import data, ops
 from sympa_amd.manifolds.metrics import MetricType
 
 
-def batches_want_source_order(model):
+def batches_want_source_order(model, batch_size=None):
     """True where the backward's scatter merges consecutive pairs with the same source row -- the split backward of the upper
     model at dims 8 (csrc/siegel_bwd_split_kernel.hpp) and the three-kernel spd backward at dims 9..16 (spd_coop_bwd3_kernel.hpp):
     there a batch sorted by its first column (data.sort_batches_by_source) is 10-15 % faster.  Everywhere else the sorted order puts
     the atomics of neighbouring lanes on the SAME rows and is slower (headline two-kernel step 62 -> 71 us, dims 7 fused step 200 ->
-    228 us per 65 536 pairs), so the batches are left in the sampler's order."""
+    228 us per 65 536 pairs), so the batches are left in the sampler's order.  The merging kernels run from 1 024 pairs per batch
+    on (ops: SYMPA_SIEGEL_BWD_WORKSPACE_MIN / SYMPA_SPD_BWD_WORKSPACE_MIN; smaller batches stay with the one-launch kernels, where
+    a sorted batch is slower), so with `batch_size` given the answer is False below that."""
     man = model.manifold
     dims = int(model.embeddings.embeds.shape[-1])
     name = getattr(man, "model_name", "")
     if os.environ.get("SYMPA_NO_BATCH_SORT"):
         return False
-    return (name == "upper" and dims == 8) or (name == "spd" and 9 <= dims <= 16)
+    if name == "upper" and dims == 8:
+        floor = int(os.environ.get("SYMPA_SIEGEL_BWD_WORKSPACE_MIN", "1024"))
+    elif name == "spd" and 9 <= dims <= 16:
+        floor = int(os.environ.get("SYMPA_SPD_BWD_WORKSPACE_MIN", "1024"))
+    else:
+        return False
+    return batch_size is None or int(batch_size) >= floor
 
 
 class GraphedTrainStep:
@@ -387,7 +395,7 @@ class GraphedTrainStep:
         steps = total // b
         if total > self.capacity:
             self._alloc_epoch(total)
-        if batches_want_source_order(self.model):      # the order inside a batch is free: equal source rows adjacent
+        if batches_want_source_order(self.model, b):      # the order inside a batch is free: equal source rows adjacent
             triplets = data.sort_batches_by_source(triplets, b)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
@@ -444,6 +452,10 @@ class DistributedTrainStep:
         if getattr(man, "model_name", None) not in ("upper", "bounded", "spd"):
             raise NotImplementedError("DistributedTrainStep: the Siegel models and spd")
         self.spd = man.model_name == "spd"
+        if self.spd and mode == "auto":
+            # the spd backward scatters a dense gradient and never writes per-pair rows: "auto" must not resolve to "rows"
+            # (it would on a large graph at the reference's default batch sizes, and every step would apply a zero gradient)
+            mode = "dense"
         if self.spd and mode == "rows":
             raise NotImplementedError("DistributedTrainStep: the spd model exchanges dense or sharded (configs[4]: 2 B > N)")
         if not isinstance(optimizer, RiemannianSGD):
@@ -454,6 +466,8 @@ class DistributedTrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.ex = GradientExchange(self.params, table=table, local_batch=self.batch_size, mode=mode, group=group)
         self.mode = self.ex.mode
+        if self.spd and self.mode == "rows":          # validated AFTER GradientExchange resolved the mode
+            raise NotImplementedError("DistributedTrainStep: the spd model exchanges dense or sharded, not touched rows")
         self.world = self.ex.world
         self.accumulate_loss = bool(accumulate_loss)
         # deterministic local accumulation (dense / sharded modes, dims <= 6): per-pair gradient rows + the segmented sum in a
@@ -649,7 +663,7 @@ class DistributedTrainStep:
         total = triplets.shape[0]
         if total > self.capacity:
             self._alloc(total)
-        if batches_want_source_order(self.model):      # the order inside a batch is free
+        if batches_want_source_order(self.model, self.batch_size):      # the order inside a batch is free
             triplets = data.sort_batches_by_source(triplets, self.batch_size)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])

@@ -52,6 +52,14 @@ SHAPE_SPD = dict(manifold="spd", metric="riem", dims=16, nodes=150, pairs=1024, 
 # configs[3]'s model: 2 048 pairs per rank, so every rank takes the split backward (two kernels, workspace held by the step,
 # batches sorted by source row)
 SHAPE_N8 = dict(manifold="upper", metric="riem", dims=8, nodes=150, pairs=4096, lr=0.02, max_norm=0.7)
+# world size 8 (round-4 review: rank::8, the sharded exchange's row PADDING -- 5 041 % 8 = 1, 45 500 % 8 = 4 -- had never run):
+# the headline's table and configs[3]'s table, 8 192 pairs per global batch (1 024 per rank: configs[3]'s ranks take the split backward)
+SHAPE_HEAD = dict(manifold="upper", metric="riem", dims=4, nodes=5041, pairs=8192, lr=0.05, max_norm=0.7)
+SHAPE_CFG3 = dict(manifold="upper", metric="riem", dims=8, nodes=45500, pairs=8192, lr=0.02, max_norm=0.7)
+# spd on a graph with more nodes than 2 x the global batch: GradientExchange's "auto" would pick the touched-rows exchange, which the
+# spd backward never feeds (round-4 advice, high): DistributedTrainStep must resolve it to dense
+SHAPE_SPDAUTO = dict(manifold="spd", metric="riem", dims=16, nodes=3000, pairs=1024, lr=0.01, max_norm=0.7)
+SHAPES = {"_spd": SHAPE_SPD, "_n8": SHAPE_N8, "_head": SHAPE_HEAD, "_cfg3": SHAPE_CFG3, "_spdauto": SHAPE_SPDAUTO}
 
 
 def main():
@@ -67,11 +75,11 @@ def main():
         from sympa_amd import ops
         from sympa_amd.distributed import GradientExchange
         from sympa_amd.optim import RiemannianSGD
-        S = SHAPE
-        if what.endswith("_spd"):
-            what, S = what[:-4], SHAPE_SPD
-        elif what.endswith("_n8"):
-            what, S = what[:-3], SHAPE_N8
+        S, suffix = SHAPE, ""
+        for sfx, shape in SHAPES.items():
+            if what.endswith(sfx):
+                what, S, suffix = what[:-len(sfx)], shape, sfx
+                break
         if what in ("exchange", "graphed", "graphed_det"):
             mode, out = sys.argv[2], sys.argv[3]
             m = toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
@@ -98,6 +106,7 @@ def main():
             else:
                 from sympa_amd.train_step import DistributedTrainStep
                 st = DistributedTrainStep(m, opt, b, S["max_norm"], dev, mode=mode, deterministic=(what == "graphed_det"))
+                resolved = st.mode
                 steps = 3
                 trip = torch.cat([global_batch(S["nodes"], S["pairs"], s)[rank::world] for s in range(steps)]).to(dev)
                 assert st.load_epoch(trip) == steps
@@ -113,8 +122,9 @@ def main():
                 wts = wts.detach().cpu() if wts is not None else torch.zeros(1)
                 torch.save({"table": m.embeddings.embeds.detach().cpu(), "scale": m.scale.detach().cpu(),
                             "weights": wts, "loss": tot.cpu(), "world": world,
-                            "steps": steps, "graphs_per_step": getattr(locals().get("st"), "graphs_per_step", None)},
-                           os.path.join(out, f"{what}_{mode}{'_spd' if S is SHAPE_SPD else ('_n8' if S is SHAPE_N8 else '')}.pt"))
+                            "steps": steps, "graphs_per_step": getattr(locals().get("st"), "graphs_per_step", None),
+                            "resolved_mode": locals().get("resolved", mode)},
+                           os.path.join(out, f"{what}_{mode}{suffix}.pt"))
         elif what == "ddp":
             out = sys.argv[2]
             from torch.nn.parallel import DistributedDataParallel
@@ -139,9 +149,15 @@ def main():
             torch.save(res, os.path.join(out, "ddp.pt"))
         else:
             raise SystemExit(f"unknown worker mode {what}")
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+    except BaseException:
+        # a failing rank must not wait for its peer in a barrier (the peer would sit in its own collective until the
+        # subprocess timeout and bury this traceback): print, tear the group down without synchronising, exit non-zero
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

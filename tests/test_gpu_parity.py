@@ -115,6 +115,37 @@ def test_model_class_is_a_drop_in(dev):
     assert rel_err((m.distance(z1, z2) * m.get_scale()).detach().cpu(), want) < TOL
 
 
+def test_model_forward_follows_replaced_parameters_and_modules(dev):
+    """Round-4 advice: forward() resolves its attribute chains once; REPLACING a Parameter object or the metric must not leave it
+    on the stale tensors while forward_batches / distortion read the live attributes."""
+    from sympa_amd import data, ops
+    from sympa_amd.manifolds.metrics import Metric, MetricType
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "upper", "riem", 3, 40
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A).to(dev)
+    trip = torch.randint(0, 40, (100, 3), device=dev)
+    with torch.no_grad():
+        first = m(trip).cpu()
+        # a NEW Parameter object (not `.data = ...`): the cached tuple must be rebuilt
+        new_table = data.trained_like_table(40, 3, model="upper", seed=5).to(dev)
+        m.embeddings.embeds = type(m.embeddings.embeds)(new_table, manifold=m.manifold)
+        got = m(trip).cpu()
+        want = so.model_forward(new_table.cpu(), trip.cpu(), "upper", "riem")
+        assert rel_err(got, want) < TOL and not torch.allclose(got, first)
+        assert torch.equal(m.forward_batches([trip])[0].cpu(), got)
+        # a new scale Parameter and another metric
+        m.scale = torch.nn.Parameter(torch.tensor([3.0], dtype=torch.float64, device=dev), requires_grad=False)
+        m.manifold.metric = Metric.get(MetricType.FINSLER_ONE, 3)
+        got = m(trip).cpu()
+        want = so.model_forward(new_table.cpu(), trip.cpu(), "upper", "fone", None, torch.tensor([3.0], dtype=torch.float64), 1.0)
+        assert rel_err(got, want) < TOL
+    ops.check_status(dev)
+
+
 def test_edge_cases(dev):
     from sympa_amd import ops
     g = torch.Generator().manual_seed(9)

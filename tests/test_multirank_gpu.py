@@ -72,24 +72,24 @@ def test_bench_two_ranks_on_one_gpu_shard_rank_by_rank_and_merge_to_the_single_p
     ops.check_status(dev)
 
 
-def _single_process_step(mode_steps, dev, spd=False, shape=None):
-    """What ONE process computes for the union batch: DDP's mean over 2 ranks of the per-rank loss sums = half the union's
-    gradient (loss_scale 0.5), learning rate x 2 (train.py:136), clip + RiemannianSGD."""
+def _single_process_step(mode_steps, dev, spd=False, shape=None, world=2):
+    """What ONE process computes for the union batch: DDP's mean over `world` ranks of the per-rank loss sums = 1 / world of the
+    union's gradient (loss_scale 1 / world), learning rate x world (train.py:136), clip + RiemannianSGD."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gpu_dist_worker as w
     from sympa_amd.optim import RiemannianSGD
     S = shape if shape is not None else (w.SHAPE_SPD if spd else w.SHAPE)
     m = w.toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], dev)
-    opt = RiemannianSGD(m.parameters(), lr=S["lr"] * 2, weight_decay=0.0, stabilize=None)
+    opt = RiemannianSGD(m.parameters(), lr=S["lr"] * world, weight_decay=0.0, stabilize=None)
     total = torch.zeros(1, dtype=torch.float64, device=dev)
     for s in range(mode_steps):
         trip = w.global_batch(S["nodes"], S["pairs"], s).to(dev)
         opt.zero_grad(set_to_none=False)
-        total += m.fused_loss_backward(trip[:, :2].contiguous(), trip[:, 2].to(torch.float64), loss_scale=0.5)
+        total += m.fused_loss_backward(trip[:, :2].contiguous(), trip[:, 2].to(torch.float64), loss_scale=1.0 / world)
         opt.clip_max_norm = S["max_norm"]
         opt.step()
         opt.clip_max_norm = None
-    return m, total * 2.0
+    return m, total * float(world)
 
 
 def _close(a, b, tol):
@@ -201,3 +201,100 @@ def test_two_rank_dims8_training_step_with_the_split_backward_equals_the_single_
     assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-10)
     assert _close(got["scale"], m.scale.detach().cpu(), 1e-10)
     assert _close(got["loss"], loss.cpu(), 1e-10)
+
+
+# ---- world size 8 on the one GPU (round-4 review, item 3: rank::8, ranks_seen == 8, the sharded exchange's row padding) --------
+
+def test_bench_eight_ranks_on_one_gpu_strong_scaling_merges_to_the_single_process_result(tmp_path):
+    """bench.py --gpus 8 --scaling strong end to end with eight fresh child ranks on cuda:0 over gloo: the headline batch of
+    65 536 pairs is sharded rank::8 (8 192 pairs per rank, train.py:105-110), ranks_seen == 8, the eight shards interleave bit for
+    bit to what ONE process computes, and the one record carries BOTH scaling modes with their spread."""
+    from sympa_amd import data, ops
+    dump = str(tmp_path / "dump")
+    args = ["--gpus", "8", "--steps", "6", "--warmup", "2", "--scaling", "strong", "--distinct-batches", "3", "--repeats", "3",
+            "--no-cpu-baseline", "--no-live-traffic"]
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          env=_env(SYMPA_BENCH_BACKEND="gloo", SYMPA_BENCH_SHARE_GPU="1", SYMPA_BENCH_DUMP=dump), timeout=1200,
+                          cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == 8 and rec["scaling"] == "strong"
+    assert rec["config"]["pairs_per_gpu_per_step"] == 8192 and rec["config"]["global_pairs_per_step"] == 65536
+    assert rec["config"]["pairs_per_gpu_per_step_weak"] == 65536 and rec["config"]["global_pairs_per_step_weak"] == 8 * 65536
+    assert rec["value_strong"] == rec["value"] and rec["value_weak"] > 0 and rec["ms_per_step_weak"] > 0
+    assert rec["repetitions"] == 3 and len(rec["ms_per_step_all"]) == 3
+    assert rec["ms_per_step_min"] <= rec["ms_per_step"] <= rec["ms_per_step_max"]
+    assert 0 < rec["elapsed_ranks_ms"]["min"] <= rec["elapsed_ranks_ms"]["max"]
+    assert rec["parity"]["ok"] and rec["parity"]["max_rel_err"] < 1e-8
+    shards = [torch.load(os.path.join(dump, f"rank{r}.pt")) for r in range(8)]
+    dev = torch.device("cuda:0")
+    table = data.trained_like_table(5041, 4, model="upper", seed=42).to(dev)
+    for j in range(3):
+        glob = data.sample_pairs(5041, 65536, j, 42)
+        want = ops.model_forward(table, glob.to(dev), "upper", "riem").cpu()
+        merged = torch.empty_like(want)
+        for r in range(8):
+            assert torch.equal(shards[r]["batches"][j][:, :2], glob[r::8][:, :2])
+            merged[r::8] = shards[r]["outs"][j]
+        assert torch.equal(merged, want), j
+    ops.check_status(dev)
+
+
+@pytest.mark.parametrize("shape,mode", [("head", "dense"), ("head", "sharded"), ("cfg3", "dense"), ("cfg3", "sharded")])
+def test_eight_rank_gradient_exchange_step_equals_the_single_process_step(tmp_path, shape, mode):
+    """One training step through GradientExchange in EIGHT processes sharing cuda:0 over gloo, on the headline's table (5 041
+    rows) and configs[3]'s (45 500 rows): neither divides by 8, so the sharded exchange pads the table gradient (631 x 8 = 5 048,
+    5 688 x 8 = 45 504 rows) and the last rank's shard is short -- == the single-process step on the union batch to 1e-12."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_dist_worker as w
+    S = w.SHAPES["_" + shape]
+    assert S["nodes"] % 8 != 0
+    _torchrun(8, [WORKER, f"exchange_{shape}", mode, str(tmp_path)], timeout=1200)
+    got = torch.load(os.path.join(str(tmp_path), f"exchange_{mode}_{shape}.pt"))
+    assert got["world"] == 8
+    dev = torch.device("cuda:0")
+    m, loss = _single_process_step(1, dev, shape=S, world=8)
+    assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-12)
+    assert _close(got["scale"], m.scale.detach().cpu(), 1e-12)
+    assert _close(got["loss"], loss.cpu(), 1e-12)
+    start = w.toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], torch.device("cpu")).embeddings.embeds.detach()
+    assert float((m.embeddings.embeds.detach().cpu() - start).abs().max()) > 1e-7          # the step did something
+    # the rows of the LAST (short) shard moved too
+    tail = slice(S["nodes"] - (S["nodes"] % 8), S["nodes"])
+    assert _close(got["table"][tail], m.embeddings.embeds.detach().cpu()[tail], 1e-12)
+
+
+def test_eight_rank_graphed_sharded_step_on_the_headline_table(tmp_path):
+    """DistributedTrainStep (replayed graphs around the exchange) at world size 8 in the sharded mode on the 5 041-row table:
+    three steps == three single-process steps on the union batches."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_dist_worker as w
+    _torchrun(8, [WORKER, "graphed_head", "sharded", str(tmp_path)], timeout=1200)
+    got = torch.load(os.path.join(str(tmp_path), "graphed_sharded_head.pt"))
+    assert got["world"] == 8 and got["steps"] == 3
+    dev = torch.device("cuda:0")
+    m, loss = _single_process_step(3, dev, shape=w.SHAPE_HEAD, world=8)
+    assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-11)
+    assert _close(got["loss"], loss.cpu(), 1e-11)
+
+
+def test_two_rank_spd_step_with_mode_auto_on_a_large_graph_resolves_to_dense_and_trains(tmp_path):
+    """Round-4 advice (high): tools/train_siegel.py hands DistributedTrainStep mode="auto"; with more nodes than 2 x the global
+    batch GradientExchange resolves that to the touched-rows exchange, which the spd backward never feeds -- every step applied
+    a ZERO table gradient.  The step now resolves "auto" to dense for spd (and rejects an explicit "rows"): three steps == the
+    single-process steps, and the table moved."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_dist_worker as w
+    S = w.SHAPE_SPDAUTO
+    assert S["nodes"] > 2 * S["pairs"]
+    _torchrun(2, [WORKER, "graphed_spdauto", "auto", str(tmp_path)])
+    got = torch.load(os.path.join(str(tmp_path), "graphed_auto_spdauto.pt"))
+    assert got["world"] == 2 and got["resolved_mode"] == "dense"
+    dev = torch.device("cuda:0")
+    m, loss = _single_process_step(got["steps"], dev, shape=S)
+    assert _close(got["table"], m.embeddings.embeds.detach().cpu(), 1e-10)
+    assert _close(got["loss"], loss.cpu(), 1e-10)
+    start = w.toy_model(S["manifold"], S["metric"], S["dims"], S["nodes"], torch.device("cpu")).embeddings.embeds.detach()
+    assert float((got["table"] - start).abs().max()) > 1e-6

@@ -87,7 +87,10 @@ def train(args, log=print):
             stepper = None
     for epoch in range(1, args.epochs + 1):
         mine = shard_triplets(trip, rank, world, epoch=epoch, seed=0).to(dev)
-        if batches_want_source_order(model):             # inside every batch: pairs with the same source row adjacent (free for SGD)
+        # inside every batch: pairs with the same source row adjacent (free for SGD) -- load_epoch of the replayed steps sorts
+        # by itself; only the eager per-batch loop needs it here (one argsort per epoch, not two)
+        loads_epoch = dstep is not None or (graphed is not None and graphed.mode == "two_kernels")
+        if not loads_epoch and batches_want_source_order(model, batch):
             mine = sort_batches_by_source(mine, batch)
         t0 = time.perf_counter()
         lr = args.learning_rate * world / (10.0 if epoch < args.burnin else 1.0)   # runner.py:162-170

@@ -23,7 +23,7 @@ from tests.helpers import spd_points  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda:0")
 # (name, manifold, metric, dims, nodes, batch)   -- BASELINE.json configs[0..4]
-WORKLOADS = [("grid", "upper", "riem", 2, 125, 512), ("tree", "upper", "riem", 4, 364, 8192),
+WORKLOADS = [("grid", "upper", "riem", 2, 125, 512), ("tree", "upper", "riem", 4, 1093, 8192),
              ("margulis", "bounded", "finf", 4, 5041, 65536), ("headline", "upper", "riem", 4, 5041, 65536),
              ("cartesian", "upper", "riem", 8, 45500, 262144), ("custom-spd", "spd", "riem", 16, 100000, 1048576)]
 only = os.environ.get("WORKLOADS")
