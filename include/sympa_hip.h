@@ -160,6 +160,39 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
                                 const double* metric_w, double eps, const double* scale, double scale_coef,
                                 double* const* out, int32_t* status, int flags, void* const* streams, int num_streams);
 
+/* ---- Packed table for the INDEXED forward, dims 5..8 (csrc/siegel_packed_kernel.hpp) ----------------------------------
+ * The reference's loops run many batches over an unchanged table: Runner.evaluate (sympa/runner.py:124-135), the N forward
+ * calls of the mAP matrix (runner.py:142-154), every Model.forward between two optimiser steps (sympa/model.py:16-30 with
+ * Embeddings.forward, sympa/embeddings.py:29-34).  sympa_table_pack factors every point ONCE per table version -- Y = L L^T
+ * (upper) / I - W W^H = C C^H (bounded) -- and writes one contiguous row per point: the upper triangles of both planes and the
+ * INVERTED factor (row stride sympa_table_pack_bytes(1, n, model) bytes: 864 at n = 8 upper, where the reference row is 1 024).
+ * The pair kernels then need no Cholesky and no solve: E = A1 (Z2 - Z1) A2^T.  A point outside the manifold is reported through
+ * `status` here (SYMPA_ST_NOT_PD) and flags every pair it enters later.
+ *   pack   caller-owned device buffer, 16-byte aligned, sympa_table_pack_bytes(num_rows, n, model) bytes (0 = this build has no
+ *          packed path for these dims / model: use sympa_model_forward); valid until the table changes (the caller keeps the
+ *          version: sympa_amd/model.py repacks when the ManifoldParameter's version counter has moved).
+ * sympa_model_forward_packed = sympa_model_forward reading `pack` instead of the table, in TWO kernels through a caller-owned
+ * workspace (sympa_model_forward_packed_workspace_bytes(b, n, model) bytes, 16-byte aligned): (1) gather + E + H = E^H E, one pair
+ * per lane, one 512-register wave per SIMD, persistent waves with the next tile's rows in flight behind the arithmetic, H (n^2
+ * doubles per pair) to the workspace; (2) eigenvalues of H + log + metric + scale at 256 registers = TWO waves per SIMD (the
+ * one-kernel forward of dims 7, 8 holds E and both factors next to H and never gets a second wave).  Same distances as
+ * sympa_model_forward to rounding (the arithmetic differs: ~1e-12 relative).
+ * sympa_model_forward_batches_packed: the list form (sympa_model_forward_batches); consecutive batches share a launch pair as far
+ * as their tiles fit `workspace` (at least one batch must fit), at most SYMPA_MAX_FUSED_BATCHES per pair; one stream. */
+int64_t sympa_table_pack_bytes(int64_t num_rows, int n, int model);
+int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes, int32_t* status,
+                     void* stream);
+int64_t sympa_model_forward_packed_workspace_bytes(int64_t b, int n, int model);
+int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
+                               int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
+                               const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
+                               int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
+int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n,
+                                       const int64_t* const* triplets, int64_t stride, const int64_t* b, int num_batches,
+                                       int model, int metric, const double* metric_w, double eps, const double* scale,
+                                       double scale_coef, double* const* out, int32_t* status, void* workspace,
+                                       int64_t workspace_bytes, int flags, void* stream);
+
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
  * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):
  *   out[(i - row_begin) * num_rows + j] = Model.forward((i, j)),  i in [row_begin, row_begin + row_count),  j in [0, N)

@@ -800,11 +800,11 @@ SYMPA_UNROLL
 // ascending vector-valued distance is written to vvd (if non-null) and status bits are OR-ed.
 // ---------------------------------------------------------------------------------------------
 // Second half of a pair: from E (sinh(v_i / 2) = sigma_i(E) / 2 upper, sigma_i(E) bounded) to the metric value.
+// From the Hermitian Gram matrix H = E^H E to the metric value (the packed forward evaluates this half in a kernel of its own,
+// csrc/siegel_packed_kernel.hpp: H is 2 n^2 registers where E and the factors are 6 n^2, so it runs two waves per SIMD).
 template <int N, int MODEL>
-SYMPA_HD double distance_from_e(const CMat<N>& e, const bool ok, int metric, const double* __restrict__ w,
+SYMPA_HD double distance_from_h(Herm<N>& h, const bool ok, int metric, const double* __restrict__ w,
                                 double inv_eps, double* __restrict__ vvd, int& status) {
-    Herm<N> h;
-    gram<N>(e, h);
     const bool conv = herm_eigenvalues<N>(h);
 
     const double scale = (MODEL == MODEL_UPPER) ? 0.25 : 1.0;
@@ -834,6 +834,14 @@ SYMPA_UNROLL
     if (!conv) status |= ST_NO_CONVERGENCE;
     if (!d_finite(out)) status |= ST_NONFINITE;
     return out;
+}
+
+template <int N, int MODEL>
+SYMPA_HD double distance_from_e(const CMat<N>& e, const bool ok, int metric, const double* __restrict__ w,
+                                double inv_eps, double* __restrict__ vvd, int& status) {
+    Herm<N> h;
+    gram<N>(e, h);
+    return distance_from_h<N, MODEL>(h, ok, metric, w, inv_eps, vvd, status);
 }
 
 template <int N, int MODEL>

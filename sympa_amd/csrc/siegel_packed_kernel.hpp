@@ -1,0 +1,337 @@
+// Indexed forward over a PACKED table, dims 5..8 (C-ABI sympa_table_pack / sympa_model_forward_packed): what Model.forward /
+// forward_batches / evaluate run while the table does not change between batches (sympa/model.py:16-30, sympa/embeddings.py:29-34,
+// sympa/runner.py:124-135,142-154: evaluation and the mAP matrix issue many batches over one table).
+//
+// (1) pack kernel, once per table version: every point is factored ONCE (Y = L L^T / I - W W^H = C C^H), the factor inverted, and
+//     the point's upper triangles + the inverted factor stored as ONE contiguous row of the packed table (PointPack of
+//     siegel_math.hpp: 108 doubles = 864 B at n = 8 upper where the reference row is 1 024 B).
+// (2) front kernel, one pair per lane, one 512-register wave per SIMD: the packed rows arrive through the LDS-DMA ring of
+//     siegel_gather.hpp (one coalesced instruction per row), E = A1 (Z2 - Z1) A2^T by two triangular products in place -- no
+//     Cholesky, no division, no square root --, H = E^H E, and H (n^2 doubles) + the pair's status word go to a caller-owned
+//     workspace laid out [tile of 64 pairs][entry][lane]: every store is 512 contiguous bytes.  The waves are PERSISTENT (grid =
+//     one wave per SIMD) and ask for the next tile's indices and first two passes before the current tile's arithmetic: the head of
+//     a tile (index load, first pass: latency a lone wave cannot hide) disappears behind the products of the previous one.
+// (3) eigen kernel, one pair per lane: H back from the workspace, Householder + lockstep QL, log1p, metric, scale.  Its live set is
+//     H (2 n^2 registers), not E + two factors (6 n^2): 256 registers, TWO waves per SIMD -- the 5 k instructions of the
+//     eigenvalue stage issue at the two-wave rate (~5.4 cycles per fp64 instruction instead of ~8.5 for a lone wave,
+//     profiles/r01_fp64_ubench.txt), which is what the one-kernel forward of dims 7, 8 could never reach.
+#pragma once
+#include "siegel_common.hpp"
+
+namespace sympa_hip {
+
+template <int N, int MODEL>
+struct PackRow {
+    using P = sympa::PointPack<N, MODEL>;
+    static constexpr int LEN = P::LEN;
+    static constexpr int K = (LEN + 1) / 2;                  // 16-byte chunks per packed row
+    static constexpr int ROW_DOUBLES = 2 * K;                // row stride of the packed table
+    static constexpr int PITCH = (K % 2 == 1) ? K : K + 1;   // LDS slots per row: odd, so ds_read_b128 is conflict-free
+    static constexpr int ROWS = 16;                          // rows per pass
+    static constexpr int IPP = ROWS * (K > 64 ? 2 : 1);      // LDS-DMA instructions per pass
+    static constexpr int BUF_SLOTS = ROWS * PITCH;
+    static constexpr int NBUF = 2;
+    static constexpr int WAVE_SLOTS = NBUF * BUF_SLOTS;
+    static constexpr int HLEN = N * N;                       // Herm<N>: d[N], then re / im of the strict upper part
+    static constexpr int WS_ENTRIES = HLEN + 1;              // + the pair's status word
+    static_assert(K <= 128, "a packed row is at most two DMA instructions");
+    static_assert(IPP <= 32, "vmcnt immediate");
+};
+
+constexpr int packed_dims_ok(int n) { return n >= 5 && n <= 8; }
+
+// ---- (1) pack ---------------------------------------------------------------------------------------------------------------
+template <int N, int MODEL>
+__global__ __launch_bounds__(64) void table_pack_kernel(const double* __restrict__ table, const int64_t num_rows,
+                                                        double* __restrict__ pack, int32_t* status) {
+    using R = PackRow<N, MODEL>;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t ii = i < num_rows ? i : num_rows - 1;
+    sympa::CMat<N> z;
+    sympa::load_point<N>(table + ii * (2 * N * N), z);
+    double p[R::ROW_DOUBLES];
+    double q[R::LEN];
+    const bool ok = sympa::pack_point<N, MODEL>(z, q);
+#pragma unroll
+    for (int k = 0; k < R::LEN; ++k) p[k] = q[k];
+    if constexpr (R::ROW_DOUBLES > R::LEN) p[R::LEN] = 0.0;
+    // a point outside the manifold has no factor: its inverted diagonal is stored as NaN, every pair it enters is flagged
+    // SYMPA_ST_NOT_PD by the front kernel and comes out NaN (the dense path reports the same bit)
+    if (!ok) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) p[R::P::OFF_DIAG + k] = __builtin_nan("");
+    }
+    if (i < num_rows) {
+        v2d* dst = reinterpret_cast<v2d*>(pack + i * R::ROW_DOUBLES);
+#pragma unroll
+        for (int c = 0; c < R::K; ++c) {
+            v2d v;
+            v.x = p[2 * c];
+            v.y = p[2 * c + 1];
+            dst[c] = v;
+        }
+    }
+    if (status != nullptr) {
+        const int bad = (i < num_rows && !ok) ? 1 : 0;
+        const unsigned long long m = __ballot(bad);
+        if (m != 0ull && (threadIdx.x & 63) == 0) {
+            atomicOr(&status[0], sympa::ST_NOT_PD);
+            atomicAdd(&status[1], (int)__popcll(m));
+        }
+    }
+}
+
+// ---- (2) front ----------------------------------------------------------------------------------------------------------------
+struct PackedArgs {
+    const double* pack;
+    int64_t num_rows;
+    const int64_t* idx1[SYMPA_MAX_FUSED_BATCHES];     // src ids of batch k, element i at idx1[k][i * stride1]
+    const int64_t* idx2[SYMPA_MAX_FUSED_BATCHES];
+    double* out[SYMPA_MAX_FUSED_BATCHES];
+    int64_t b[SYMPA_MAX_FUSED_BATCHES];
+    unsigned tile_end[SYMPA_MAX_FUSED_BATCHES];       // exclusive prefix end of batch k, in tiles of 64 pairs
+    int64_t stride1, stride2;
+    double* ws;                                       // [tiles][WS_ENTRIES][64]
+    const double* metric_w;
+    const double* scale;
+    double inv_scale_coef, inv_eps;
+    int32_t* status;
+    int metric;
+    int num_batches;
+    unsigned tiles;
+    int stagger;                                      // first round: CU j of every XCD starts j x 0.6 us late (tables beyond the L2s)
+};
+
+// batch of tile t: binary search over <= 32 prefix ends (wave-uniform, scalar)
+__device__ __forceinline__ int packed_batch_of(const PackedArgs& a, const unsigned t) {
+    int lo = 0, hi = a.num_batches - 1;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int mid = (lo + hi) >> 1;
+        const bool right = t >= a.tile_end[mid];
+        lo = right ? mid + 1 : lo;
+        hi = right ? hi : mid;
+    }
+    return lo;
+}
+
+// ids of this lane's pair of tile t (clamped for the idle tail lanes): the RAW loads only -- nothing here depends on the loaded
+// values, so the wave does not wait for them until packed_ids_check runs, a whole tile later
+__device__ __forceinline__ void packed_ids_load(const PackedArgs& a, const unsigned t, int64_t& x1, int64_t& x2) {
+    const int k = packed_batch_of(a, t);
+    const unsigned t0 = (k == 0) ? 0u : a.tile_end[k - 1];
+    const int64_t i = (int64_t)(t - t0) * 64 + (threadIdx.x & 63);
+    const int64_t ii = i < a.b[k] ? i : a.b[k] - 1;
+    x1 = __builtin_nontemporal_load(a.idx1[k] + ii * a.stride1);
+    x2 = __builtin_nontemporal_load(a.idx2[k] + ii * a.stride2);
+}
+// out-of-range ids are flagged and replaced by row 0 (the reference raises IndexError)
+__device__ __forceinline__ void packed_ids_check(const PackedArgs& a, int64_t x1, int64_t x2, int& r1, int& r2, int& st) {
+    st = 0;
+    if (x1 < 0 || x1 >= a.num_rows || x2 < 0 || x2 >= a.num_rows) {
+        st = sympa::ST_BAD_INDEX;
+        x1 = 0;
+        x2 = 0;
+    }
+    r1 = (int)x1;
+    r2 = (int)x2;
+}
+
+template <int N, int MODEL>
+__device__ __forceinline__ void packed_pass_issue(const double* __restrict__ base, const int row, const int pass,
+                                                  v2d* __restrict__ buf) {
+    using R = PackRow<N, MODEL>;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < R::ROWS; ++j) {
+        const int rr = __shfl(row, 16 * pass + j);
+        const double* src = base + (int64_t)rr * R::ROW_DOUBLES + 2 * lane;
+        if (R::K >= 64 || lane < R::K)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * R::PITCH), 16, 0, 0);
+        if constexpr (R::K > 64) {
+            if (lane < R::K - 64)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 128), (lds_ptr_t)(buf + j * R::PITCH + 64), 16, 0, 0);
+        }
+    }
+}
+
+template <int N, int MODEL>
+__device__ __forceinline__ void packed_pass_read(const v2d* __restrict__ buf, const int pass, double (&p)[PackRow<N, MODEL>::ROW_DOUBLES]) {
+    using R = PackRow<N, MODEL>;
+    const int lane = threadIdx.x & 63;
+    if ((lane >> 4) == pass) {
+        const v2d* mine = buf + (lane & 15) * R::PITCH;
+#pragma unroll
+        for (int c = 0; c < R::K; ++c) {
+            const v2d q = mine[c];
+            p[2 * c] = q.x;
+            p[2 * c + 1] = q.y;
+        }
+    }
+}
+
+// SYMPA_PACKED_PREFETCH: 1 (product) persistent waves with the next tile's head in flight behind the arithmetic; 0 keeps the
+// loop but issues a tile's first passes at its own top (A/B hook of tools/build_variant.sh)
+#ifndef SYMPA_PACKED_PREFETCH
+#define SYMPA_PACKED_PREFETCH 1
+#endif
+
+template <int N, int MODEL>
+__global__ __launch_bounds__(64, 1) void packed_front_kernel(const PackedArgs a) {
+    using R = PackRow<N, MODEL>;
+    using P = sympa::PointPack<N, MODEL>;
+    __shared__ v2d tile[R::WAVE_SLOTS];
+    v2d* buf0 = tile;
+    v2d* buf1 = tile + R::BUF_SLOTS;
+    if (a.stagger && blockIdx.x < 1024u) {
+        const int k = (int)((blockIdx.x >> 5) & 31u);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
+    }
+    unsigned t = blockIdx.x;
+    if (t >= a.tiles) return;
+    int r1, r2, st;
+    int64_t x1, x2;
+    packed_ids_load(a, t, x1, x2);
+    packed_ids_check(a, x1, x2, r1, r2, st);
+    packed_pass_issue<N, MODEL>(a.pack, r1, 0, buf0);
+    packed_pass_issue<N, MODEL>(a.pack, r1, 1, buf1);
+    // the ids of the NEXT tile are always one tile ahead of the passes that need them (loaded behind the previous prefetch)
+    unsigned tn = t + gridDim.x;
+    bool more = tn < a.tiles;                      // wave-uniform
+    x1 = 0;
+    x2 = 0;
+    if (more) packed_ids_load(a, tn, x1, x2);
+    for (;;) {
+        // the ring below counts on the DMA passes of THIS tile being the only outstanding vector-memory operations
+        __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0): passes 0, 1 (issued long ago), the next ids, the previous tile's stores
+        double p1[R::ROW_DOUBLES], p2[R::ROW_DOUBLES];
+#pragma unroll
+        for (int k = 0; k < R::ROW_DOUBLES; ++k) { p1[k] = 0.0; p2[k] = 0.0; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            // pass s has landed: s = 0 by the vmcnt(0) above; then at most the IPP instructions of pass s + 1 are outstanding
+            if (s > 0) {
+                if (s + 1 < 8) wait_vmcnt<R::IPP>();
+                else wait_vmcnt<0>();
+            }
+            wave_lds_fence();
+            const v2d* cur = (s & 1) ? buf1 : buf0;
+            if (s < 4) packed_pass_read<N, MODEL>(cur, s, p1);
+            else packed_pass_read<N, MODEL>(cur, s - 4, p2);
+            if (s + 2 < 8) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the reads of the buffer being refilled are complete
+                wave_lds_fence();
+                v2d* nxt = (s & 1) ? buf1 : buf0;
+                if (s + 2 < 4) packed_pass_issue<N, MODEL>(a.pack, r1, s + 2, nxt);
+                else packed_pass_issue<N, MODEL>(a.pack, r2, s + 2 - 4, nxt);
+            }
+        }
+        // the head of the next tile goes out before this tile's arithmetic, the ids of the one after that behind it
+        const unsigned tnn = tn + gridDim.x;
+        const bool more2 = more && tnn < a.tiles;
+        int n1 = 0, n2 = 0, nst = 0;
+        if (more) packed_ids_check(a, x1, x2, n1, n2, nst);     // (loaded a tile ago)
+        if (SYMPA_PACKED_PREFETCH && more) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            wave_lds_fence();
+            packed_pass_issue<N, MODEL>(a.pack, n1, 0, buf0);
+            packed_pass_issue<N, MODEL>(a.pack, n1, 1, buf1);
+        }
+        if (more2) packed_ids_load(a, tnn, x1, x2);
+        // ---- arithmetic of tile t
+        const bool ok = sympa::d_finite(p1[P::OFF_DIAG]) && sympa::d_finite(p2[P::OFF_DIAG]);
+        sympa::Herm<N> h;
+        {
+            sympa::CMat<N> e;
+            sympa::e_from_packed<N, MODEL>(p1, p2, e);
+            sympa::gram<N>(e, h);
+        }
+        const int flags = st | (ok ? 0 : sympa::ST_NOT_PD);
+        if (st & sympa::ST_BAD_INDEX) h.d[0] = __builtin_nan("");
+        double* w = a.ws + ((int64_t)t * R::WS_ENTRIES) * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int j = 0; j < N; ++j) __builtin_nontemporal_store(h.d[j], w + (int64_t)j * 64);
+        {
+            int e_ = N;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+#pragma unroll
+                for (int k = j + 1; k < N; ++k) {
+                    __builtin_nontemporal_store(h.re[j][k], w + (int64_t)e_ * 64);
+                    __builtin_nontemporal_store(h.im[j][k], w + (int64_t)(e_ + 1) * 64);
+                    e_ += 2;
+                }
+        }
+        __builtin_nontemporal_store((double)flags, w + (int64_t)R::HLEN * 64);
+        if (!more) break;
+        if (!SYMPA_PACKED_PREFETCH) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            wave_lds_fence();
+            packed_pass_issue<N, MODEL>(a.pack, n1, 0, buf0);
+            packed_pass_issue<N, MODEL>(a.pack, n1, 1, buf1);
+        }
+        t = tn; r1 = n1; r2 = n2; st = nst;
+        tn = tnn; more = more2;
+    }
+}
+
+// ---- (3) eigen ----------------------------------------------------------------------------------------------------------------
+#ifndef SYMPA_PACKED_EIGEN_WAVES
+#define SYMPA_PACKED_EIGEN_WAVES 2
+#endif
+template <int N, int MODEL>
+__global__ __launch_bounds__(64, SYMPA_PACKED_EIGEN_WAVES) void packed_eigen_kernel(const PackedArgs a) {
+    using R = PackRow<N, MODEL>;
+    const unsigned t = blockIdx.x;
+    const int k = packed_batch_of(a, t);
+    const unsigned t0 = (k == 0) ? 0u : a.tile_end[k - 1];
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)(t - t0) * 64 + lane;
+    const bool live = i < a.b[k];
+    const double* w = a.ws + ((int64_t)t * R::WS_ENTRIES) * 64 + lane;
+    sympa::Herm<N> h;
+#pragma unroll
+    for (int j = 0; j < N; ++j) h.d[j] = __builtin_nontemporal_load(w + (int64_t)j * 64);
+    int e_ = N;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int q = j + 1; q < N; ++q) {
+            h.re[j][q] = __builtin_nontemporal_load(w + (int64_t)e_ * 64);
+            h.im[j][q] = __builtin_nontemporal_load(w + (int64_t)(e_ + 1) * 64);
+            e_ += 2;
+        }
+    int st = (int)__builtin_nontemporal_load(w + (int64_t)R::HLEN * 64);
+    double d = sympa::distance_from_h<N, MODEL>(h, true, a.metric, a.metric_w, a.inv_eps, nullptr, st);
+    if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
+    if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
+    if (live) __builtin_nontemporal_store(d, a.out[k] + i);
+    if (a.status != nullptr) {
+        const int flagged = (live && st != 0) ? 1 : 0;
+        const unsigned long long m = __ballot(flagged);
+        if (m != 0ull) {
+            if (flagged) atomicOr(&a.status[0], st);
+            if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(m));
+        }
+    }
+}
+
+template <int N, int MODEL>
+int launch_table_pack(const double* table, int64_t num_rows, double* pack, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL((table_pack_kernel<N, MODEL>), dim3((unsigned)((num_rows + 63) / 64)), dim3(64), 0, s, table, num_rows, pack,
+                       status);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+template <int N, int MODEL>
+int launch_packed_forward(const PackedArgs& a, unsigned front_grid, hipStream_t s) {
+    hipLaunchKernelGGL((packed_front_kernel<N, MODEL>), dim3(front_grid), dim3(64), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    hipLaunchKernelGGL((packed_eigen_kernel<N, MODEL>), dim3(a.tiles), dim3(64), 0, s, a);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+}  // namespace sympa_hip
