@@ -171,27 +171,25 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
  *   pack   caller-owned device buffer, 16-byte aligned, sympa_table_pack_bytes(num_rows, n, model) bytes (0 = this build has no
  *          packed path for these dims / model: use sympa_model_forward); valid until the table changes (the caller keeps the
  *          version: sympa_amd/model.py repacks when the ManifoldParameter's version counter has moved).
- * sympa_model_forward_packed = sympa_model_forward reading `pack` instead of the table, in TWO kernels through a caller-owned
- * workspace (sympa_model_forward_packed_workspace_bytes(b, n, model) bytes, 16-byte aligned): (1) gather + E + H = E^H E, one pair
- * per lane, one 512-register wave per SIMD, persistent waves with the next tile's rows in flight behind the arithmetic, H (n^2
- * doubles per pair) to the workspace; (2) eigenvalues of H + log + metric + scale at 256 registers = TWO waves per SIMD (the
- * one-kernel forward of dims 7, 8 holds E and both factors next to H and never gets a second wave).  Same distances as
- * sympa_model_forward to rounding (the arithmetic differs: ~1e-12 relative).
- * sympa_model_forward_batches_packed: the list form (sympa_model_forward_batches); consecutive batches share a launch pair as far
- * as their tiles fit `workspace` (at least one batch must fit), at most SYMPA_MAX_FUSED_BATCHES per pair; one stream. */
+ * sympa_model_forward_packed = sympa_model_forward reading `pack` instead of the table: one pair per lane, PERSISTENT one-wave blocks
+ * (grid = what the chip holds at once), the next tile's ids and first rows in flight behind the current tile's arithmetic, the first
+ * point's triangles subtracted from the second's in place as they arrive (no scratch in any instantiation: bounded n = 8 runs 245 ->
+ * 163 us per 262 144 pairs, upper n = 8 135 -> 127, n = 6 85 -> 68; profiles/r05_packed_forward.txt).  Same distances as
+ * sympa_model_forward to rounding (~1e-15 relative on the bench tables; the arithmetic differs: products with the inverted factor
+ * instead of triangular solves).
+ * sympa_model_forward_batches_packed: the list form (sympa_model_forward_batches); up to SYMPA_MAX_FUSED_BATCHES consecutive batches
+ * share a launch; one stream. */
 int64_t sympa_table_pack_bytes(int64_t num_rows, int n, int model);
 int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes, int32_t* status,
                      void* stream);
-int64_t sympa_model_forward_packed_workspace_bytes(int64_t b, int n, int model);
 int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
                                int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                                const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
-                               int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
+                               int32_t* status, int flags, void* stream);
 int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n,
                                        const int64_t* const* triplets, int64_t stride, const int64_t* b, int num_batches,
                                        int model, int metric, const double* metric_w, double eps, const double* scale,
-                                       double scale_coef, double* const* out, int32_t* status, void* workspace,
-                                       int64_t workspace_bytes, int flags, void* stream);
+                                       double scale_coef, double* const* out, int32_t* status, int flags, void* stream);
 
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
  * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):

@@ -22,6 +22,10 @@ SYMBOLS = (
     "sympa_siegel_dist_fwd",
     "sympa_model_forward",
     "sympa_model_forward_batches",
+    "sympa_table_pack_bytes",
+    "sympa_table_pack",
+    "sympa_model_forward_packed",
+    "sympa_model_forward_batches_packed",
     "sympa_all_pairs_dist",
     "sympa_all_pairs_workspace_bytes",
     "sympa_all_pairs_dist_packed",
@@ -260,6 +264,19 @@ def load():
     lib.sympa_spd_rsgd_step.restype = ctypes.c_int
     lib.sympa_spd_rsgd_step.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_double, _c_double_p, ctypes.c_double, _c_i32_p, ctypes.c_void_p]
+    C = ctypes
+    lib.sympa_table_pack_bytes.restype = C.c_int64
+    lib.sympa_table_pack_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
+    lib.sympa_table_pack.restype = C.c_int
+    lib.sympa_table_pack.argtypes = [_c_double_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, _c_i32_p, C.c_void_p]
+    lib.sympa_model_forward_packed.restype = C.c_int
+    lib.sympa_model_forward_packed.argtypes = [
+        C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_i64_p, C.c_int64, _c_i64_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+        _c_double_p, C.c_double, _c_double_p, C.c_double, _c_double_p, _c_i32_p, C.c_int, C.c_void_p]
+    lib.sympa_model_forward_batches_packed.restype = C.c_int
+    lib.sympa_model_forward_batches_packed.argtypes = [
+        C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
+        _c_double_p, C.c_double, _c_double_p, C.c_double, C.c_void_p, _c_i32_p, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 

@@ -360,7 +360,12 @@ __device__ __forceinline__ void pass_issue(const double* __restrict__ base, cons
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < PassTile<N>::ROWS; ++j) {
-        const int rr = __shfl(row, 16 * pass + j);
+        // full rows (upper model): v_readlane -- the source lane is a compile-time constant, the row index arrives in a scalar
+        // register and the row's base address is scalar arithmetic.  __shfl makes this a ds_bpermute + wait + v_readfirstlane per
+        // DMA instruction, 128 serialised LDS round trips per wave: upper n = 8 135.4 -> 130.8 us, n = 7 119.3 -> 114.7 per 262 144
+        // pairs (profiles/r05_packed_forward.txt).  The masked form (bounded model) keeps __shfl: with v_readlane its n = 8
+        // kernel allocates differently and runs 245 -> 283 us.
+        const int rr = MASKED ? __shfl(row, 16 * pass + j) : __builtin_amdgcn_readlane(row, 16 * pass + j);
         const double* src = base + (int64_t)rr * (2 * N * N) + 2 * my_chunk;
         if (K == 64 || lane < K)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);

@@ -957,7 +957,9 @@ SYMPA_UNROLL
 // from the last to the first (row r of T needs rows k <= r of D only), then E = T A2^T with the columns taken from the last
 // to the first -- the products of an 8 x 8 pair then fit the register file next to nothing else (the ascending order kept
 // D, T and E alive together: 384 doubles).  Every entry of p1 / p2 is read once (twice for the points themselves).
-template <int N, int MODEL, class P1, class P2>
+// DIFF: the point part of p2 already holds Z2 - Z1 (the packed forward subtracts the chunks of the first point as they arrive:
+// no second copy of a point's triangles is ever alive) and the point part of p1 is not read.
+template <int N, int MODEL, bool DIFF = false, class P1, class P2>
 SYMPA_HD void e_from_packed(const P1& p1, const P2& p2, CMat<N>& e) {
     using P = PointPack<N, MODEL>;
     constexpr bool CPLX = MODEL != MODEL_UPPER;
@@ -966,8 +968,9 @@ SYMPA_UNROLL
     for (int i = 0; i < N; ++i)
 SYMPA_UNROLL
         for (int j = i; j < N; ++j) {
-            const double xr = p2[tri_index(N, i, j)] - p1[tri_index(N, i, j)];
-            const double xi = p2[P::OFF_IM + tri_index(N, i, j)] - p1[P::OFF_IM + tri_index(N, i, j)];
+            const double xr = DIFF ? p2[tri_index(N, i, j)] : p2[tri_index(N, i, j)] - p1[tri_index(N, i, j)];
+            const double xi = DIFF ? p2[P::OFF_IM + tri_index(N, i, j)]
+                                   : p2[P::OFF_IM + tri_index(N, i, j)] - p1[P::OFF_IM + tri_index(N, i, j)];
             e.re[i][j] = xr; e.im[i][j] = xi;
             e.re[j][i] = xr; e.im[j][i] = xi;
         }

@@ -1,5 +1,5 @@
 // C-ABI of the packed indexed forward, dims 5..8 (siegel_packed_kernel.hpp): sympa_table_pack_bytes / sympa_table_pack /
-// sympa_model_forward_packed_workspace_bytes / sympa_model_forward_packed / sympa_model_forward_batches_packed.
+// sympa_model_forward_packed / sympa_model_forward_batches_packed.
 // Compiled like siegel_dist_big.hip without the pre-RA machine scheduler (__graft_entry__.py: the fully unrolled dims-8 bodies keep
 // the source order).
 #include "siegel_packed_kernel.hpp"
@@ -13,11 +13,11 @@ int pack_row_doubles(int n, int model) {
     return 2 * ((len + 1) / 2);
 }
 
-int simd_count() {
+int cu_count() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
-    return 4 * cus;
+    return cus;
 }
 
 template <int N>
@@ -47,7 +47,7 @@ int check_common(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, 
     return 0;
 }
 
-// one front + one eigen launch over the batches [i0, i0 + cnt) (cnt <= SYMPA_MAX_FUSED_BATCHES; their tiles fit the workspace)
+// one launch over the batches [i0, i0 + cnt) (cnt <= SYMPA_MAX_FUSED_BATCHES)
 int launch_group(PackedArgs& a, int n, int model, const int64_t* const* idx1, const int64_t* const* idx2, const int64_t* b,
                  double* const* out, int cnt, hipStream_t s) {
     uint64_t tiles = 0;
@@ -72,10 +72,9 @@ int launch_group(PackedArgs& a, int n, int model, const int64_t* const* idx1, co
     }
     a.num_batches = k;
     a.tiles = (unsigned)tiles;
-    const unsigned simds = (unsigned)simd_count();
-    const unsigned grid = a.tiles < simds ? a.tiles : simds;
+    const unsigned grid = (unsigned)cu_count();          // (the launcher turns it into resident one-wave blocks)
     // staggered first round (siegel_dist_kernel.hpp): dims 7, 8, upper model, tables beyond the L2s, two rounds or more
-    a.stagger = (n >= 7 && model == SYMPA_MODEL_UPPER && a.tiles >= 2 * simds &&
+    a.stagger = (n >= 7 && model == SYMPA_MODEL_UPPER && a.tiles >= 8 * grid &&
                  a.num_rows * (int64_t)pack_row_doubles(n, model) * 8 >= ((int64_t)12 << 20)) ? 1 : 0;
     switch (n) {
         case 5: return forward_n<5>(a, grid, model, s);
@@ -116,16 +115,10 @@ int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, vo
     return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed table: dims 5..8");
 }
 
-int64_t sympa_model_forward_packed_workspace_bytes(int64_t b, int n, int model) {
-    if (b <= 0 || !packed_dims_ok(n)) return 0;
-    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return 0;
-    return ((b + 63) / 64) * (int64_t)(n * n + 1) * 64 * 8;
-}
-
 int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
                                int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                                const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
-                               int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
+                               int32_t* status, int flags, void* stream) {
     (void)flags;
     if (b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (b == 0) return 0;
@@ -133,16 +126,12 @@ int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num
     if (rc != 0) return rc;
     if (src == nullptr || dst == nullptr || out == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
     if (b > (int64_t)0x7fffffff * 32) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
-    if (workspace == nullptr || workspace_bytes < sympa_model_forward_packed_workspace_bytes(b, n, model) ||
-        (reinterpret_cast<uintptr_t>(workspace) & 15))
-        return fail(SYMPA_ERR_BAD_ARG, "workspace: 16-byte aligned, sympa_model_forward_packed_workspace_bytes(b, n, model) bytes");
     PackedArgs a;
     std::memset(&a, 0, sizeof(a));
     a.pack = reinterpret_cast<const double*>(pack);
     a.num_rows = num_rows;
     a.stride1 = src_stride;
     a.stride2 = dst_stride;
-    a.ws = reinterpret_cast<double*>(workspace);
     a.metric_w = metric_w;
     a.scale = scale;
     a.inv_scale_coef = 1.0 / scale_coef;
@@ -155,8 +144,7 @@ int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num
 int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n,
                                        const int64_t* const* triplets, int64_t stride, const int64_t* b, int num_batches,
                                        int model, int metric, const double* metric_w, double eps, const double* scale,
-                                       double scale_coef, double* const* out, int32_t* status, void* workspace,
-                                       int64_t workspace_bytes, int flags, void* stream) {
+                                       double scale_coef, double* const* out, int32_t* status, int flags, void* stream) {
     (void)flags;
     if (num_batches < 0) return fail(SYMPA_ERR_BAD_ARG, "bad batch list");
     if (num_batches == 0) return 0;
@@ -164,16 +152,12 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
     if (stride < 2) return fail(SYMPA_ERR_BAD_ARG, "triplet stride must be >= 2");
     const int rc = check_common(pack, pack_bytes, num_rows, n, model, metric, metric_w, eps, scale, scale_coef);
     if (rc != 0) return rc;
-    if (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 15)) return fail(SYMPA_ERR_BAD_ARG, "null / misaligned workspace");
-    const int64_t tile_bytes = (int64_t)(n * n + 1) * 64 * 8;
-    const int64_t ws_tiles = workspace_bytes / tile_bytes;
     PackedArgs a;
     std::memset(&a, 0, sizeof(a));
     a.pack = reinterpret_cast<const double*>(pack);
     a.num_rows = num_rows;
     a.stride1 = stride;
     a.stride2 = stride;
-    a.ws = reinterpret_cast<double*>(workspace);
     a.metric_w = metric_w;
     a.scale = scale;
     a.inv_scale_coef = 1.0 / scale_coef;
@@ -181,8 +165,7 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
     a.status = status;
     a.metric = metric;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // groups of consecutive batches whose tiles fit the workspace (at most SYMPA_MAX_FUSED_BATCHES per launch pair); launches of
-    // one stream run in order, so the next group's front kernel reuses the workspace after this group's eigen kernel
+    // groups of up to SYMPA_MAX_FUSED_BATCHES consecutive batches per launch
     const int64_t* idx1[SYMPA_MAX_FUSED_BATCHES];
     const int64_t* idx2[SYMPA_MAX_FUSED_BATCHES];
     int i0 = 0;
@@ -194,13 +177,13 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
             if (bi < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
             if (bi > 0 && (triplets[i0 + cnt] == nullptr || out[i0 + cnt] == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
             const int64_t t = (bi + 63) / 64;
-            if (tiles + t > ws_tiles || tiles + t > (int64_t)0x7fffffff) break;
+            if (tiles + t > (int64_t)0x7fffffff) break;
             tiles += t;
             idx1[cnt] = triplets[i0 + cnt];
             idx2[cnt] = triplets[i0 + cnt] + 1;
             ++cnt;
         }
-        if (cnt == 0) return fail(SYMPA_ERR_BAD_ARG, "workspace smaller than sympa_model_forward_packed_workspace_bytes of one batch");
+        if (cnt == 0) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
         const int rc2 = launch_group(a, n, model, idx1, idx2, b + i0, out + i0, cnt, s);
         if (rc2 != 0) return rc2;
         i0 += cnt;

@@ -5,16 +5,23 @@
 // (1) pack kernel, once per table version: every point is factored ONCE (Y = L L^T / I - W W^H = C C^H), the factor inverted, and
 //     the point's upper triangles + the inverted factor stored as ONE contiguous row of the packed table (PointPack of
 //     siegel_math.hpp: 108 doubles = 864 B at n = 8 upper where the reference row is 1 024 B).
-// (2) front kernel, one pair per lane, one 512-register wave per SIMD: the packed rows arrive through the LDS-DMA ring of
-//     siegel_gather.hpp (one coalesced instruction per row), E = A1 (Z2 - Z1) A2^T by two triangular products in place -- no
-//     Cholesky, no division, no square root --, H = E^H E, and H (n^2 doubles) + the pair's status word go to a caller-owned
-//     workspace laid out [tile of 64 pairs][entry][lane]: every store is 512 contiguous bytes.  The waves are PERSISTENT (grid =
-//     one wave per SIMD) and ask for the next tile's indices and first two passes before the current tile's arithmetic: the head of
-//     a tile (index load, first pass: latency a lone wave cannot hide) disappears behind the products of the previous one.
-// (3) eigen kernel, one pair per lane: H back from the workspace, Householder + lockstep QL, log1p, metric, scale.  Its live set is
-//     H (2 n^2 registers), not E + two factors (6 n^2): 256 registers, TWO waves per SIMD -- the 5 k instructions of the
-//     eigenvalue stage issue at the two-wave rate (~5.4 cycles per fp64 instruction instead of ~8.5 for a lone wave,
-//     profiles/r01_fp64_ubench.txt), which is what the one-kernel forward of dims 7, 8 could never reach.
+// (2) pair kernel, one pair per lane, one wave per block, PERSISTENT waves (grid = what the chip holds at once, each wave walks
+//     tiles of 64 pairs t, t + G, ...):
+//       * the packed rows arrive through the LDS-DMA ring of siegel_gather.hpp, one coalesced instruction per row, the row index
+//         through v_readlane (scalar base address);
+//       * the SECOND point of a pair is read first; the triangles of the first one are subtracted from it IN PLACE as its chunks
+//         come out of the LDS (D = Z2 - Z1), only its inverted factor is kept: a lane never holds two points' triangles
+//         (144 doubles at n = 8 where the dense kernel holds 256 + two factors) -- no scratch in any instantiation, where the dense
+//         bounded n = 8 kernel spills 652 bytes;
+//       * E = A1 D A2^T by two triangular products in place -- no Cholesky, no division, no square root --, then H = E^H E,
+//         eigenvalues, log, metric as in the dense kernel (siegel_math.hpp distance_from_h);
+//       * the ids of the next tile are loaded one tile ahead and its first two passes are issued BEFORE the current tile's
+//         arithmetic: the head of a tile (index load, first pass -- latency a lone wave cannot hide) disappears behind it.
+//     Measured (profiles/r05_packed_forward.txt, 262 144 pairs, 45 500 rows, same box): upper n = 8 135.4 -> 126.9 us, n = 7
+//     119.3 -> 103.6, n = 6 84.8 -> 67.7, n = 5 58.8 -> 53.4; bounded n = 8 245.2 -> 163.3, n = 7 152.5 -> 118.5.
+//     A TWO-kernel form (front: gather + E + H to a workspace; eigen stage from the workspace at 170 registers = two waves per
+//     SIMD) was built first and measured slower everywhere (upper n = 8: 169 us = 103 + 66): the 2 x 136 MB of H through the
+//     workspace cost what the second wave brings.  It is not in the library; the measurements are in the profile.
 #pragma once
 #include "siegel_common.hpp"
 
@@ -32,8 +39,6 @@ struct PackRow {
     static constexpr int BUF_SLOTS = ROWS * PITCH;
     static constexpr int NBUF = 2;
     static constexpr int WAVE_SLOTS = NBUF * BUF_SLOTS;
-    static constexpr int HLEN = N * N;                       // Herm<N>: d[N], then re / im of the strict upper part
-    static constexpr int WS_ENTRIES = HLEN + 1;              // + the pair's status word
     static_assert(K <= 128, "a packed row is at most two DMA instructions");
     static_assert(IPP <= 32, "vmcnt immediate");
 };
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(64) void table_pack_kernel(const double* __restrict
     }
 }
 
-// ---- (2) front ----------------------------------------------------------------------------------------------------------------
+// ---- (2) pairs ----------------------------------------------------------------------------------------------------------------
 struct PackedArgs {
     const double* pack;
     int64_t num_rows;
@@ -91,7 +96,6 @@ struct PackedArgs {
     int64_t b[SYMPA_MAX_FUSED_BATCHES];
     unsigned tile_end[SYMPA_MAX_FUSED_BATCHES];       // exclusive prefix end of batch k, in tiles of 64 pairs
     int64_t stride1, stride2;
-    double* ws;                                       // [tiles][WS_ENTRIES][64]
     const double* metric_w;
     const double* scale;
     double inv_scale_coef, inv_eps;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void packed_pass_issue(const double* __restrict__ bas
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < R::ROWS; ++j) {
-        const int rr = __shfl(row, 16 * pass + j);
+        const int rr = __builtin_amdgcn_readlane(row, 16 * pass + j);      // scalar row index, scalar base address
         const double* src = base + (int64_t)rr * R::ROW_DOUBLES + 2 * lane;
         if (R::K >= 64 || lane < R::K)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * R::PITCH), 16, 0, 0);
@@ -155,34 +159,63 @@ __device__ __forceinline__ void packed_pass_issue(const double* __restrict__ bas
     }
 }
 
-template <int N, int MODEL>
-__device__ __forceinline__ void packed_pass_read(const v2d* __restrict__ buf, const int pass, double (&p)[PackRow<N, MODEL>::ROW_DOUBLES]) {
+// The rows of a pass back into registers (the sixteen lanes of the pass only).  SECOND = false: the row of the pair's SECOND point
+// (dst) lands in p2 whole.  SECOND = true, the FIRST point (src): its triangles are subtracted from p2's in place (D = Z2 - Z1), only
+// its inverted factor is kept (p1a) -- a lane never holds two points' triangles, 144 doubles at n = 8 instead of 216.
+template <int N, int MODEL, bool SECOND>
+__device__ __forceinline__ void packed_pass_read(const v2d* __restrict__ buf, const int pass, double (&p2)[PackRow<N, MODEL>::ROW_DOUBLES],
+                                                 double (&p1a)[PackRow<N, MODEL>::ROW_DOUBLES - 2 * PackRow<N, MODEL>::P::TRI]) {
     using R = PackRow<N, MODEL>;
+    constexpr int ZLEN = 2 * R::P::TRI;
     const int lane = threadIdx.x & 63;
     if ((lane >> 4) == pass) {
         const v2d* mine = buf + (lane & 15) * R::PITCH;
+        if constexpr (!SECOND) {
 #pragma unroll
-        for (int c = 0; c < R::K; ++c) {
-            const v2d q = mine[c];
-            p[2 * c] = q.x;
-            p[2 * c + 1] = q.y;
+            for (int c = 0; c < R::K; ++c) {
+                const v2d q = mine[c];
+                p2[2 * c] = q.x;
+                p2[2 * c + 1] = q.y;
+            }
+        } else {
+            // groups of G chunks: G reads in flight, then their subtractions (one read, one dependent subtraction at a time would
+            // expose the LDS latency 54 times per pass -- this unit keeps the source order)
+            constexpr int G = 12;
+#pragma unroll
+            for (int c0 = 0; c0 < R::K; c0 += G) {
+                v2d q[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (c0 + g < R::K) q[g] = mine[c0 + g];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int c = c0 + g;
+                    if (c < R::K) {
+                        if (2 * c < ZLEN) p2[2 * c] -= q[g].x; else p1a[2 * c - ZLEN] = q[g].x;
+                        if (2 * c + 1 < ZLEN) p2[2 * c + 1] -= q[g].y; else p1a[2 * c + 1 - ZLEN] = q[g].y;
+                    }
+                }
+            }
         }
     }
 }
 
-// SYMPA_PACKED_PREFETCH: 1 (product) persistent waves with the next tile's head in flight behind the arithmetic; 0 keeps the
-// loop but issues a tile's first passes at its own top (A/B hook of tools/build_variant.sh)
-#ifndef SYMPA_PACKED_PREFETCH
-#define SYMPA_PACKED_PREFETCH 1
-#endif
+// p1a as the first operand of e_from_packed<DIFF>: only the factor part is ever read
+template <int N, int MODEL>
+struct FactorOnly {
+    const double* a;
+    __device__ __forceinline__ double operator[](int k) const { return a[k - 2 * sympa::PointPack<N, MODEL>::TRI]; }
+};
 
 template <int N, int MODEL>
-__global__ __launch_bounds__(64, 1) void packed_front_kernel(const PackedArgs a) {
+__global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs a) {
     using R = PackRow<N, MODEL>;
     using P = sympa::PointPack<N, MODEL>;
     __shared__ v2d tile[R::WAVE_SLOTS];
     v2d* buf0 = tile;
     v2d* buf1 = tile + R::BUF_SLOTS;
+    // staggered first round, as in siegel_dist_kernel.hpp (tables beyond the L2s: CU j of every XCD starts j x 0.5 us late, the
+    // waves stay out of step from there on; upper n = 8: 135.9 -> 126.9 us)
     if (a.stagger && blockIdx.x < 1024u) {
         const int k = (int)((blockIdx.x >> 5) & 31u);
         for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
@@ -193,8 +226,8 @@ __global__ __launch_bounds__(64, 1) void packed_front_kernel(const PackedArgs a)
     int64_t x1, x2;
     packed_ids_load(a, t, x1, x2);
     packed_ids_check(a, x1, x2, r1, r2, st);
-    packed_pass_issue<N, MODEL>(a.pack, r1, 0, buf0);
-    packed_pass_issue<N, MODEL>(a.pack, r1, 1, buf1);
+    packed_pass_issue<N, MODEL>(a.pack, r2, 0, buf0);        // passes 0..3: the pair's second point, 4..7: the first
+    packed_pass_issue<N, MODEL>(a.pack, r2, 1, buf1);
     // the ids of the NEXT tile are always one tile ahead of the passes that need them (loaded behind the previous prefetch)
     unsigned tn = t + gridDim.x;
     bool more = tn < a.tiles;                      // wave-uniform
@@ -204,9 +237,11 @@ __global__ __launch_bounds__(64, 1) void packed_front_kernel(const PackedArgs a)
     for (;;) {
         // the ring below counts on the DMA passes of THIS tile being the only outstanding vector-memory operations
         __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0): passes 0, 1 (issued long ago), the next ids, the previous tile's stores
-        double p1[R::ROW_DOUBLES], p2[R::ROW_DOUBLES];
+        double p2[R::ROW_DOUBLES], p1a[R::ROW_DOUBLES - 2 * P::TRI];
 #pragma unroll
-        for (int k = 0; k < R::ROW_DOUBLES; ++k) { p1[k] = 0.0; p2[k] = 0.0; }
+        for (int k = 0; k < R::ROW_DOUBLES; ++k) p2[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < R::ROW_DOUBLES - 2 * P::TRI; ++k) p1a[k] = 0.0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             // pass s has landed: s = 0 by the vmcnt(0) above; then at most the IPP instructions of pass s + 1 are outstanding
@@ -216,14 +251,14 @@ __global__ __launch_bounds__(64, 1) void packed_front_kernel(const PackedArgs a)
             }
             wave_lds_fence();
             const v2d* cur = (s & 1) ? buf1 : buf0;
-            if (s < 4) packed_pass_read<N, MODEL>(cur, s, p1);
-            else packed_pass_read<N, MODEL>(cur, s - 4, p2);
+            if (s < 4) packed_pass_read<N, MODEL, false>(cur, s, p2, p1a);
+            else packed_pass_read<N, MODEL, true>(cur, s - 4, p2, p1a);
             if (s + 2 < 8) {
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the reads of the buffer being refilled are complete
                 wave_lds_fence();
                 v2d* nxt = (s & 1) ? buf1 : buf0;
-                if (s + 2 < 4) packed_pass_issue<N, MODEL>(a.pack, r1, s + 2, nxt);
-                else packed_pass_issue<N, MODEL>(a.pack, r2, s + 2 - 4, nxt);
+                if (s + 2 < 4) packed_pass_issue<N, MODEL>(a.pack, r2, s + 2, nxt);
+                else packed_pass_issue<N, MODEL>(a.pack, r1, s + 2 - 4, nxt);
             }
         }
         // the head of the next tile goes out before this tile's arithmetic, the ids of the one after that behind it
@@ -231,88 +266,43 @@ __global__ __launch_bounds__(64, 1) void packed_front_kernel(const PackedArgs a)
         const bool more2 = more && tnn < a.tiles;
         int n1 = 0, n2 = 0, nst = 0;
         if (more) packed_ids_check(a, x1, x2, n1, n2, nst);     // (loaded a tile ago)
-        if (SYMPA_PACKED_PREFETCH && more) {
+        if (more) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             wave_lds_fence();
-            packed_pass_issue<N, MODEL>(a.pack, n1, 0, buf0);
-            packed_pass_issue<N, MODEL>(a.pack, n1, 1, buf1);
+            packed_pass_issue<N, MODEL>(a.pack, n2, 0, buf0);
+            packed_pass_issue<N, MODEL>(a.pack, n2, 1, buf1);
         }
         if (more2) packed_ids_load(a, tnn, x1, x2);
         // ---- arithmetic of tile t
-        const bool ok = sympa::d_finite(p1[P::OFF_DIAG]) && sympa::d_finite(p2[P::OFF_DIAG]);
+        const bool ok = sympa::d_finite(p1a[P::OFF_DIAG - 2 * P::TRI]) && sympa::d_finite(p2[P::OFF_DIAG]);
         sympa::Herm<N> h;
         {
             sympa::CMat<N> e;
-            sympa::e_from_packed<N, MODEL>(p1, p2, e);
+            const FactorOnly<N, MODEL> p1{p1a};
+            sympa::e_from_packed<N, MODEL, true>(p1, p2, e);
             sympa::gram<N>(e, h);
         }
-        const int flags = st | (ok ? 0 : sympa::ST_NOT_PD);
+        int flags = st | (ok ? 0 : sympa::ST_NOT_PD);
         if (st & sympa::ST_BAD_INDEX) h.d[0] = __builtin_nan("");
-        double* w = a.ws + ((int64_t)t * R::WS_ENTRIES) * 64 + (threadIdx.x & 63);
-#pragma unroll
-        for (int j = 0; j < N; ++j) __builtin_nontemporal_store(h.d[j], w + (int64_t)j * 64);
-        {
-            int e_ = N;
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-#pragma unroll
-                for (int k = j + 1; k < N; ++k) {
-                    __builtin_nontemporal_store(h.re[j][k], w + (int64_t)e_ * 64);
-                    __builtin_nontemporal_store(h.im[j][k], w + (int64_t)(e_ + 1) * 64);
-                    e_ += 2;
-                }
+        const int kb = packed_batch_of(a, t);
+        const unsigned t0 = (kb == 0) ? 0u : a.tile_end[kb - 1];
+        const int64_t i = (int64_t)(t - t0) * 64 + (threadIdx.x & 63);
+        const bool live = i < a.b[kb];
+        double d = sympa::distance_from_h<N, MODEL>(h, true, a.metric, a.metric_w, a.inv_eps, nullptr, flags);
+        if (flags & sympa::ST_BAD_INDEX) d = __builtin_nan("");
+        if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
+        if (live) __builtin_nontemporal_store(d, a.out[kb] + i);
+        if (a.status != nullptr) {
+            const int flagged = (live && flags != 0) ? 1 : 0;
+            const unsigned long long m = __ballot(flagged);
+            if (m != 0ull) {
+                if (flagged) atomicOr(&a.status[0], flags);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
+            }
         }
-        __builtin_nontemporal_store((double)flags, w + (int64_t)R::HLEN * 64);
         if (!more) break;
-        if (!SYMPA_PACKED_PREFETCH) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            wave_lds_fence();
-            packed_pass_issue<N, MODEL>(a.pack, n1, 0, buf0);
-            packed_pass_issue<N, MODEL>(a.pack, n1, 1, buf1);
-        }
         t = tn; r1 = n1; r2 = n2; st = nst;
         tn = tnn; more = more2;
-    }
-}
-
-// ---- (3) eigen ----------------------------------------------------------------------------------------------------------------
-#ifndef SYMPA_PACKED_EIGEN_WAVES
-#define SYMPA_PACKED_EIGEN_WAVES 2
-#endif
-template <int N, int MODEL>
-__global__ __launch_bounds__(64, SYMPA_PACKED_EIGEN_WAVES) void packed_eigen_kernel(const PackedArgs a) {
-    using R = PackRow<N, MODEL>;
-    const unsigned t = blockIdx.x;
-    const int k = packed_batch_of(a, t);
-    const unsigned t0 = (k == 0) ? 0u : a.tile_end[k - 1];
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)(t - t0) * 64 + lane;
-    const bool live = i < a.b[k];
-    const double* w = a.ws + ((int64_t)t * R::WS_ENTRIES) * 64 + lane;
-    sympa::Herm<N> h;
-#pragma unroll
-    for (int j = 0; j < N; ++j) h.d[j] = __builtin_nontemporal_load(w + (int64_t)j * 64);
-    int e_ = N;
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-#pragma unroll
-        for (int q = j + 1; q < N; ++q) {
-            h.re[j][q] = __builtin_nontemporal_load(w + (int64_t)e_ * 64);
-            h.im[j][q] = __builtin_nontemporal_load(w + (int64_t)(e_ + 1) * 64);
-            e_ += 2;
-        }
-    int st = (int)__builtin_nontemporal_load(w + (int64_t)R::HLEN * 64);
-    double d = sympa::distance_from_h<N, MODEL>(h, true, a.metric, a.metric_w, a.inv_eps, nullptr, st);
-    if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
-    if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
-    if (live) __builtin_nontemporal_store(d, a.out[k] + i);
-    if (a.status != nullptr) {
-        const int flagged = (live && st != 0) ? 1 : 0;
-        const unsigned long long m = __ballot(flagged);
-        if (m != 0ull) {
-            if (flagged) atomicOr(&a.status[0], st);
-            if (lane == 0) atomicAdd(&a.status[1], (int)__popcll(m));
-        }
     }
 }
 
@@ -324,13 +314,19 @@ int launch_table_pack(const double* table, int64_t num_rows, double* pack, int32
     return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 
+// persistent grid: as many one-wave blocks as the chip holds at once (registers / LDS of the instantiation)
+template <class K>
+unsigned resident_blocks(K kern, unsigned cus) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    return cus * (unsigned)per_cu;
+}
+
 template <int N, int MODEL>
-int launch_packed_forward(const PackedArgs& a, unsigned front_grid, hipStream_t s) {
-    hipLaunchKernelGGL((packed_front_kernel<N, MODEL>), dim3(front_grid), dim3(64), 0, s, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    hipLaunchKernelGGL((packed_eigen_kernel<N, MODEL>), dim3(a.tiles), dim3(64), 0, s, a);
-    e = hipGetLastError();
+int launch_packed_forward(const PackedArgs& a, unsigned cus, hipStream_t s) {
+    const unsigned res = resident_blocks(packed_forward_kernel<N, MODEL>, cus);
+    hipLaunchKernelGGL((packed_forward_kernel<N, MODEL>), dim3(a.tiles < res ? a.tiles : res), dim3(64), 0, s, a);
+    const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 

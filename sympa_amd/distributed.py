@@ -239,6 +239,7 @@ class GradientExchange:
         if self.world > 1:
             dist.all_gather_into_tensor(self.table_padded, self.shard_send, group=self.group)
             table.data.copy_(self.table_padded[:table.shape[0]])
+        ops.table_changed(table)                   # written through .data / raw pointers
         self.flat.zero_()
 
     def exchange_rows(self, idx_src, idx_dst):

@@ -28,6 +28,7 @@ class Embeddings(nn.Module, abc.ABC):
     def proj_embeds(self):            # embeddings.py:36-39
         with torch.no_grad():
             self.embeds.data = self.manifold.projx(self.embeds.data)
+            torch.autograd.graph.increment_version(self.embeds)     # cached packs of the table (ops.PackedTable) key on it
 
     def check_all_points(self):
         """embeddings.py:41-47 loops over the N rows in Python (a host sync per row, called once per epoch by

@@ -3,6 +3,8 @@
 `forward` is the drop-in boundary of the hot path: instead of two `index` gathers that materialise
 2 x [b,2,n,n] in HBM followed by ~100 ATen ops, one fused HIP kernel reads the two table rows of
 each pair straight from the table and writes the b scaled distances."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -10,6 +12,10 @@ from sympa_amd import autograd as sa
 from sympa_amd import ops
 from sympa_amd.embeddings import EmbeddingsFactory, ManifoldFactory
 from sympa_amd.manifolds.metrics import MetricType
+
+
+# forward() under no_grad takes the packed path (two launches) from this many pairs per call on
+PACKED_MIN_PAIRS = 4096
 
 
 class _SpdBatches:
@@ -83,8 +89,29 @@ class Model(nn.Module):
         if torch.is_grad_enabled() and (table.requires_grad or scale.requires_grad or
                                         (weights is not None and weights.requires_grad)):
             return sa.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
-        # no autograd graph to build (Runner.evaluate / build_distance_matrix run under no_grad): straight to the binding
+        # no autograd graph to build (Runner.evaluate / build_distance_matrix run under no_grad): straight to the binding --
+        # dims 5..8 over the packed table once the same table version is seen a second time (ops.PackedTable)
+        if 5 <= table.shape[-1] <= 8 and input_triplet.shape[0] >= PACKED_MIN_PAIRS:
+            pk = self.packed_table()
+            if pk is not None and pk.current(table):
+                return ops.model_forward_packed(pk, input_triplet, metric_name, weights, scale, self.scale_coef)
         return ops.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
+
+    def packed_table(self):
+        """The ops.PackedTable of this model's embedding table (dims 5..8 of the Siegel models on the GPU; None elsewhere, with
+        `model.use_packed = False` or SYMPA_NO_PACKED=1): upper triangles + inverted Cholesky factor per point, made once per
+        table version (the ManifoldParameter's torch version counter, which every sympa_amd optimiser step moves) and shared by
+        forward() under no_grad, forward_batches() and evaluate()."""
+        if not self.__dict__.get("use_packed", True) or os.environ.get("SYMPA_NO_PACKED"):
+            return None
+        table = self.embeddings.embeds
+        name = self.manifold.model_name
+        if not ops.PackedTable.supported(table, name):
+            return None
+        pk = self.__dict__.get("_packed")
+        if pk is None or pk.model != name:
+            pk = self.__dict__["_packed"] = ops.PackedTable(name)
+        return pk
 
     def _metric_key(self):
         """What a cached plan bakes in of the metric: its kind and the address of the wsum weights."""
@@ -114,8 +141,14 @@ class Model(nn.Module):
         if man.model_name == "spd":
             return _SpdBatches(self, batches, outs)
         weights = man.metric.weights if man.metric.kind is MetricType.WEIGHTED_SUM else None
-        plan = ops.BatchedForward(table, batches, outs, man.model_name, man.metric.kind.value, weights, self.scale.data,
-                                  self.scale_coef, flags=ops.FLAG_FUSE)
+        pk = self.packed_table()
+        if pk is not None and sum(int(t.shape[0]) for t in batches) >= PACKED_MIN_PAIRS:
+            # dims 5..8: the list goes over the packed table (repacked by the plan's run() whenever the table's version moved)
+            plan = ops.PackedBatchedForward(pk, self.embeddings.embeds, batches, outs, man.metric.kind.value, weights,
+                                            self.scale.data, self.scale_coef)
+        else:
+            plan = ops.BatchedForward(table, batches, outs, man.model_name, man.metric.kind.value, weights, self.scale.data,
+                                      self.scale_coef, flags=ops.FLAG_FUSE)
         plan.outs = outs
         return plan
 

@@ -316,6 +316,172 @@ class BatchedForward:
             check_status(self.dev)
 
 
+def table_changed(param):
+    """Tells torch (and with it every cached pack of the table, PackedTable below) that `param` was written IN PLACE by something
+    torch cannot see: the HIP optimiser kernels write through raw pointers of `param.data`, and a replayed hipGraph has no Python
+    in it at all.  sympa_amd's own optimisers, training steps and the sharded exchange call this after every step."""
+    torch.autograd.graph.increment_version(param)
+
+
+class PackedTable:
+    """The packed image of a Siegel table for the INDEXED forward, dims 5..8 (C-ABI sympa_table_pack): one contiguous row per point
+    -- the upper triangles of both planes and the inverted Cholesky factor -- made ONCE per table version and reused by every
+    batch until the table changes (Runner.evaluate's loop, runner.py:124-135; the N forward calls of the mAP matrix, runner.py:
+    142-154; Model.forward, model.py:16-30).  `ensure(table)` repacks when the table's storage, offset, shape or torch version
+    counter (`ManifoldParameter._version`: every in-place torch op and every sympa_amd optimiser step moves it, see
+    `table_changed`) differs from what was packed; it keeps a reference to the packed storage, so a freed table's address cannot
+    come back under the same key.  In-place writes through `.data` aliases that torch does not track need `invalidate()`."""
+
+    @staticmethod
+    def supported(table, model):
+        return (model in MODEL_IDS and table.is_cuda and table.dtype == torch.float64 and table.dim() == 4 and table.shape[1] == 2
+                and table.shape[2] == table.shape[3] and 5 <= table.shape[2] <= 8 and table.is_contiguous())
+
+    def __init__(self, model):
+        self.model = model
+        self.key = None
+        self.pack = None
+        self.repacks = 0
+        self._src = None
+
+    def invalidate(self):
+        self.key = None
+        self._seen = None
+
+    @staticmethod
+    def _key_of(table):
+        return (table.untyped_storage().data_ptr(), table.storage_offset(), table.shape[0], table.shape[2], table._version,
+                table.device)
+
+    def current(self, table):
+        """True when the pack is that of `table` as it is now.  Otherwise the table's state is remembered and the pack is made
+        the SECOND time the same state is seen: a caller that alternates optimiser steps with single forward calls never pays
+        for a pack it would use once, a caller that runs batch after batch over an unchanged table packs before its second
+        batch.  (`ensure` packs at once: the list forms -- forward_batches, evaluate -- know they have many batches.)"""
+        key = PackedTable._key_of(table)
+        if key == self.key:
+            return True
+        if getattr(self, "_seen", None) == key:
+            self.ensure(table)
+            return True
+        self._seen = key
+        return False
+
+    def ensure(self, table):
+        st = table.untyped_storage()
+        key = PackedTable._key_of(table)
+        if key == self.key:
+            return self
+        lib = _lib.load()
+        if not PackedTable.supported(table, self.model):
+            raise ValueError("PackedTable: a contiguous float64 [N,2,n,n] device table of a Siegel model, dims 5..8")
+        num_rows, n = table.shape[0], table.shape[2]
+        need = int(lib.sympa_table_pack_bytes(num_rows, n, MODEL_IDS[self.model]))
+        if self.pack is None or self.pack.numel() != need or self.pack.device != table.device:
+            self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
+        status = _status_buf(table.device)
+        with torch.cuda.device(table.device):
+            rc = lib.sympa_table_pack(table.data_ptr(), num_rows, n, MODEL_IDS[self.model], self.pack.data_ptr(), need,
+                                      status.data_ptr(), torch.cuda.current_stream(table.device).cuda_stream)
+        _lib.check(rc)
+        self.key, self._src = key, st
+        self.num_rows, self.n, self.bytes = num_rows, n, need
+        self.repacks += 1
+        return self
+
+
+def model_forward_packed(packed, triplets, metric="riem", weights=None, scale=None, scale_coef=1.0, eps=None, out=None):
+    """Model.forward over a PackedTable (`packed.ensure(table)` first): C-ABI sympa_model_forward_packed."""
+    lib = _lib.load()
+    _need_gpu(triplets, "triplets")
+    if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
+        raise TypeError("triplets must be an int64 [b, >=2] tensor (src, dst[, graph_distance])")
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    dev = packed.pack.device
+    b = triplets.shape[0]
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    if out is None:
+        out = torch.empty(b, dtype=torch.float64, device=dev)
+    if b == 0:
+        return out
+    n, mid = packed.n, MODEL_IDS[packed.model]
+    w = _weights(metric, weights, n, dev) if metric == "wsum" else None
+    sc_ptr = None
+    if scale is not None:
+        sc = scale if (scale.device == dev and scale.dtype == torch.float64) else scale.detach().to(device=dev, dtype=torch.float64)
+        sc_ptr = sc.data_ptr()
+    tp = triplets.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.sympa_model_forward_packed(packed.pack.data_ptr(), packed.bytes, packed.num_rows, n, tp, stride, tp + 8, stride, b,
+                                            mid, METRIC_IDS[metric], None if w is None else w.data_ptr(),
+                                            1e-5 if eps is None else float(eps), sc_ptr, float(scale_coef), out.data_ptr(),
+                                            _status_buf(dev).data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _lib.check(rc)
+    if _debug:
+        check_status(dev)
+    return out
+
+
+class PackedBatchedForward:
+    """BatchedForward over a PackedTable (C-ABI sympa_model_forward_batches_packed): `run()` first makes sure the pack is that of the
+    table's current version (one tuple comparison), then ONE C call; up to 32 consecutive batches share a launch."""
+
+    def __init__(self, packed, table, batches, outs, metric="riem", weights=None, scale=None, scale_coef=1.0, eps=None):
+        self.lib = _lib.load()
+        self.packed, self.table = packed, table
+        if len(batches) != len(outs):
+            raise ValueError("one output per batch")
+        stride = None
+        for t, o in zip(batches, outs):
+            _need_gpu(t, "triplets"); _need_gpu(o, "out")
+            if t.dtype != torch.int64 or t.dim() != 2 or t.shape[1] < 2 or not t.is_contiguous():
+                raise TypeError("every batch must be a contiguous int64 [b, >=2] tensor")
+            if stride is not None and t.shape[1] != stride:
+                raise ValueError("all batches must have the same number of columns")
+            stride = t.shape[1]
+            if o.dtype != torch.float64 or not o.is_contiguous() or o.numel() < t.shape[0]:
+                raise TypeError("every output must be a contiguous float64 tensor of at least b elements")
+        self.keep = (list(batches), list(outs), weights, scale)
+        self.dev = table.device
+        self.n = table.shape[2]
+        self.k = len(batches)
+        self.stride = stride or 2
+        C = ctypes
+        self.trip = (C.c_void_p * max(self.k, 1))(*[t.data_ptr() for t in batches])
+        self.b = (C.c_int64 * max(self.k, 1))(*[t.shape[0] for t in batches])
+        self.out = (C.c_void_p * max(self.k, 1))(*[o.data_ptr() for o in outs])
+        self.w = _weights(metric, weights, self.n, self.dev) if metric == "wsum" else None
+        self.sc = None
+        if scale is not None:
+            self.sc = scale if (scale.device == self.dev and scale.dtype == torch.float64) else scale.detach().to(self.dev, torch.float64)
+        self.metric = METRIC_IDS[metric]
+        self.eps = 1e-5 if eps is None else float(eps)
+        self.scale_coef = float(scale_coef)
+        self.status = _status_buf(self.dev)
+
+    def set_streams(self, streams):
+        if streams:
+            raise ValueError("the packed forward runs its launch pairs on ONE stream (the current one)")
+
+    def run(self):
+        if self.k == 0:
+            return
+        pk = self.packed.ensure(self.table)
+        C = ctypes
+        with torch.cuda.device(self.dev):
+            rc = self.lib.sympa_model_forward_batches_packed(
+                pk.pack.data_ptr(), pk.bytes, pk.num_rows, self.n, C.addressof(self.trip), self.stride, C.addressof(self.b), self.k,
+                MODEL_IDS[pk.model], self.metric, None if self.w is None else self.w.data_ptr(), self.eps,
+                None if self.sc is None else self.sc.data_ptr(), self.scale_coef, C.addressof(self.out), self.status.data_ptr(),
+                0, torch.cuda.current_stream(self.dev).cuda_stream)
+        if rc != 0:
+            _lib.check(rc)
+        if _debug:
+            check_status(self.dev)
+
+
 def _siegel_bwd_workspace(lib, b, n, model, dev, flags, workspace):
     """The caller-owned scratch of the split Siegel backward (C-ABI sympa_siegel_backward_workspace_bytes; 0 bytes where no kernel
     uses one: dims outside 5..8): `workspace` when given (a persistent uint8 tensor: what a replayed graph wants), else a fresh

@@ -55,6 +55,8 @@ class RiemannianSGD(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 manifold = getattr(p, "manifold", None)
+                if manifold is not None:
+                    ops.table_changed(p)       # the kernels below write through p.data: torch's version counter does not see them
                 if isinstance(manifold, SymmetricPositiveDefinite) and p.is_cuda:
                     if p.dtype != torch.float64:
                         raise TypeError("the spd table must be float64 (config.py:17-18)")
@@ -172,6 +174,8 @@ class RiemannianAdam(torch.optim.Optimizer):
                     continue
                 manifold = getattr(p, "manifold", None)
                 siegel = isinstance(manifold, SiegelManifold) and p.is_cuda
+                if manifold is not None:
+                    ops.table_changed(p)       # (see RiemannianSGD.step)
                 if isinstance(manifold, SymmetricPositiveDefinite):
                     raise NotImplementedError("RiemannianAdam on the spd model needs geoopt's parallel transport: use rsgd")
                 state = self._init_param_state(p, (b1, b2), group["step"] - 1)

@@ -271,6 +271,7 @@ class GraphedTrainStep:
         if b == 0:
             return loss                 # nothing to step on (and the deterministic clip would read the last step's partials)
         self._fused_step()
+        ops.table_changed(table)
         # the fused optimiser kernel advances the device step counter that addresses the batches of a loaded epoch; an
         # eager step is not one of them, so the window stays where run_steps left it (stream-ordered, no sync)
         self.counter.sub_(1)
@@ -380,6 +381,7 @@ class GraphedTrainStep:
                 self.rowptr[0].copy_(rowptr[0])
         self._ready()
         self.graph.replay()
+        ops.table_changed(self.model.embeddings.embeds)        # a replayed graph has no Python in it: tell torch the table moved
         return self.loss
 
     def load_epoch(self, triplets):
@@ -418,6 +420,8 @@ class GraphedTrainStep:
             raise ValueError("more steps than full batches left in the loaded epoch")
         for _ in range(k):
             self.graph.replay()
+        if k > 0:
+            ops.table_changed(self.model.embeddings.embeds)
         self.steps_loaded -= k
         return self.loss
 
@@ -695,6 +699,8 @@ class DistributedTrainStep:
                     self.replays += 1
                 else:
                     item()
+        if k > 0:
+            ops.table_changed(self.model.embeddings.embeds)
         self.steps_loaded -= k
         return self.loss
 

@@ -88,8 +88,10 @@ def hostsim_dist(z1, z2, model, metric, weights=None, eps=1e-5, generic=False):
     return out, vvd, st.value
 
 
-def hostsim_dist_packed(z1, z2, model, metric, weights=None, eps=1e-5):
-    """The all-pairs kernel's per-pair arithmetic: packed points (inverted factors), E = A1 (Z2 - Z1) A2^T."""
+def hostsim_dist_packed(z1, z2, model, metric, weights=None, eps=1e-5, diff=False):
+    """The all-pairs kernel's per-pair arithmetic: packed points (inverted factors), E = A1 (Z2 - Z1) A2^T.  diff=True: the indexed
+    packed forward's form (csrc/siegel_packed_kernel.hpp): the first point's triangles subtracted from the second's packed row in
+    place, e_from_packed<DIFF>, distance_from_h."""
     lib = hostsim()
     P = ctypes.c_void_p
     z1 = np.ascontiguousarray(z1, dtype=np.float64)
@@ -99,8 +101,8 @@ def hostsim_dist_packed(z1, z2, model, metric, weights=None, eps=1e-5):
     st = ctypes.c_int32(0)
     w = np.ascontiguousarray(np.ones(n) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1))
     rc = lib.sympa_hostsim_dist_packed(P(z1.ctypes.data), P(z2.ctypes.data), ctypes.c_int64(b), n, MODELS.index(model),
-                                       METRICS.index(metric), P(w.ctypes.data), ctypes.c_double(eps), P(out.ctypes.data),
-                                       ctypes.byref(st))
+                                       METRICS.index(metric) + (16 if diff else 0), P(w.ctypes.data), ctypes.c_double(eps),
+                                       P(out.ctypes.data), ctypes.byref(st))
     assert rc == 0, rc
     return out, st.value
 

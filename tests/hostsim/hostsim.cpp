@@ -62,9 +62,43 @@ void run_packed(const double* z1, const double* z2, int64_t b, int metric, const
     }
     if (status) *status = st;
 }
+// the INDEXED packed forward's per-pair path (csrc/siegel_packed_kernel.hpp): the second point's packed row whole, the first
+// point's triangles subtracted from it in place, only the first point's factor kept; e_from_packed<DIFF> + distance_from_h
+template <int N, int MODEL>
+void run_packed_diff(const double* z1, const double* z2, int64_t b, int metric, const double* w, double eps, double* out,
+                     int32_t* status) {
+    using P = sympa::PointPack<N, MODEL>;
+    struct FactorOnly {
+        const double* a;
+        double operator[](int k) const { return a[k - 2 * P::TRI]; }
+    };
+    for (int64_t i = 0; i < b; ++i) {
+        sympa::CMat<N> a, c, e;
+        sympa::load_point<N>(z1 + i * 2 * N * N, a);
+        sympa::load_point<N>(z2 + i * 2 * N * N, c);
+        double p1[P::LEN], p2[P::LEN];
+        const bool ok1 = sympa::pack_point<N, MODEL>(a, p1);
+        const bool ok2 = sympa::pack_point<N, MODEL>(c, p2);
+        for (int k = 0; k < 2 * P::TRI; ++k) p2[k] -= p1[k];
+        const FactorOnly f{p1 + 2 * P::TRI};
+        sympa::e_from_packed<N, MODEL, true>(f, p2, e);
+        sympa::Herm<N> h;
+        sympa::gram<N>(e, h);
+        int st = 0;
+        out[i] = sympa::distance_from_h<N, MODEL>(h, ok1 && ok2, metric, w, 1.0 / eps, nullptr, st);
+        if (status) status[0] |= st;
+    }
+}
+
 template <int N>
 void run_packed_n(const double* z1, const double* z2, int64_t b, int model, int metric, const double* w, double eps,
                   double* out, int32_t* status) {
+    // metric ids >= 16: the same through the in-place difference form of the indexed packed forward
+    if (metric >= 16) {
+        if (model == sympa::MODEL_UPPER) run_packed_diff<N, sympa::MODEL_UPPER>(z1, z2, b, metric - 16, w, eps, out, status);
+        else run_packed_diff<N, sympa::MODEL_BOUNDED>(z1, z2, b, metric - 16, w, eps, out, status);
+        return;
+    }
     if (model == sympa::MODEL_UPPER) run_packed<N, sympa::MODEL_UPPER>(z1, z2, b, metric, w, eps, out, status);
     else run_packed<N, sympa::MODEL_BOUNDED>(z1, z2, b, metric, w, eps, out, status);
 }

@@ -131,12 +131,16 @@ def test_packed_point_path_of_the_all_pairs_kernel(model, n):
             assert st == 0 and np.all(got[:5] == 0.0)
             assert rel_err(got, ref) < 1e-10, (model, n, s, metric)
             assert rel_err(got, so.manifold_dist(model, z1, z2, metric, w)) < TOL
-    if n in (2, 3, 4, 8):
+            # the indexed packed forward's in-place difference form (dims 5..8 on the GPU; every n here)
+            got_d, st_d = hostsim_dist_packed(z1.numpy(), z2.numpy(), model, metric, w.numpy(), diff=True)
+            assert st_d == 0 and np.all(got_d[:5] == 0.0) and rel_err(got_d, got) < 1e-12, (model, n, s, metric)
+    if n in (2, 3, 4, 5, 6, 7, 8):
         gold = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
         for case in gold["case_names"]:
-            got, st = hostsim_dist_packed(gold[f"{case}__z1"], gold[f"{case}__z2"], model, "riem")
             tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
-            assert st == 0 and rel_err(got, gold[f"{case}__riem"]) < tol, (model, n, case)
+            for diff in (False, True):
+                got, st = hostsim_dist_packed(gold[f"{case}__z1"], gold[f"{case}__z2"], model, "riem", diff=diff)
+                assert st == 0 and rel_err(got, gold[f"{case}__riem"]) < tol, (model, n, case, diff)
 
 
 @pytest.mark.parametrize("n", [12, 16])

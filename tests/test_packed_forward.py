@@ -1,0 +1,219 @@
+"""GPU (`-m gpu`): the INDEXED forward over the packed table, dims 5..8 (C-ABI sympa_table_pack / sympa_model_forward_packed /
+sympa_model_forward_batches_packed; csrc/siegel_packed_kernel.hpp) -- what Model.forward / forward_batches / evaluate run while the
+table does not change between batches (sympa/model.py:16-30, sympa/embeddings.py:29-34, sympa/runner.py:124-135,142-154).
+
+Parity: the golden vectors of the imported reference n = 5..8 through the packed path (1e-9; the arithmetic differs from the dense
+kernel's: products with the inverted factor instead of triangular solves), packed == dense to 1e-12 on the bench tables, the
+oracle on seeded inputs, properties at configs[3]'s full size, the error contract (bad index, point outside the manifold), and the
+pack's life cycle (torch version counter, storage, optimiser steps)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import siegel_oracle as so
+from tests.helpers import GOLDEN, METRICS, MODELS, T, points, rel_err, sym, upper_points
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+TOL_FAR_VS_REFERENCE = 1e-6   # see tests/test_hostsim_parity.py
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from sympa_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def packed_dist(z1, z2, model, metric, w=None, dev="cuda:0"):
+    """dist(z1[i], z2[i]) through the packed INDEXED path: the two point lists become one table, pair i = (i, b + i)."""
+    from sympa_amd import ops
+    z1, z2 = T(z1), T(z2)
+    b = z1.shape[0]
+    table = torch.cat((z1, z2)).to(dev).contiguous()
+    trip = torch.stack((torch.arange(b), torch.arange(b) + b), 1).to(dev)
+    pk = ops.PackedTable(model).ensure(table)
+    out = ops.model_forward_packed(pk, trip, metric, None if w is None else T(w).to(dev))
+    ops.check_status(torch.device(dev))
+    return out.cpu()
+
+
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_packed_forward_golden_vectors_of_the_reference(dev, model, n):
+    g = np.load(f"{GOLDEN}/dist_{model}_n{n}.npz")
+    for case in g["case_names"]:
+        z1, z2 = g[f"{case}__z1"], g[f"{case}__z2"]
+        for metric in METRICS:
+            got = packed_dist(z1, z2, model, metric, g["wsum_weights"])
+            tol = TOL_FAR_VS_REFERENCE if case in ("far", "s1.0") else TOL
+            assert rel_err(got, g[f"{case}__{metric}"], atol=1e-12) < tol, (model, n, case, metric)
+
+
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_packed_forward_against_oracle_and_dense_kernel(dev, model, n):
+    """Seeded inputs at three scales, ragged batch (not a multiple of 64), every metric: the oracle to 1e-9, the dense kernel to
+    1e-12."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(2000 + n)
+    N, b = 301, 777
+    for s in (1e-3, 0.3, 0.8):
+        table = points(model, N, n, s, g)
+        trip = torch.stack((torch.randint(0, N, (b,), generator=g), torch.randint(0, N, (b,), generator=g)), 1)
+        tab_d, trip_d = table.to(dev), trip.to(dev)
+        pk = ops.PackedTable(model).ensure(tab_d)
+        for metric in METRICS:
+            w = torch.linspace(-0.3, 1.2, n)
+            got = ops.model_forward_packed(pk, trip_d, metric, w.to(dev)).cpu()
+            dense = ops.model_forward(tab_d, trip_d, model, metric, w.to(dev)).cpu()
+            want = so.model_forward(table, trip, model, metric, w)
+            assert rel_err(got, want) < TOL, (model, n, s, metric)
+            assert rel_err(got, dense, atol=1e-13) < 1e-12, (model, n, s, metric)
+    ops.check_status(dev)
+
+
+@pytest.mark.parametrize("model,n,N,b", [("upper", 8, 45500, 262144), ("bounded", 8, 5041, 65536), ("upper", 6, 5041, 65536)])
+def test_packed_forward_full_size_equals_dense_and_properties(dev, model, n, N, b):
+    """configs[3]'s full size (upper n = 8, 262 144 pairs of 45 500 rows) and two more shapes on the BENCH tables: packed == dense
+    to 1e-12, symmetry d(x, y) = d(y, x), d(x, x) = 0 exactly, a 256-pair oracle sample."""
+    from sympa_amd import data, ops
+    table = data.trained_like_table(N, n, model=model, seed=42).to(dev)
+    trip = data.sample_pairs(N, b, 0, 42).to(dev)
+    pk = ops.PackedTable(model).ensure(table)
+    d_p = ops.model_forward_packed(pk, trip, "riem")
+    d_d = ops.model_forward(table, trip, model, "riem")
+    ops.check_status(dev)
+    assert torch.isfinite(d_p).all() and (d_p > 0).all()
+    assert rel_err(d_p.cpu(), d_d.cpu(), atol=1e-13) < 1e-12
+    flipped = trip[:, [1, 0, 2]].contiguous() if trip.shape[1] > 2 else trip.flip(1).contiguous()
+    assert rel_err(ops.model_forward_packed(pk, flipped, "riem").cpu(), d_p.cpu()) < 1e-10
+    same = torch.stack((trip[:, 0], trip[:, 0]), 1).contiguous()
+    assert torch.all(ops.model_forward_packed(pk, same, "riem") == 0)
+    k = 256
+    want = so.model_forward(table.cpu(), trip[:k].cpu(), model, "riem")
+    assert rel_err(d_p[:k].cpu(), want) < 1e-8
+
+
+def test_packed_forward_error_contract_and_edge_cases(dev):
+    """Empty batch, one pair, strided triplets, index out of range (NaN + IndexError like the dense path), a point outside the
+    manifold (reported at pack time AND by every pair it enters: AssertionError like siegel_manifold.py:64-66), non-finite input."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(9)
+    table = upper_points(70, 6, 0.3, g).to(dev)
+    pk = ops.PackedTable("upper").ensure(table)
+    assert ops.model_forward_packed(pk, torch.zeros(0, 2, dtype=torch.int64, device=dev)).shape == (0,)
+    one = ops.model_forward_packed(pk, torch.tensor([[1, 2]], device=dev))
+    assert one.shape == (1,) and torch.isfinite(one).all()
+    trip3 = torch.randint(0, 70, (200, 3), generator=g).to(dev)                # [b, 3] triplets: stride 3
+    assert torch.equal(ops.model_forward_packed(pk, trip3), ops.model_forward_packed(pk, trip3[:, :2].contiguous()))
+    ops.check_status(dev)
+    bad = ops.model_forward_packed(pk, torch.tensor([[1, 2], [3, 70], [-1, 0]], device=dev))
+    assert torch.isfinite(bad[0]) and torch.isnan(bad[1]) and torch.isnan(bad[2])
+    with pytest.raises(IndexError):
+        ops.check_status(dev)
+    off = table.clone()
+    off[4, 1] = -off[4, 1]
+    pk_off = ops.PackedTable("upper").ensure(off)
+    with pytest.raises(AssertionError):                                        # the pack kernel reports the point
+        ops.check_status(dev)
+    out = ops.model_forward_packed(pk_off, torch.tensor([[4, 5], [1, 2], [7, 4]], device=dev))
+    assert torch.isnan(out[0]) and torch.isfinite(out[1]) and torch.isnan(out[2])
+    with pytest.raises(AssertionError):                                        # ... and so does every pair it enters
+        ops.check_status(dev)
+    nanny = table.clone()
+    nanny[9, 0, 2, 3] = float("nan")
+    out = ops.model_forward_packed(ops.PackedTable("upper").ensure(nanny), torch.tensor([[9, 1], [1, 2]], device=dev))
+    assert torch.isnan(out[0]) and torch.isfinite(out[1])
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+    with pytest.raises(ValueError):                                            # dims outside 5..8: no packed path
+        ops.PackedTable("upper").ensure(upper_points(10, 4, 0.3, g).to(dev))
+
+
+@pytest.mark.parametrize("model,n", [("upper", 8), ("bounded", 7), ("upper", 5)])
+def test_packed_batches_equal_single_calls_bit_for_bit(dev, model, n):
+    """sympa_model_forward_batches_packed: 40 ragged batches (more than one launch group of 32, an empty batch among them) ==
+    one sympa_model_forward_packed call per batch, bit for bit (the per-pair arithmetic does not depend on the batch)."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(31)
+    N = 400
+    table = points(model, N, n, 0.4, g).to(dev)
+    sizes = [int(x) for x in torch.randint(1, 900, (40,), generator=g)]
+    sizes[7] = 0
+    batches = [torch.randint(0, N, (b, 3), generator=g).to(dev) for b in sizes]
+    outs = [torch.full((b,), -1.0, dtype=torch.float64, device=dev) for b in sizes]
+    pk = ops.PackedTable(model)
+    plan = ops.PackedBatchedForward(pk, table, batches, outs, "fone")
+    plan.run()
+    ops.check_status(dev)
+    for t, o in zip(batches, outs):
+        if t.shape[0]:
+            assert torch.equal(o, ops.model_forward_packed(pk, t, "fone"))
+
+
+def test_model_uses_the_pack_and_follows_the_table(dev):
+    """Model.forward under no_grad takes the packed path from the SECOND call on an unchanged table; forward_batches / evaluate
+    pack at once; an optimiser step (raw-pointer kernels: sympa_amd bumps the torch version counter), an in-place torch op, a
+    replaced storage (`embeds.data = ...`) and load_state_dict all make the next call repack; `use_packed = False` and autograd
+    calls stay on the dense kernel."""
+    from sympa_amd import data, ops
+    from sympa_amd.model import Model
+    from sympa_amd.optim import RiemannianSGD
+
+    class A:
+        manifold, metric, dims, num_points = "upper", "riem", 6, 500
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.trained_like_table(500, 6, model="upper", seed=3)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(1)
+    trip = torch.randint(0, 500, (8192, 3), generator=g).to(dev)
+
+    def dense():
+        return ops.model_forward(m.embeddings.embeds.data, trip, "upper", "riem", None, m.scale.data, m.scale_coef)
+
+    pk = m.packed_table()
+    assert pk is not None and pk.repacks == 0
+    with torch.no_grad():
+        a = m(trip)
+        assert pk.repacks == 0                       # first sight of this table version: dense kernel
+        b = m(trip)
+        assert pk.repacks == 1                       # second: packed
+        assert rel_err(b.cpu(), a.cpu(), atol=1e-13) < 1e-12
+        m(trip)
+        assert pk.repacks == 1
+    # an optimiser step writes the table through raw pointers
+    opt = RiemannianSGD(m.parameters(), lr=0.05, weight_decay=0.0, stabilize=None)
+    m.embeddings.embeds.grad = torch.randn(m.embeddings.embeds.shape, generator=g, dtype=torch.float64).to(dev) * 0.1
+    opt.step()
+    with torch.no_grad():
+        outs = m.forward_batches([trip])             # the list form packs at once
+        assert pk.repacks == 2
+        assert rel_err(outs[0].cpu(), dense().cpu(), atol=1e-13) < 1e-12
+        assert not torch.allclose(outs[0], a)
+        # an in-place torch op on the parameter
+        m.embeddings.embeds.mul_(1.0)
+        m.embeddings.embeds[:, 0].add_(0.01 * sym(torch.randn(500, 6, 6, generator=g, dtype=torch.float64)).to(dev))
+        dd = m.evaluate(trip[:, :2].contiguous(), torch.ones(8192, dtype=torch.float64, device=dev), 2048)
+        assert pk.repacks == 3
+        # a new storage behind the same Parameter
+        m.embeddings.embeds.data = data.trained_like_table(500, 6, model="upper", seed=4).to(dev)
+        c = m.forward_batches([trip])[0].clone()
+        assert pk.repacks == 4
+        assert rel_err(c.cpu(), dense().cpu(), atol=1e-13) < 1e-12
+        # load_state_dict copies in place
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["embeddings.embeds"] = data.trained_like_table(500, 6, model="upper", seed=5).to(dev)
+        m.load_state_dict(sd)
+        e = m.forward_batches([trip])[0]
+        assert pk.repacks == 5
+        assert rel_err(e.cpu(), dense().cpu(), atol=1e-13) < 1e-12
+        assert dd > 0
+        m.use_packed = False
+        assert m.packed_table() is None
+        assert torch.equal(m(trip), dense())
+    ops.check_status(dev)
