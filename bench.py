@@ -169,7 +169,9 @@ def live_counters(argv_base, kernel_substring, timeout_s=60):
     """PMC counters of the timed kernel, measured NOW: child runs of this file under `rocprofv3 --pmc <group>` -- FETCH_SIZE,
     WRITE_SIZE, then {SQ_INSTS_VALU, SQ_WAVES}: one counter group per pass, counters only, the program directly after
     `--`, as MI355X_MICROARCH.md prescribes -- every sample normalised by the work-items of its dispatch.  Returns
-    {counter: value per work-item} for the passes that worked (children, never an exec; {} when rocprofv3 is absent)."""
+    {counter: value per work-item, counter + "/dispatch": value per dispatch} for the passes that worked (children, never an
+    exec; {} when rocprofv3 is absent).  The per-dispatch figures are what a PERSISTENT kernel needs (the packed forward of dims
+    5..8: its grid is the resident waves, not the pairs; the child's launches have the parent's size)."""
     import csv
     import glob
     import shutil
@@ -192,6 +194,7 @@ def live_counters(argv_base, kernel_substring, timeout_s=60):
                 continue
             total = {c: 0.0 for c in group}
             items = {c: 0.0 for c in group}
+            calls = {c: 0 for c in group}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
@@ -199,9 +202,11 @@ def live_counters(argv_base, kernel_substring, timeout_s=60):
                         if c in total and kernel_substring in row.get("Kernel_Name", ""):
                             total[c] += float(row["Counter_Value"])
                             items[c] += float(row["Grid_Size"])
+                            calls[c] += 1
             for c in group:
                 if items[c] > 0:
                     per_item[c] = total[c] / items[c]
+                    per_item[c + "/dispatch"] = total[c] / calls[c]
         except (subprocess.TimeoutExpired, OSError, ValueError, KeyError):
             continue
         finally:
@@ -692,12 +697,28 @@ def main():
             t_live = time.perf_counter()
             counters = live_counters(child, timed_kernel.split(" (")[0])
             t_live = time.perf_counter() - t_live
+            persistent = timed_kernel.startswith("packed_forward_kernel")
             if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-                live = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0 * timed_pairs_per_launch
+                if persistent:      # (the child's launches are the parent's as long as both run whole 32-step groups)
+                    live = (2.0 * counters["FETCH_SIZE/dispatch"] + counters["WRITE_SIZE/dispatch"]) * 1024.0
+                    if min(args.steps, 128) % spl or args.steps % spl:
+                        live = None
+                else:
+                    live = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0 * timed_pairs_per_launch
         # work-items per pair of the timed kernel's grid: the spd kernel's grid is one work-item per pair (a wave serves its
         # 64 pairs four at a time, sixteen lanes each, over sixteen rounds); the Siegel dims 9..16 kernels launch sixteen
         lanes_per_pair = 16 if (model != "spd" and n > 8) else 1
-        if counters.get("SQ_WAVES"):
+        if counters.get("SQ_WAVES") and timed_kernel.startswith("packed_forward_kernel"):
+            # persistent waves, each walking many tiles of 64 pairs: wave-instructions per PAIR from the per-dispatch totals,
+            # expressed as "per wave of 64 pairs" like the other kernels
+            valu_per_wave = counters["SQ_INSTS_VALU/dispatch"] / timed_pairs_per_launch * 64.0
+            waves_per_pair = 1.0 / 64.0
+            valu_source = (f"measured in this run: a child run of the same command line under `rocprofv3 --pmc SQ_INSTS_VALU "
+                           f"SQ_WAVES` (counters only), samples of {timed_kernel} per dispatch / pairs per launch x 64 (persistent "
+                           "waves: VALU instructions per 64 pairs)")
+            if min(args.steps, 128) % spl or args.steps % spl:
+                valu_per_wave, valu_source = None, None
+        elif counters.get("SQ_WAVES"):
             valu_per_wave = counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"]
             waves_per_pair = counters["SQ_WAVES"] * lanes_per_pair        # counters are per work-item
             valu_source = (f"measured in this run: a child run of the same command line under `rocprofv3 --pmc SQ_INSTS_VALU "

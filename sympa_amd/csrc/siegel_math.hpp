@@ -717,6 +717,8 @@ SYMPA_HD bool tridiag_ql_lockstep(double (&d)[N], double (&e2)[N]) {
 }
 
 // Eigenvalues of H into h.d[]: Jacobi for n <= 4, tridiagonal QL for n >= 5.
+// (n = 4 through Householder + lockstep QL instead of Jacobi was measured in round 5, profiles/r05_n4_eigen_ab.txt: 9.10 -> 10.19 us
+// per 65 536 pairs, the fused 20-step launch 88.0 -> 96.8 us, and the `far` golden fails at 1e-6: Jacobi stays.)
 template <int N>
 SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
     if constexpr (N <= 4) {
