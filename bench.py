@@ -75,7 +75,7 @@ def kernel_name(model, n, low_lds):
     if n > 8:
         return f"siegel_coop_kernel (n={n})"
     low = bool(low_lds) and n in (2, 4)          # DmaTile<N>::ENABLED (csrc/siegel_gather.hpp)
-    return f"siegel_dist_kernel<{n}, {MODEL_ID[model]}, {'true' if low else 'false'}, false>"
+    return f"siegel_dist_kernel<{n}, {MODEL_ID[model]}, {'true' if low else 'false'}>"
 
 
 def cpu_model_name():

@@ -119,12 +119,10 @@ __device__ __attribute__((noinline)) void scatter_add_rows_outlined(const sympa:
     scatter_add_rows<N>(g, row, grad, tile, live);
 }
 
-// A/B hook: -DSYMPA_BWD_ROWS_MIN_BLOCKS=2 asks for two blocks per CU (two 256-register waves per SIMD) in the rows-out form at n <= 4
-#ifndef SYMPA_BWD_ROWS_MIN_BLOCKS
-#define SYMPA_BWD_ROWS_MIN_BLOCKS 1
-#endif
+// (two 256-register waves per SIMD in the rows-out form at n <= 4: measured slower, 32.2 -> 34.7 us upper, 36.5 -> 51.0 us bounded --
+// 60 spilled registers cost more than the second wave brings, profiles/r03_rejected_variants.txt)
 template <int N, bool SCATTER>
-constexpr int bwd_min_blocks() { return (N <= 4 && !SCATTER) ? SYMPA_BWD_ROWS_MIN_BLOCKS : 1; }
+constexpr int bwd_min_blocks() { return 1; }
 
 template <int N, int MODEL, bool SCATTER>
 __global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, SCATTER>())) void siegel_bwd_kernel(const BwdArgs a) {

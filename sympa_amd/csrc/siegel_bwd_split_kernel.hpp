@@ -132,12 +132,8 @@ __device__ __forceinline__ void flush_plane_rows(const double sign, double* __re
 // 256 fp64 atomic instructions at once (the gradient kernel) or their 100 workspace stores (the spectral kernel).  The atomic
 // units take ~250 us for the 67 M adds of 262 144 pairs and idle while everybody computes: kernel time = compute + atomics.
 // Spread over one compute period the two overlap.  Block x of the first 1 024 sleeps (x * 5 mod STEPS) x ~2.7 us.
-#ifndef SYMPA_SPLIT_STAGGER_STEPS_GRAD
-#define SYMPA_SPLIT_STAGGER_STEPS_GRAD 24
-#endif
-#ifndef SYMPA_SPLIT_STAGGER_STEPS_SPEC
-#define SYMPA_SPLIT_STAGGER_STEPS_SPEC -40
-#endif
+constexpr int SPLIT_STAGGER_STEPS_GRAD = 24;
+constexpr int SPLIT_STAGGER_STEPS_SPEC = -40;
 template <int STEPS>
 __device__ __forceinline__ void split_stagger(const bool on) {
     // STEPS < 0: the forward's scheme (siegel_dist_kernel.hpp) -- CU j of every XCD (blocks 32 j .. 32 j + 31 of the first 1 024) starts
@@ -175,7 +171,7 @@ __global__ __launch_bounds__(64, 1) void siegel_bwd_spectral_kernel(const SplitA
     using P = sympa::AdjPack<N, MODEL>;
     constexpr int WAVE_SLOTS = PassTile<N, false>::WAVE_SLOTS;
     __shared__ v2d lds[WAVE_SLOTS];
-    split_stagger<SYMPA_SPLIT_STAGGER_STEPS_SPEC>((sa.a.f.flags & SYMPA_INTERNAL_FLAG_STAGGER) != 0);      // set by launch_bwd_split
+    split_stagger<SPLIT_STAGGER_STEPS_SPEC>((sa.a.f.flags & SYMPA_INTERNAL_FLAG_STAGGER) != 0);      // set by launch_bwd_split
     const BwdArgs& a = sa.a;
     DistArgs f = a.f;
     const double* graph_dist = a.graph_dist;
@@ -287,13 +283,9 @@ __global__ __launch_bounds__(64, 1) void siegel_bwd_gradient_kernel(const SplitA
     constexpr int PLANE_SLOTS = (64 * (N * N + 1) + 1) / 2 > 64 * (N * (N + 1) / 2) ? (64 * (N * N + 1) + 1) / 2
                                                                                   : 64 * (N * (N + 1) / 2);   // scatter_add_plane tile | the two parked factors
     constexpr int SCATTER_SLOTS = MODEL == sympa::MODEL_UPPER ? PLANE_SLOTS : (SCATTER ? (ScatterTile<N>::WAVE_DOUBLES + 1) / 2 : 1);
-#ifdef SYMPA_SPLIT_AB_GLDS
-    constexpr int WAVE_SLOTS = 64 * 3 * (N * (N + 1) / 2) / 2;
-#else
     constexpr int WAVE_SLOTS = GATHER_SLOTS > SCATTER_SLOTS ? GATHER_SLOTS : SCATTER_SLOTS;
-#endif
     __shared__ v2d lds[WAVE_SLOTS];
-    split_stagger<SYMPA_SPLIT_STAGGER_STEPS_GRAD>(gridDim.x >= 2048u);
+    split_stagger<SPLIT_STAGGER_STEPS_GRAD>(gridDim.x >= 2048u);
     const BwdArgs& a = sa.a;
     DistArgs f = a.f;
     if (f.batch_counter != nullptr) {
@@ -324,11 +316,7 @@ __global__ __launch_bounds__(64, 1) void siegel_bwd_gradient_kernel(const SplitA
         gather_pair_passes<N, false>(f.base1, (int)r1, f.base2, (int)r2, lds, z1, z2);
         wave_lds_fence();
         sympa::pair_adjoint_gradient_upper<N>(
-            z1, z2, [&](const int k) {
-#ifdef SYMPA_SPLIT_AB_NOPACK       // measurement hook: the pack is not read (wrong results)
-                return 1.0 / (double)(k + 1 + lane);
-#endif
-                return *ws_at(ws + k * wss, wo); },
+            z1, z2, [&](const int k) { return *ws_at(ws + k * wss, wo); },
             [&](const int which, const sympa::Tri<N, false>& l) {
                 double* p = dtile + which * TRI * 64 + lane;
 SYMPA_UNROLL
@@ -347,22 +335,13 @@ SYMPA_UNROLL
                     for (int c = 0; c < r; ++c) l.re[r][c] = p[sympa::tri_index(N, c, r) * 64];
                 }
             },
-#ifdef SYMPA_SPLIT_AB_GLDS          // measurement hook: Re G parked in the LDS behind the factors (needs 54 KB per wave)
-            [&](const int k, const double g) { dtile[(2 * TRI + k) * 64 + lane] = g; },
-            [&](const int k) { return dtile[(2 * TRI + k) * 64 + lane]; },
-#else
             [&](const int k, const double g) { *ws_at(ws + (P::H_RE + k) * wss, wo) = g; },
             [&](const int k) { return *ws_at(ws + (P::H_RE + k) * wss, wo); },
-#endif
             [&](const double (&m)[N][N]) { stage_plane<N>(m, dtile, on); },
             [&](const int point, const int plane, const double sign) {
                 // nothing moves across this point: the scheduler otherwise pulls the first planes' atomics in front of the last
                 // congruences, whose spilled operands (scratch loads) then wait for every atomic before them
                 __builtin_amdgcn_sched_barrier(0);
-#ifdef SYMPA_SPLIT_AB_NOEMIT       // measurement hook: nothing leaves (wrong results)
-                if (dtile[lane] == 1.2345e-300) a.g1[0] = 0.0;
-                return;
-#endif
                 if constexpr (SCATTER) {
                     flush_plane_atomic<N>(sign, (int)(point == 0 ? r1 : r2), (point == 0 ? a.g1 : a.g2) + plane * N * N, dtile);
                 } else {

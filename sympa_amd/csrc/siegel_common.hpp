@@ -18,9 +18,7 @@ constexpr int BLOCK = 256;
 // slowest of the four waves (gather latency, lockstep QL sweeps) is through -- with one-wave blocks every SIMD takes its
 // next wave by itself.  Measured (profiles/r04_fwd_wave_blocks.txt, 262 144 pairs, same box, interleaved): upper n = 8 152.5 -> 149.8 us,
 // bounded n = 8 240.2 -> 237.7, upper n = 7 106.5 -> 105.5, dims 5, 6 -0.1..-0.7 %: small, never slower, bit-identical results.
-#ifndef SYMPA_FWD_WAVE_BLOCK_FROM
-#define SYMPA_FWD_WAVE_BLOCK_FROM 5
-#endif
+constexpr int SYMPA_FWD_WAVE_BLOCK_FROM = 5;
 constexpr int SYMPA_INTERNAL_FLAG_STAGGER = 0x4000;      // set by the forward launcher, never by callers (siegel_dist_kernel.hpp)
 constexpr int fwd_block(int n) { return n >= SYMPA_FWD_WAVE_BLOCK_FROM ? 64 : BLOCK; }
 

@@ -16,11 +16,8 @@ namespace sympa_hip {
 // Waves per SIMD (measured per 65 536 pairs, one 512-register wave against two 256-register waves that spill 300-1300
 // registers): upper n = 10 836 / 953 us, n = 16 2489 / 3015 us -> one wave;  bounded n = 10 1469 / 1285 us, n = 16
 // 4558 / 4036 us -> two waves (its tail of complex solves and products has the longer dependent chains to hide).
-#ifndef SYMPA_COOP_BWD_WAVES_UPPER
-#define SYMPA_COOP_BWD_WAVES_UPPER 1
-#endif
 template <int MODEL>
-constexpr int coop_bwd_waves() { return MODEL == sympa::MODEL_UPPER ? SYMPA_COOP_BWD_WAVES_UPPER : 2; }
+constexpr int coop_bwd_waves() { return MODEL == sympa::MODEL_UPPER ? 1 : 2; }
 
 template <int MODEL, int M, bool SCATTER>
 __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_kernel(const BwdArgs a, const int rounds) {
@@ -125,9 +122,6 @@ __global__ __launch_bounds__(64, coop_bwd_waves<MODEL>()) void siegel_coop_bwd_k
             });
             e[M - 1] = 0.0;
         }
-#ifdef SYMPA_BWD_FRONT_ONLY          // measurement hook: the front alone (gather, factors, E, Gram matrix, Householder form)
-        if (lane < 64) { loss_acc += d[0] + e[0] + vr[0] + vi[0] + bk[0] + phr[M - 1] + phi_[M - 1]; continue; }
-#endif
         // the QL below runs redundantly in the sixteen lanes of the pair and its predicates must agree bit for bit
 #pragma unroll
         for (int j = 0; j < M; ++j) { d[j] = bcast<0>(d[j]); e[j] = bcast<0>(e[j]); }

@@ -23,18 +23,14 @@ constexpr bool coop_two_waves() { return M <= (MODEL == sympa::MODEL_UPPER ? 14 
 // Size of the trailing block that is parked in the LDS and tridiagonalised one pair per lane (siegel_coop.hpp): what the
 // LDS of the occupancy allows -- 20 KB per wave at two waves per SIMD (4 x 4: 10.4 KB next to the 9.7 KB of the transposition
 // buffers), 40 KB at one (7 x 7: 29.1 KB).  Eight lanes per pair (A/B unit): none.
-#ifndef SYMPA_SIEGEL_TB_TWO_WAVES
-#define SYMPA_SIEGEL_TB_TWO_WAVES 4
-#endif
-#ifndef SYMPA_SIEGEL_TB_ONE_WAVE
-#define SYMPA_SIEGEL_TB_ONE_WAVE 7
-#endif
+constexpr int SIEGEL_TB_TWO_WAVES = 4;
+constexpr int SIEGEL_TB_ONE_WAVE = 7;
 // (The stores of the block carry no branch: with one `if (lane is in the block)` around them the two-wave variants needed
 // ~20 registers more and upper M = 12..14 spilled and lost 0-19 %; with every lane storing -- the outside lanes into a dummy
 // column -- they need FEWER registers than without the parked block: profiles/r03_siegel_parked_block.txt.)
 template <int MODEL, int M>
 constexpr int coop_parked_block() {
-    return spd_coop::GROUP != 16 ? 0 : (coop_two_waves<MODEL, M>() ? SYMPA_SIEGEL_TB_TWO_WAVES : SYMPA_SIEGEL_TB_ONE_WAVE);
+    return spd_coop::GROUP != 16 ? 0 : (coop_two_waves<MODEL, M>() ? SIEGEL_TB_TWO_WAVES : SIEGEL_TB_ONE_WAVE);
 }
 constexpr int COOP_GPW = spd_coop::GROUPS_PER_WAVE;
 constexpr int COOP_ROUNDS = 64 / COOP_GPW;

@@ -97,9 +97,6 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     if (n <= 4 && a.num_rows * 16 * n * n >= ((int64_t)1 << 32))
         return fail(SYMPA_ERR_BAD_ARG, "tables of dims <= 4 are limited to 4 GiB (32-bit row offsets in the gather)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#ifdef SYMPA_COOP8_SIXTEEN      // A/B build: dims 8 with SIXTEEN lanes per pair (half of them phantoms) and the parked 4 x 4 block
-    if ((a.flags & SYMPA_FLAG_COOP) && n == 8) return launch_siegel_coop(a, n, model, s);
-#endif
     if ((a.flags & SYMPA_FLAG_COOP) && (n == 7 || n == 8)) return launch_siegel_coop_half(a, n, model, s);   // A/B only: eight lanes per pair
     if ((a.flags & SYMPA_FLAG_COOP) && n == 6) return launch_siegel_coop(a, n, model, s);                 // A/B only: sixteen
     switch (n) {

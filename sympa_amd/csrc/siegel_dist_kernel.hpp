@@ -10,15 +10,10 @@
 namespace sympa_hip {
 
 // Body of one 256-thread block: pairs [first, first + 256) of the batch described by `a`.
-// EXPERIMENT: a spare instantiation selected by flags bit 0x100 for in-process A/B timing (tools/ab_bench.py);
-// identical to the product kernel unless a variant is being measured.
 // dims 5..8: the bounded model gathers only the chunks that hold upper-triangle elements through three ring buffers, the
 // upper model whole rows through two (siegel_gather.hpp: measured per model)
-#ifndef SYMPA_FWD_MASK_UPPER
-#define SYMPA_FWD_MASK_UPPER 0
-#endif
 template <int MODEL>
-constexpr bool pass_masked() { return MODEL != sympa::MODEL_UPPER || SYMPA_FWD_MASK_UPPER; }
+constexpr bool pass_masked() { return MODEL != sympa::MODEL_UPPER; }
 
 template <int N, int MODEL, bool LOWLDS>
 struct BlockLds {
@@ -91,22 +86,13 @@ __device__ __forceinline__ void dist_block(const DistArgs& a, const int64_t firs
     }
 }
 
-// Blocks per CU the compiler must make room for (dims >= 5).  1: one 512-register wave per SIMD.  A/B hook
-// (tools/build_variant.sh -DSYMPA_FWD_BIG_BLOCKS=2: two 256-register waves per SIMD, the rest spilled to scratch).
-#ifndef SYMPA_FWD_BIG_BLOCKS
-#define SYMPA_FWD_BIG_BLOCKS 1
-#endif
-// dims 6, upper: 286 registers by itself; held to 256 (two waves per SIMD, 35 registers in scratch) it measures 88.4 -> 83.7 us per
-// 262 144 pairs on the 46.6 MB table and 84.4 -> 74.4 us on an L2-resident one (profiles/r03_n6_two_waves.txt).  bounded would
-// spill 163 registers, dims 7 and 8 several hundred.
-#ifndef SYMPA_FWD_N6_WAVES
-#define SYMPA_FWD_N6_WAVES 2
-#endif
-template <int N, int MODEL> constexpr int fwd_min_blocks() {
-    return (N == 6 && MODEL == sympa::MODEL_UPPER) ? SYMPA_FWD_N6_WAVES : (N >= 5 ? SYMPA_FWD_BIG_BLOCKS : 1);
-}
+// Waves per SIMD the compiler must make room for: 1 = one 512-register wave (dims 5, 7, 8).  dims 6, upper: 286 registers by
+// itself; held to 256 (two waves per SIMD, 35 registers in scratch) it measures 88.4 -> 83.7 us per 262 144 pairs on the 46.6 MB
+// table and 84.4 -> 74.4 us on an L2-resident one (profiles/r03_n6_two_waves.txt).  bounded would spill 163 registers, dims 7 and 8
+// several hundred.
+template <int N, int MODEL> constexpr int fwd_min_blocks() { return (N == 6 && MODEL == sympa::MODEL_UPPER) ? 2 : 1; }
 
-template <int N, int MODEL, bool LOWLDS, bool EXPERIMENT = false>
+template <int N, int MODEL, bool LOWLDS>
 __global__ __launch_bounds__(fwd_block(N), (fwd_min_blocks<N, MODEL>())) void siegel_dist_kernel(const DistArgs a) {
     __shared__ v2d lds[(fwd_block(N) / 64) * BlockLds<N, MODEL, LOWLDS>::WAVE_SLOTS];
     // Staggered first round (dims 7, 8 on tables that do not fit the L2s; the launcher sets the bit): a lone launch starts one wave
@@ -117,16 +103,8 @@ __global__ __launch_bounds__(fwd_block(N), (fwd_min_blocks<N, MODEL>())) void si
     // +4-8 % on L2-resident tables (hence the size test), no gain for the bounded model (more arithmetic per byte).
     if constexpr (N >= 7) {
         if ((a.flags & SYMPA_INTERNAL_FLAG_STAGGER) && blockIdx.x < 1024u) {
-#ifndef SYMPA_FWD_STAGGER_S
-#define SYMPA_FWD_STAGGER_S 20
-#endif
-#ifndef SYMPA_FWD_STAGGER_MAP
-#define SYMPA_FWD_STAGGER_MAP 0
-#endif
-            int k = (int)((blockIdx.x >> 5) & 31u);
-            if (SYMPA_FWD_STAGGER_MAP == 1) k = (int)(__builtin_bitreverse32((unsigned)k) >> 27);
-            if (SYMPA_FWD_STAGGER_MAP == 2) k = (k & 1) ? 31 - (k >> 1) : (k >> 1);            // 0, 31, 1, 30, ...
-            for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_FWD_STAGGER_S);
+            const int k = (int)((blockIdx.x >> 5) & 31u);
+            for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
         }
     }
     dist_block<N, MODEL, LOWLDS>(a, (int64_t)blockIdx.x * fwd_block(N), lds);
@@ -147,16 +125,10 @@ struct MultiArgs {
     int num_batches;
 };
 
-// Blocks per CU the compiler must make room for in the fused multi-batch kernel (A/B hook: -DSYMPA_MULTI_MIN_BLOCKS_BOUNDED4=4
-// caps the bounded n = 4 instantiation, 146 registers = three waves per SIMD, at 128 = four like the upper one).
-#ifndef SYMPA_MULTI_MIN_BLOCKS_BOUNDED4
-#define SYMPA_MULTI_MIN_BLOCKS_BOUNDED4 1
-#endif
+// Waves per SIMD the compiler must make room for in the fused multi-batch kernel (the bounded n = 4 instantiation keeps its 146
+// registers = three waves per SIMD: capped at 128 for four it spills 66 and runs 5.39 -> 8.03 us/step, profiles/r03_rejected_variants.txt)
 template <int N, int MODEL>
-constexpr int multi_min_blocks() {
-    return (N == 4 && MODEL != sympa::MODEL_UPPER) ? SYMPA_MULTI_MIN_BLOCKS_BOUNDED4
-                                                    : ((N == 6 && MODEL == sympa::MODEL_UPPER) ? SYMPA_FWD_N6_WAVES : 1);
-}
+constexpr int multi_min_blocks() { return (N == 6 && MODEL == sympa::MODEL_UPPER) ? 2 : 1; }
 
 template <int N, int MODEL>
 __global__ __launch_bounds__(fwd_block(N), (multi_min_blocks<N, MODEL>())) void siegel_dist_multi_kernel(const MultiArgs m) {
@@ -207,9 +179,7 @@ int launch_n(const DistArgs& a, int model, hipStream_t s) {
     // low-LDS gather when asked for, or when the grid is deep enough for a second block per CU to matter
     const bool low = DmaTile<N>::ENABLED && ((a.flags & SYMPA_FLAG_LOW_LDS) || grid > 2 * 256 * (BLOCK / FB));
     hipError_t e;
-    if (N == 4 && model == SYMPA_MODEL_UPPER && !low && (a.flags & 0x100)) {   // A/B experiment slot (tools/ab_bench.py)
-        e = launch_kernel(siegel_dist_kernel<4, sympa::MODEL_UPPER, false, true>, grid, FB, st, s);
-    } else if (model == SYMPA_MODEL_UPPER) {
+    if (model == SYMPA_MODEL_UPPER) {
         if (low) e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, true>, grid, FB, st, s);
         else e = launch_kernel(siegel_dist_kernel<N, sympa::MODEL_UPPER, false>, grid, FB, st, s);
     } else {

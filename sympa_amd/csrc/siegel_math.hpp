@@ -644,11 +644,7 @@ SYMPA_HD bool ql_negligible(double e2, double da, double db) { return !(e2 > 1.3
 template <int N, int L>
 SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
     bool conv = false;
-#ifdef SYMPA_QL_SKIP            // measurement hook: the kernel without its QL iterations (wrong results, timing only)
-    for (int it = 0; it < 0; ++it) {
-#else
     for (int it = 0; it < 60; ++it) {
-#endif
         conv = ql_negligible(e2[L], d[L], d[L + 1]);
         if (wave_all(conv)) break;
         double dl = d[L], dl1 = d[L + 1], el = e2[L];

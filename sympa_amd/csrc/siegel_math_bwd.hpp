@@ -591,12 +591,7 @@ SYMPA_UNROLL
     gram<N>(e, h);
     CMat<N> v;
     bool conv;
-    constexpr bool QL_ROUTE =
-#ifndef SYMPA_BWD_EIGEN_JACOBI
-        N >= 5;
-#else
-        false;
-#endif
+    constexpr bool QL_ROUTE = N >= 5;
     if constexpr (QL_ROUTE) conv = herm_eigen_vectors_ql<N>(h, v);
     else conv = herm_eigen_vectors<N>(h, v);
     if constexpr (QL_ROUTE) {

@@ -163,11 +163,7 @@ SYMPA_UNROLL
     }
     CMat<N> v;
     bool conv;
-#ifdef SYMPA_SPLIT_EIGEN_INVIT      // A/B: eigenvalue-only QL + inverse iteration (herm_eigen_vectors_invit above; measured slower)
-    if constexpr (N >= 5) conv = herm_eigen_vectors_invit<N>(h, v);
-#else
     if constexpr (N >= 5) conv = herm_eigen_vectors_ql<N>(h, v);
-#endif
     else conv = herm_eigen_vectors<N>(h, v);
 
     double phi[N], philam[N];

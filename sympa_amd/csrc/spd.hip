@@ -43,11 +43,8 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
 // r >= M of a group are phantoms (spd_coop.hpp), the time goes with M^2.  Rows are n*n*8 bytes then, not the 2 KB image
 // the DMA tile is made for, so each lane loads the elements of its row itself (upper triangle: (min, max)).
 // two waves per SIMD (256 registers) up to this size of the handed-over block, one beyond
-#ifndef SYMPA_SPD_TB_TWO_WAVES
-#define SYMPA_SPD_TB_TWO_WAVES 10
-#endif
 template <int M>
-__global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_TWO_WAVES ? 2 : 1)) void spd16_coop_kernel(const DistArgs a) {
+__global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) void spd16_coop_kernel(const DistArgs a) {
     using namespace spd_coop;
     constexpr bool PADDED = M < N;      // historical name: "not the 2 KB image of n = 16"
     constexpr int n = M;
@@ -127,9 +124,7 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 unsigned pk = eoff2[j / 2];
-#ifndef SYMPA_SPD_EOFF_HOIST
                 asm volatile("" : "+v"(pk));        // unpack here, every round: hoisted out of the loop it is sixteen registers again
-#endif
                 const unsigned e = (j & 1) ? (pk >> 16) : (pk & 0xffffu);
                 x[j] = *reinterpret_cast<const double*>(tile + e);
                 y[j] = *reinterpret_cast<const double*>(tile + 2048 + e);
@@ -158,7 +153,6 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_
     // one pair per lane from here: the rest of the tridiagonalisation (the trailing TB x TB block of my pair), ...
     if constexpr (TB >= 3) sympa::tridiag_packed<TB>(blk, d + (M - TB), e2 + (M - TB));
     // ... QL on the tridiagonal forms, then the norm of the logarithms
-#ifndef SYMPA_SPD_QL_FORWARD
     {   // The lockstep iteration deflates position 0 first; started from the END of the Householder form (the block that was
         // reduced last) the wave needs 6 % fewer sweeps (simulated on the bench table: 372 -> 350 element-sweeps per wave)
         // and the kernel measures 1.2 % faster (profiles/r03_spd_forward_ab.txt).  A register renaming, no instructions.
@@ -168,7 +162,6 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= SYMPA_SPD_TB_
 #pragma unroll
         for (int k = 0; k < M; ++k) { d[k] = dr[k]; e2[k] = er[k]; }
     }
-#endif
     const bool conv = sympa::tridiag_ql_lockstep<M>(d, e2);
     double acc = 0.0;
 #pragma unroll

@@ -352,11 +352,7 @@ __device__ __forceinline__ bool reduce_pair_front(double (&x)[M], double (&y)[M]
 // last round together with the 63 other pairs of the wave.
 template <int M>
 constexpr int trailing_block() {
-#ifdef SYMPA_SPD_TB
-    return (SYMPA_SPD_TB > M) ? M : SYMPA_SPD_TB;
-#else
     return M < 10 ? M : 10;
-#endif
 }
 template <int TB>
 constexpr int packed_len() { return TB >= 3 ? TB * (TB + 1) / 2 : 1; }

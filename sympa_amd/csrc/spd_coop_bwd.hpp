@@ -109,11 +109,7 @@ __device__ __forceinline__ bool tridiag_ql_vectors_row(double (&d)[M], double (&
     sfor<0, M - 1>([&](auto LL) {
         constexpr int L = LL;
         bool conv = false;
-#ifdef SYMPA_QL_SKIP            // measurement hook: the kernel without its QL iterations (wrong results, timing only)
-        for (int it = 0; it < 0; ++it) {
-#else
         for (int it = 0; it < 50; ++it) {
-#endif
             int mm = M - 1;
             sfor<0, M - 1 - L>([&](auto II) {
                 constexpr int i = M - 2 - II;
@@ -176,11 +172,7 @@ __device__ __forceinline__ bool tridiag_ql_vectors_2rows(double (&d)[M], double 
     sfor<0, M - 1>([&](auto LL) {
         constexpr int L = LL;
         bool conv = false;
-#ifdef SYMPA_QL_SKIP            // measurement hook: the kernel without its QL iterations (wrong results, timing only)
-        for (int it = 0; it < 0; ++it) {
-#else
         for (int it = 0; it < 50; ++it) {
-#endif
             int mm = M - 1;
             sfor<0, M - 1 - L>([&](auto II) {
                 constexpr int i = M - 2 - II;

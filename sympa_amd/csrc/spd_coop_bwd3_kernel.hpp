@@ -126,9 +126,6 @@ __global__ __launch_bounds__(64) void spd_bwd3_eig_kernel(const int64_t b, doubl
     sympa::sort_ascending<M>(w);
     double* const out = ws + i * W::SLOT;                        // (a dead lane's slot exists: whole chunks are allocated)
     bool small_blocks = true;
-#ifdef SYMPA_BWD3_SKIP_INVIT        // measurement hook: timing without the inverse iteration (wrong results)
-    if (false)
-#endif
     small_blocks = sympa::tridiag_eigvecs_invit<M>(dk, ek, w, [&](auto IC, const double (&x)[M]) {
         constexpr int k = decltype(IC)::value;
 #pragma unroll
@@ -158,11 +155,9 @@ __global__ __launch_bounds__(64) void spd_bwd3_eig_kernel(const int64_t b, doubl
     if (lane == 0) chunk_flags[blockIdx.x] = fallback ? 1 : 0;
 }
 
-#ifndef SYMPA_BWD3_BACK_WAVES
-#define SYMPA_BWD3_BACK_WAVES 1      // 256 registers spill 77 of them; one wave: 8.26 -> 8.13 ms per 1 M pairs (the kernel is HBM-bound)
-#endif
+// one wave per SIMD: at 256 registers it spills 77 of them (8.26 -> 8.13 ms per 1 M pairs with one wave; the kernel is HBM-bound)
 template <int M>
-__global__ __launch_bounds__(64, SYMPA_BWD3_BACK_WAVES) void spd_bwd3_back_kernel(const SpdBwdArgs a, const int rounds, const double* __restrict__ ws,
+__global__ __launch_bounds__(64, 1) void spd_bwd3_back_kernel(const SpdBwdArgs a, const int rounds, const double* __restrict__ ws,
                                                               const int32_t* __restrict__ chunk_flags) {
     using namespace spd_coop;
     using W = SpdBwd3Ws<M>;

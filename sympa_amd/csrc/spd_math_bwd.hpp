@@ -252,9 +252,6 @@ SYMPA_HD double spd_pair_backward(SpdBwdWork& w, const double* __restrict__ px, 
     spd_congruence_inv(w.a, w.l, w.rd, n);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) { const double t = 0.5 * (w.a[i * n + j] + w.a[j * n + i]); w.a[i * n + j] = t; w.a[j * n + i] = t; }
-#ifdef SYMPA_SPD_EIGEN_JACOBI
-    const bool conv = spd_eigh_jacobi(w.a, w.v, w.lam, n);
-#else
     // tridiagonal QL (eigenvalues to eps ||A||), then Rayleigh quotients lam_i = v_i^T A v_i with the saved matrix for the
     // eigenvalues near zero (x ~ y in some directions), where the logarithm's relative accuracy matters
     for (int k = 0; k < n * n; ++k) w.p[k] = w.a[k];
@@ -268,7 +265,6 @@ SYMPA_HD double spd_pair_backward(SpdBwdWork& w, const double* __restrict__ px, 
         }
         w.lam[c] = acc2;
     }
-#endif
     double acc = 0.0;
     for (int i = 0; i < n; ++i) {
         ok = ok && (w.lam[i] > -1.0);

@@ -2,7 +2,7 @@
 # One gpurun call: GPU tests, smoke, the numerical self-check of every lanes-per-pair kernel instantiation, bench at the
 # driver's K and at the default K, rocprofv3 kernel trace + PMC passes, secondary workloads, training path.
 # usage: tools/gpu_check.sh <tag> [notests]
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
