@@ -7,7 +7,14 @@ What these fixtures pin instead is the published formula itself, evaluated INDEP
 repository (no Cholesky, no Householder, no QL, no torch): with mpmath at 50 digits,
     dist(x, y) = || log(x^-1/2 y x^-1/2) ||_F,     x^-1/2 and log through mp.eigsy,
 plus, for the backward kernel, the Euclidean gradients of dist by 50-digit central differences along symmetric
-directions.  Inputs and expected outputs only; nothing of geoopt or of the reference is stored."""
+directions.  Inputs and expected outputs only; nothing of geoopt or of the reference is stored.
+
+    python tools/make_golden_spd.py --from-geoopt
+closes the pin the day the dependency is provided: when `import geoopt` succeeds in the build container it evaluates geoopt's OWN
+SymmetricPositiveDefinite (default metric, as sympa/embeddings.py:70 constructs it) -- dist, egrad2rgrad, retr, projx -- on the same
+inputs and writes tests/golden/spd_geoopt_n{2,4,8,16}.npz (inputs + geoopt's outputs); tests/test_oracle_golden.py then compares
+the oracle's spd_* restatements with those files (and with a live geoopt when it is importable) and SURVEY 8f-4 is pinned.  Without
+geoopt the flag prints why it cannot run and exits 2; nothing is written."""
 import os
 import sys
 
@@ -114,5 +121,37 @@ def main():
         print(path, os.path.getsize(path), "bytes")
 
 
+def from_geoopt():
+    """geoopt's own outputs on the fixtures' inputs (only when geoopt is importable: it is absent from /root/reference and from
+    this image)."""
+    try:
+        import geoopt
+        import torch
+    except ImportError as e:
+        print(f"--from-geoopt: geoopt is not importable here ({e}); spd parity stays UNPINNED, nothing written")
+        return 2
+    torch.set_default_dtype(torch.float64)
+    man = geoopt.manifolds.SymmetricPositiveDefinite()            # sympa/embeddings.py:70: the default (affine-invariant) metric
+    for n in (2, 4, 8, 16):
+        rng = np.random.default_rng(1000 + n)
+        blob = {"case_names": [], "geoopt_version": np.array(getattr(geoopt, "__version__", "unknown"))}
+        for name, (x, y) in cases(n, rng, b=10 if n <= 8 else 6).items():
+            tx, ty = torch.from_numpy(x), torch.from_numpy(y)
+            u = torch.from_numpy(sym(rng.normal(size=x.shape)) * 0.1)
+            blob["case_names"].append(name)
+            blob[f"{name}__x"], blob[f"{name}__y"], blob[f"{name}__u"] = x, y, u.numpy()
+            blob[f"{name}__dist"] = man.dist(tx, ty).numpy()
+            blob[f"{name}__egrad2rgrad"] = man.egrad2rgrad(tx, u).numpy()
+            blob[f"{name}__retr"] = man.retr(tx, 0.05 * man.egrad2rgrad(tx, u)).numpy()
+            blob[f"{name}__projx"] = man.projx(tx + u).numpy()
+        blob["case_names"] = np.array(blob["case_names"])
+        path = os.path.join(ROOT, "tests", "golden", f"spd_geoopt_n{n}.npz")
+        np.savez_compressed(path, **blob)
+        print(path, os.path.getsize(path), "bytes")
+    return 0
+
+
 if __name__ == "__main__":
+    if "--from-geoopt" in sys.argv[1:]:
+        sys.exit(from_geoopt())
     main()
