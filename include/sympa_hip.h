@@ -420,6 +420,22 @@ int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const 
                             const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale, double scale_coef,
                             double* out, int32_t* status, int flags, void* stream);
 
+/* Packed table of the spd model, n = 6..16 (csrc/spd.hip; the Siegel counterpart is sympa_table_pack): one row of n (n + 1)
+ * doubles per point -- an n x n image whose upper triangle (diagonal included) is the point and whose strict lower triangle is the
+ * UNIT factor Lh of x = Lh D Lh^T, then the n values D^-1/2 -- made once per table version.  sympa_spd_model_forward_packed is
+ * sympa_spd_model_forward reading it: the sixteen-lanes-per-pair kernel without its factorisation (~310 of the ~1 170 VALU
+ * instructions of a round of four pairs), the first point's image read twice (symmetric rows for y - x, then its factor rows), the
+ * second point's upper triangle only.  Same values to rounding (the factor is the one the dense kernel computes).  A point that
+ * is not positive definite is reported by the pack call (SYMPA_ST_NOT_PD) and every pair it enters later comes out NaN and
+ * flagged.  sympa_spd_table_pack_bytes returns 0 where no packed kernel exists (n < 6).  Replaces the per-pair factorisation inside
+ * geoopt's SymmetricPositiveDefinite.dist (sympa/embeddings.py:70-72,142; parity UNPINNED like every spd entry). */
+int64_t sympa_spd_table_pack_bytes(int64_t num_rows, int n);
+int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, int32_t* status,
+                         void* stream);
+int sympa_spd_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
+                                   int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
+                                   double scale_coef, double* out, int32_t* status, int flags, void* stream);
+
 /* ---- SPD model, training path (PARITY UNPINNED like the forward; formulas restated from geoopt's published source,
  * pinned by 50-digit finite differences, tests/golden/spd_n*.npz) ----
  * sympa_spd_backward_rows: backward of SymmetricPositiveDefinite.dist / of Model.forward for the spd model

@@ -51,6 +51,9 @@ SYMBOLS = (
     "sympa_rsgd_step_fused",
     "sympa_spd_dist_fwd",
     "sympa_spd_model_forward",
+    "sympa_spd_table_pack_bytes",
+    "sympa_spd_table_pack",
+    "sympa_spd_model_forward_packed",
     "sympa_scatter_add_flat_rows",
     "sympa_spd_backward_rows",
     "sympa_spd_backward_workspace_bytes",
@@ -277,6 +280,14 @@ def load():
     lib.sympa_model_forward_batches_packed.argtypes = [
         C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
         _c_double_p, C.c_double, _c_double_p, C.c_double, C.c_void_p, _c_i32_p, C.c_int, C.c_void_p]
+    lib.sympa_spd_table_pack_bytes.restype = C.c_int64
+    lib.sympa_spd_table_pack_bytes.argtypes = [C.c_int64, C.c_int]
+    lib.sympa_spd_table_pack.restype = C.c_int
+    lib.sympa_spd_table_pack.argtypes = [_c_double_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, _c_i32_p, C.c_void_p]
+    lib.sympa_spd_model_forward_packed.restype = C.c_int
+    lib.sympa_spd_model_forward_packed.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_i64_p, C.c_int64, _c_i64_p,
+                                                   C.c_int64, C.c_int64, _c_double_p, C.c_double, _c_double_p, _c_i32_p, C.c_int,
+                                                   C.c_void_p]
     _lib = lib
     return lib
 

@@ -43,13 +43,22 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
 // r >= M of a group are phantoms (spd_coop.hpp), the time goes with M^2.  Rows are n*n*8 bytes then, not the 2 KB image
 // the DMA tile is made for, so each lane loads the elements of its row itself (upper triangle: (min, max)).
 // two waves per SIMD (256 registers) up to this size of the handed-over block, one beyond
-template <int M>
+// PACKED (round 5; C-ABI sympa_spd_table_pack / sympa_spd_model_forward_packed): base1 = base2 = the packed table, one row of
+// n (n + 1) doubles per point -- an n x n image whose upper triangle (with the diagonal) is the point and whose strict lower
+// triangle is its UNIT factor Lh (X = Lh D Lh^T), followed by the n values D^-1/2.  The factorisation (ldl_rows: sixteen steps of
+// pivot capture + DPP updates, ~310 of the ~1 170 VALU instructions of a round) then happens once per table version in the
+// pack kernel instead of once per pair; a round reads the first point's image twice (its symmetric rows for Y - X, then its
+// factor rows in place of them) and the second point's upper triangle only.
+template <int M, bool PACKED = false>
 __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) void spd16_coop_kernel(const DistArgs a) {
     using namespace spd_coop;
     constexpr bool PADDED = M < N;      // historical name: "not the 2 KB image of n = 16"
     constexpr int n = M;
     constexpr int TB = trailing_block<M>();
+    constexpr unsigned ROWB = PACKED ? (unsigned)(M * (M + 1) * 8) : 2048u;     // bytes per table row of the image path (M = 16)
+    constexpr unsigned ROWD = PACKED ? (unsigned)(M * (M + 1)) : (unsigned)(M * M);   // doubles per table row
     __shared__ __attribute__((aligned(16))) char tile[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) double rdl_lds[PACKED && !PADDED ? GROUPS_PER_WAVE * N : 2];
     __shared__ __attribute__((aligned(16))) double hand_all[GROUPS_PER_WAVE * (TB >= 3 ? TB * TB : 2) + (TB >= 3 ? TB + (TB & 1) : 0)];    // + one dummy row
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
@@ -93,8 +102,16 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
         for (int q = 0; q < 16; ++q) {
             const int gg = q >> 2, side = (q >> 1) & 1, h = q & 1;
             const int row = __builtin_amdgcn_readlane(side ? row2 : row1, 16 * gg + t);
-            const char* src = reinterpret_cast<const char*>(side ? a.base2 : a.base1) + (size_t)(unsigned)row * 2048u + voff[h];
+            const char* src = reinterpret_cast<const char*>(side ? a.base2 : a.base1) + (size_t)(unsigned)row * ROWB + voff[h];
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 1024), 16, 0, 0);
+        }
+        if constexpr (PACKED) {          // D^-1/2 of the four first points: 128 bytes behind each image
+#pragma unroll
+            for (int gg = 0; gg < GROUPS_PER_WAVE; ++gg) {
+                const int row = __builtin_amdgcn_readlane(row1, 16 * gg + t);
+                const char* src = reinterpret_cast<const char*>(a.base1) + (size_t)(unsigned)row * ROWB + 2048u + (unsigned)(lane & 7) * 16u;
+                if (lane < 8) __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(rdl_lds + gg * N), 16, 0, 0);
+            }
         }
     };
     double d[M], e2[M], blk[packed_len<TB>()];
@@ -109,8 +126,8 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
         if constexpr (PADDED) {
             const int rowx = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row1);     // rows of my group's pair
             const int rowy = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row2);
-            const double* px = a.base1 + (size_t)(unsigned)rowx * (unsigned)(n * n);
-            const double* py = a.base2 + (size_t)(unsigned)rowy * (unsigned)(n * n);
+            const double* px = a.base1 + (size_t)(unsigned)rowx * ROWD;
+            const double* py = a.base2 + (size_t)(unsigned)rowy * ROWD;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const int lo = r < j ? r : j, hi = r < j ? j : r;
@@ -136,7 +153,37 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
             if (t > 0 && r == t - 1) take_block<TB>(blk, hand);
         }
         double rdl, m[M];
-        const bool pd = reduce_pair_front(x, y, rdl, m, reinterpret_cast<double*>(tile) + g * TBUF, r);
+        bool pd;
+        if constexpr (PACKED) {
+            // A = Y - X with the symmetric rows, then the first point's FACTOR rows (strict lower triangle of the same image:
+            // element (r, j) itself) and D^-1/2 take the place of x -- what ldl_rows would have left there
+#pragma unroll
+            for (int j = 0; j < M; ++j) y[j] -= x[j];
+            if constexpr (PADDED) {
+                const int rowx = __builtin_amdgcn_ds_bpermute(4 * (16 * g + t), row1);
+                const double* px = a.base1 + (size_t)(unsigned)rowx * ROWD;
+#pragma unroll
+                for (int j = 0; j < M; ++j) x[j] = px[(r < n) ? r * n + j : 0];
+                rdl = (r < n) ? px[n * n + r] : 1.0;
+            } else {
+                // (derived from the lane id here, every round: hoisted out of the loop they are two more registers of a kernel that
+                // sits at exactly 256)
+                unsigned ln = (unsigned)lane;
+                asm volatile("" : "+v"(ln));
+                const unsigned base = (ln >> 4) * 4096u + (ln & 15u) * 128u;
+                const unsigned sw = ((ln >> 1) & 7u) << 4;
+#pragma unroll
+                for (int c = 0; c < M / 2; ++c) {
+                    const v2d q = *reinterpret_cast<const v2d*>(tile + base + (((unsigned)c << 4) ^ sw));
+                    x[2 * c] = q.x;
+                    x[2 * c + 1] = q.y;
+                }
+                rdl = rdl_lds[g * N + r];
+            }
+            pd = reduce_pair_front_factored(x, y, rdl, m, reinterpret_cast<double*>(tile) + g * TBUF, r);
+        } else {
+            pd = reduce_pair_front(x, y, rdl, m, reinterpret_cast<double*>(tile) + g * TBUF, r);
+        }
         // the tile is free again (images and transpose consumed): fetch the next round behind the arithmetic
         __builtin_amdgcn_s_waitcnt(0xC07F);
         wave_lds_fence();
@@ -187,7 +234,44 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
     }
 }
 
-int launch_spd(const DistArgs& a, int n, void* stream) {
+// the pack kernel: sixteen lanes per point, lane r owns row r; X = Lh D Lh^T by ldl_rows, row r of the packed image = the point's
+// row right of (and on) the diagonal, the factor's row left of it, D^-1/2 behind the image (NaN when the point is not positive
+// definite: every pair it enters then comes out NaN and is flagged)
+template <int M>
+__global__ __launch_bounds__(64) void spd_pack_kernel(const double* __restrict__ table, const int64_t num_rows, double* __restrict__ pack,
+                                                      int32_t* status) {
+    using namespace spd_coop;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, r = lane & 15;
+    const int64_t i = (int64_t)blockIdx.x * GROUPS_PER_WAVE + g;
+    const int64_t ii = i < num_rows ? i : num_rows - 1;
+    const double* px = table + ii * (M * M);
+    double x[M], orig[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int lo = r < j ? r : j, hi = r < j ? j : r;
+        x[j] = px[(hi < M) ? lo * M + hi : 0];
+        orig[j] = x[j];
+    }
+    double rdl;
+    const bool pd = ldl_rows(x, rdl);
+    if (i < num_rows && r < M) {
+        double* out = pack + i * (M * (M + 1));
+#pragma unroll
+        for (int j = 0; j < M; ++j) out[r * M + j] = (j < r) ? x[j] : orig[j];
+        out[M * M + r] = pd ? rdl : __builtin_nan("");
+    }
+    if (status != nullptr) {
+        const int bad = (i < num_rows && !pd && r == 0) ? 1 : 0;
+        const unsigned long long m = __ballot(bad);
+        if (m != 0ull && lane == 0) {
+            atomicOr(&status[0], sympa::ST_NOT_PD);
+            atomicAdd(&status[1], (int)__popcll(m));
+        }
+    }
+}
+
+int launch_spd(const DistArgs& a, int n, void* stream, const bool packed = false) {
     if (a.b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (a.b == 0) return 0;
     if (a.base1 == nullptr || a.base2 == nullptr || a.out == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
@@ -197,7 +281,8 @@ int launch_spd(const DistArgs& a, int n, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n >= 6 && !(a.flags & SYMPA_FLAG_GENERIC) && !instance_fallback(SYMPA_FAMILY_SPD_FWD, 0, n)) {     // measured crossover against the one-lane-per-pair kernel: n = 6
         switch (n) {
-#define SYMPA_SPD_COOP_CASE(MM) case MM: hipLaunchKernelGGL(spd16_coop_kernel<MM>, grid, dim3(64), 0, s, a); break;
+#define SYMPA_SPD_COOP_CASE(MM) case MM: if (packed) hipLaunchKernelGGL((spd16_coop_kernel<MM, true>), grid, dim3(64), 0, s, a); \
+                                         else hipLaunchKernelGGL((spd16_coop_kernel<MM, false>), grid, dim3(64), 0, s, a); break;
             SYMPA_SPD_COOP_CASE(6) SYMPA_SPD_COOP_CASE(7) SYMPA_SPD_COOP_CASE(8) SYMPA_SPD_COOP_CASE(9)
             SYMPA_SPD_COOP_CASE(10) SYMPA_SPD_COOP_CASE(11) SYMPA_SPD_COOP_CASE(12) SYMPA_SPD_COOP_CASE(13)
             SYMPA_SPD_COOP_CASE(14) SYMPA_SPD_COOP_CASE(15) SYMPA_SPD_COOP_CASE(16)
@@ -205,6 +290,7 @@ int launch_spd(const DistArgs& a, int n, void* stream) {
             default: break;
         }
     } else {
+        if (packed) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed forward: dims 6..16 (the sixteen-lanes-per-pair kernel)");
         hipLaunchKernelGGL(spd_dist_kernel, grid, dim3(64), 0, s, a, n);
     }
     const hipError_t e = hipGetLastError();
@@ -253,6 +339,59 @@ int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const 
     a.status = status;
     a.flags = flags;
     return launch_spd(a, n, stream);
+}
+
+int64_t sympa_spd_table_pack_bytes(int64_t num_rows, int n) {
+    if (num_rows <= 0 || n < 6 || n > sympa::SPD_MAX_N) return 0;
+    return num_rows * (int64_t)(n * (n + 1)) * 8;
+}
+
+int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, int32_t* status,
+                         void* stream) {
+    if (n < 6 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed table: dims 6..16");
+    if (table == nullptr || num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (pack == nullptr || pack_bytes < sympa_spd_table_pack_bytes(num_rows, n) || (reinterpret_cast<uintptr_t>(pack) & 15))
+        return fail(SYMPA_ERR_BAD_ARG, "packed table: a 16-byte aligned buffer of sympa_spd_table_pack_bytes(num_rows, n) bytes");
+    const dim3 grid((unsigned)((num_rows + spd_coop::GROUPS_PER_WAVE - 1) / spd_coop::GROUPS_PER_WAVE));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    double* p = reinterpret_cast<double*>(pack);
+    switch (n) {
+#define SYMPA_SPD_PACK_CASE(MM) case MM: hipLaunchKernelGGL(spd_pack_kernel<MM>, grid, dim3(64), 0, s, table, num_rows, p, status); break;
+        SYMPA_SPD_PACK_CASE(6) SYMPA_SPD_PACK_CASE(7) SYMPA_SPD_PACK_CASE(8) SYMPA_SPD_PACK_CASE(9) SYMPA_SPD_PACK_CASE(10)
+        SYMPA_SPD_PACK_CASE(11) SYMPA_SPD_PACK_CASE(12) SYMPA_SPD_PACK_CASE(13) SYMPA_SPD_PACK_CASE(14) SYMPA_SPD_PACK_CASE(15)
+        SYMPA_SPD_PACK_CASE(16)
+#undef SYMPA_SPD_PACK_CASE
+        default: break;
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+int sympa_spd_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
+                                   int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, const double* scale,
+                                   double scale_coef, double* out, int32_t* status, int flags, void* stream) {
+    if (b > 0 && (src == nullptr || dst == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null index buffer");
+    if (num_rows <= 0 && b > 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (scale != nullptr && !(scale_coef != 0.0)) return fail(SYMPA_ERR_BAD_ARG, "scale_coef must be non-zero");
+    if (n < 6 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed forward: dims 6..16");
+    if (pack == nullptr || pack_bytes < sympa_spd_table_pack_bytes(num_rows, n) || (reinterpret_cast<uintptr_t>(pack) & 15))
+        return fail(SYMPA_ERR_BAD_ARG, "packed table: a 16-byte aligned buffer of sympa_spd_table_pack_bytes(num_rows, n) bytes");
+    DistArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.base1 = reinterpret_cast<const double*>(pack);
+    a.base2 = a.base1;
+    a.idx1 = src;
+    a.idx2 = dst;
+    a.idx1_stride = src_stride;
+    a.idx2_stride = dst_stride;
+    a.num_rows = num_rows;
+    a.b = b;
+    a.scale = scale;
+    a.inv_scale_coef = 1.0 / scale_coef;
+    a.out = out;
+    a.status = status;
+    a.flags = flags & ~(SYMPA_FLAG_GENERIC);
+    return launch_spd(a, n, stream, true);
 }
 
 }  // extern "C"

@@ -344,6 +344,18 @@ __device__ __forceinline__ bool reduce_pair_front(double (&x)[M], double (&y)[M]
     return pd;
 }
 
+// The same with the factorisation taken from the packed table (spd.hip, PACKED): x = the factor rows Lh, rdl = D^-1/2 of my row (NaN
+// when the point was not positive definite at pack time), y = A = Y - X already.
+template <int M>
+__device__ __forceinline__ bool reduce_pair_front_factored(const double (&x)[M], double (&y)[M], const double rdl, double (&m)[M],
+                                                           double* __restrict__ tbuf, const int r) {
+    solve_right_unit(y, x);
+    transpose_rows(y, m, tbuf, r);
+    sfor<0, M>([&](auto J) { m[J] *= rdl; });
+    const unsigned long long fin = __ballot(rdl == rdl);
+    return ((fin >> (threadIdx.x & 48)) & 0xffffull) == 0xffffull;
+}
+
 // Trailing block handed to the one-pair-per-lane phase (spd_math.hpp tridiag_packed).  A Householder step in the
 // row-per-lane layout costs ~75 wave instructions of group-uniform scalar work and reductions next to its 3 (M - k - 1)
 // useful DPP FMAs, and serves FOUR pairs; the same step one pair per lane serves 64.  So only the first M - TB steps

@@ -31,6 +31,12 @@ class _SpdBatches:
     def run(self):
         from sympa_amd import ops
         m = self.model
+        pk = m.packed_table()
+        if pk is not None and sum(int(t.shape[0]) for t in self.batches) >= PACKED_MIN_PAIRS:
+            pk.ensure(m.embeddings.embeds)          # (one tuple comparison while the table's version has not moved)
+            for t, o in zip(self.batches, self.outs):
+                ops.spd_model_forward_packed(pk, t, m.scale.data, m.scale_coef, out=o)
+            return
         for t, o in zip(self.batches, self.outs):
             ops.spd_model_forward(m.embeddings.embeds.data, t, m.scale.data, m.scale_coef, out=o)
 
@@ -85,6 +91,11 @@ class Model(nn.Module):
             c = self._forward_cache()
         table, scale, weights, model_name, metric_name = c[:5]
         if model_name == "spd":
+            if not (torch.is_grad_enabled() and (table.requires_grad or scale.requires_grad)) and \
+                    input_triplet.shape[0] >= PACKED_MIN_PAIRS:
+                pk = self.packed_table()            # no autograd graph to build: the packed table once its version is seen twice
+                if pk is not None and pk.current(table):
+                    return ops.spd_model_forward_packed(pk, input_triplet, scale, self.scale_coef)
             return sa.spd_model_forward(table, input_triplet, scale, self.scale_coef)
         if torch.is_grad_enabled() and (table.requires_grad or scale.requires_grad or
                                         (weights is not None and weights.requires_grad)):
@@ -98,7 +109,8 @@ class Model(nn.Module):
         return ops.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
 
     def packed_table(self):
-        """The ops.PackedTable of this model's embedding table (dims 5..8 of the Siegel models on the GPU; None elsewhere, with
+        """The ops.PackedTable of this model's embedding table (dims 5..8 of the Siegel models, n = 16 of the spd model, on the GPU;
+        None elsewhere, with
         `model.use_packed = False` or SYMPA_NO_PACKED=1): upper triangles + inverted Cholesky factor per point, made once per
         table version (the ManifoldParameter's torch version counter, which every sympa_amd optimiser step moves) and shared by
         forward() under no_grad, forward_batches() and evaluate()."""
@@ -106,11 +118,12 @@ class Model(nn.Module):
             return None
         table = self.embeddings.embeds
         name = self.manifold.model_name
-        if not ops.PackedTable.supported(table, name):
+        cls = ops.SpdPackedTable if name == "spd" else ops.PackedTable
+        if not cls.supported(table, name):
             return None
         pk = self.__dict__.get("_packed")
         if pk is None or pk.model != name:
-            pk = self.__dict__["_packed"] = ops.PackedTable(name)
+            pk = self.__dict__["_packed"] = cls(name)
         return pk
 
     def _metric_key(self):

@@ -1161,6 +1161,89 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, fla
     return out
 
 
+class SpdPackedTable(PackedTable):
+    """PackedTable of the spd model (C-ABI sympa_spd_table_pack, n = 6..16): per point the n x n image [point's upper triangle |
+    unit factor Lh of x = Lh D Lh^T in the strict lower triangle] + D^-1/2, made once per table version -- the pair kernel then
+    skips the factorisation.  Same life cycle as PackedTable (`current` / `ensure` / `invalidate`)."""
+
+    @staticmethod
+    def supported(table, model="spd"):
+        return (table.is_cuda and table.dtype == torch.float64 and table.dim() == 3 and table.shape[1] == table.shape[2]
+                and SPD_PACKED_DIMS[0] <= table.shape[1] <= SPD_PACKED_DIMS[1] and table.is_contiguous())
+
+    def __init__(self, model="spd"):
+        super().__init__("spd")
+
+    @staticmethod
+    def _key_of(table):
+        return (table.untyped_storage().data_ptr(), table.storage_offset(), table.shape[0], table.shape[1], table._version,
+                table.device)
+
+    def current(self, table):
+        key = SpdPackedTable._key_of(table)
+        if key == self.key:
+            return True
+        if getattr(self, "_seen", None) == key:
+            self.ensure(table)
+            return True
+        self._seen = key
+        return False
+
+    def ensure(self, table):
+        key = SpdPackedTable._key_of(table)
+        if key == self.key:
+            return self
+        lib = _lib.load()
+        if not SpdPackedTable.supported(table):
+            raise ValueError("SpdPackedTable: a contiguous float64 [N,n,n] device table, n = %d..%d" % SPD_PACKED_DIMS)
+        num_rows, n = table.shape[0], table.shape[1]
+        need = int(lib.sympa_spd_table_pack_bytes(num_rows, n))
+        if self.pack is None or self.pack.numel() != need or self.pack.device != table.device:
+            self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
+        with torch.cuda.device(table.device):
+            rc = lib.sympa_spd_table_pack(table.data_ptr(), num_rows, n, self.pack.data_ptr(), need,
+                                          _status_buf(table.device).data_ptr(), torch.cuda.current_stream(table.device).cuda_stream)
+        _lib.check(rc)
+        self.key, self._src = key, table.untyped_storage()
+        self.num_rows, self.n, self.bytes = num_rows, n, need
+        self.repacks += 1
+        return self
+
+
+# the packed spd forward is used where it measured faster and does not spill (profiles/r05_spd_packed_forward.txt)
+SPD_PACKED_DIMS = (16, 16)
+
+
+def spd_model_forward_packed(packed, triplets, scale=None, scale_coef=1.0, out=None):
+    """spd Model.forward over an SpdPackedTable (`packed.ensure(table)` first): C-ABI sympa_spd_model_forward_packed."""
+    lib = _lib.load()
+    _need_gpu(triplets, "triplets")
+    if triplets.dtype != torch.int64 or triplets.dim() != 2 or triplets.shape[1] < 2:
+        raise TypeError("triplets must be an int64 [b, >=2] tensor")
+    if triplets.stride(1) != 1:
+        triplets = triplets.contiguous()
+    dev = packed.pack.device
+    b = triplets.shape[0]
+    stride = triplets.stride(0) if b > 1 else triplets.shape[1]
+    if out is None:
+        out = torch.empty(b, dtype=torch.float64, device=dev)
+    if b == 0:
+        return out
+    _gate(_sc.SPD_FWD, "spd", packed.n, dev)
+    sc = None
+    if scale is not None:
+        sc = scale.detach().reshape(-1)[:1].to(device=dev, dtype=torch.float64).contiguous()
+    tp = triplets.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.sympa_spd_model_forward_packed(packed.pack.data_ptr(), packed.bytes, packed.num_rows, packed.n, tp, stride, tp + 8,
+                                                stride, b, None if sc is None else sc.data_ptr(), float(scale_coef),
+                                                out.data_ptr(), _status_buf(dev).data_ptr(), 0, _stream())
+    _lib.check(rc)
+    if _debug:
+        check_status(dev)
+    return out
+
+
 def _spd_bwd_workspace(lib, b, n, dev, flags, workspace):
     """The caller-owned scratch of the three-phase spd backward (C-ABI sympa_spd_backward_workspace_bytes; 0 bytes where no kernel
     uses one): `workspace` when given (a persistent uint8 tensor: what a replayed graph wants), else a fresh tensor -- the caching

@@ -217,3 +217,116 @@ def test_model_uses_the_pack_and_follows_the_table(dev):
         assert m.packed_table() is None
         assert torch.equal(m(trip), dense())
     ops.check_status(dev)
+
+
+# ---- spd (configs[4]; PARITY UNPINNED like every spd entry: geoopt is absent from the reference tree) ----------------------------
+
+def spd_packed_dist(x, y, dev="cuda:0"):
+    from sympa_amd import ops
+    b = x.shape[0]
+    table = torch.cat((x, y)).to(dev).contiguous()
+    trip = torch.stack((torch.arange(b), torch.arange(b) + b), 1).to(dev)
+    pk = ops.SpdPackedTable().ensure(table)
+    out = ops.spd_model_forward_packed(pk, trip)
+    ops.check_status(torch.device(dev))
+    return out.cpu()
+
+
+@pytest.mark.parametrize("n", [8, 16])
+def test_spd_packed_forward_against_mpmath_goldens(dev, monkeypatch, n):
+    """The 50-digit evaluations of the published formula (tests/golden/spd_n*.npz) through the packed path: the tolerances of
+    tests/test_spd.py::test_gpu_spd_against_mpmath_goldens (the factor is the one the dense kernel computes)."""
+    from sympa_amd import ops
+    monkeypatch.setattr(ops, "SPD_PACKED_DIMS", (6, 16))
+    g = np.load(f"{GOLDEN}/spd_n{n}.npz")
+    for case in g["case_names"]:
+        x, y, want = torch.from_numpy(g[f"{case}__x"]), torch.from_numpy(g[f"{case}__y"]), g[f"{case}__dist_exact50"]
+        got = spd_packed_dist(x, y)
+        tol = {"s1.5": 2e-7 if n < 16 else 3e-6, "cond1e6": 1e-9}.get(str(case), 1e-11)
+        assert rel_err(got, want, atol=1e-13) < tol, (n, case)
+        if case == "same":
+            assert torch.all(got == 0)
+
+
+@pytest.mark.parametrize("n", list(range(6, 17)))
+def test_spd_packed_forward_equals_dense_kernel_every_size(dev, monkeypatch, n):
+    """Every instantiation (n = 6..16; the binding uses the packed path at n = 16 only, where it is faster): packed == dense to
+    1e-12 and the oracle to 1e-10 on seeded tables of three scales, ragged batch, bad index, a point that is not positive definite."""
+    from sympa_amd import ops
+    from tests.helpers import spd_points
+    monkeypatch.setattr(ops, "SPD_PACKED_DIMS", (6, 16))
+    g = torch.Generator().manual_seed(3000 + n)
+    N, b = 211, 333
+    for s in (1e-3, 0.3, 0.8):
+        table = spd_points(N, n, s, g)
+        trip = torch.stack((torch.randint(0, N, (b,), generator=g), torch.randint(0, N, (b,), generator=g)), 1)
+        tab_d, trip_d = table.to(dev), trip.to(dev)
+        pk = ops.SpdPackedTable().ensure(tab_d)
+        got = ops.spd_model_forward_packed(pk, trip_d).cpu()
+        dense = ops.spd_model_forward(tab_d, trip_d).cpu()
+        assert rel_err(got, dense, atol=1e-13) < 1e-12, (n, s)
+        assert rel_err(got, so.spd_dist(table[trip[:, 0]], table[trip[:, 1]]), atol=1e-12) < 1e-10, (n, s)
+    ops.check_status(dev)
+    bad = ops.spd_model_forward_packed(pk, torch.tensor([[1, 2], [3, N], [-1, 0]], device=dev))
+    assert torch.isfinite(bad[0]) and torch.isnan(bad[1]) and torch.isnan(bad[2])
+    with pytest.raises(IndexError):
+        ops.check_status(dev)
+    off = tab_d.clone()
+    off[4] = -off[4]
+    pk_off = ops.SpdPackedTable().ensure(off)
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)                      # the pack kernel reports the point
+    out = ops.spd_model_forward_packed(pk_off, torch.tensor([[4, 5], [1, 2]], device=dev))
+    assert torch.isnan(out[0]) and torch.isfinite(out[1])
+    with pytest.raises(AssertionError):
+        ops.check_status(dev)
+
+
+def test_spd_packed_forward_full_size_and_model(dev):
+    """configs[4] at full size (n = 16, 100 000 points, 1 048 576 pairs): packed == dense to 1e-12, symmetry, d(x, x) = 0; and the
+    spd Model takes the packed path under no_grad from the second call on an unchanged table and repacks after an optimiser step."""
+    from sympa_amd import data, ops
+    from sympa_amd.model import Model
+    from sympa_amd.optim import RiemannianSGD
+    n, rows, b = 16, 100_000, 1 << 20
+    table = data.spd_table(rows, n, scale=0.1, seed=7).to(dev)
+    trip = data.sample_pairs(rows, b, 0, 7).to(dev)
+    pk = ops.SpdPackedTable().ensure(table)
+    d_p = ops.spd_model_forward_packed(pk, trip)
+    d_d = ops.spd_model_forward(table, trip)
+    ops.check_status(dev)
+    assert torch.isfinite(d_p).all() and (d_p > 0).all()
+    assert rel_err(d_p.cpu(), d_d.cpu(), atol=1e-13) < 1e-12
+    flipped = trip[:, [1, 0]].contiguous()
+    assert rel_err(ops.spd_model_forward_packed(pk, flipped).cpu(), d_p.cpu()) < 1e-11
+    same = torch.stack((trip[:, 0], trip[:, 0]), 1).contiguous()
+    assert torch.all(ops.spd_model_forward_packed(pk, same) == 0)
+    del table, pk, d_p, d_d
+
+    class A:
+        manifold, metric, dims, num_points = "spd", "riem", 16, 2000
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.spd_table(2000, 16, scale=0.3, seed=3)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(1)
+    t = torch.randint(0, 2000, (8192, 3), generator=g).to(dev)
+    pk = m.packed_table()
+    assert pk is not None and pk.repacks == 0
+    with torch.no_grad():
+        a = m(t)
+        assert pk.repacks == 0
+        b2 = m(t)
+        assert pk.repacks == 1 and rel_err(b2.cpu(), a.cpu(), atol=1e-13) < 1e-12
+    opt = RiemannianSGD(m.parameters(), lr=0.01, weight_decay=0.0, stabilize=None)
+    gr = torch.randn(m.embeddings.embeds.shape, generator=g, dtype=torch.float64).to(dev) * 0.05
+    m.embeddings.embeds.grad = 0.5 * (gr + gr.transpose(-1, -2))
+    opt.step()
+    with torch.no_grad():
+        c = m.forward_batches([t])[0]
+        assert pk.repacks == 2
+        assert rel_err(c.cpu(), ops.spd_model_forward(m.embeddings.embeds.data, t, m.scale.data, m.scale_coef).cpu(), atol=1e-13) < 1e-12
+        assert not torch.allclose(c, a)
+    ops.check_status(dev)
