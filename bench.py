@@ -68,10 +68,10 @@ def algorithmic_bytes_per_pair(n, model="upper"):
     return 2 * 8 + 2 * (planes * n * n * 8) + 8
 
 
-def kernel_name(model, n, low_lds):
+def kernel_name(model, n, low_lds, packed=False):
     """Name of the kernel instantiation a forward launch runs (as `rocprofv3 --kernel-trace` prints it)."""
     if model == "spd":
-        return f"spd16_coop_kernel<{n}>" if n >= 6 else "spd_dist_kernel"
+        return f"spd16_coop_kernel<{n}, {'true' if packed else 'false'}>" if n >= 6 else "spd_dist_kernel"
     if n > 8:
         return f"siegel_coop_kernel (n={n})"
     low = bool(low_lds) and n in (2, 4)          # DmaTile<N>::ENABLED (csrc/siegel_gather.hpp)
@@ -378,6 +378,8 @@ def main():
     table = net.embeddings.embeds.data      # the single-step kernels below read the same table
     scale = net.scale.data
 
+    spd_pack = net.packed_table() if model == "spd" else None
+
     def sync_all():
         torch.cuda.synchronize(dev)
         if use_dist:
@@ -437,7 +439,10 @@ def main():
         def step(self, i, fl=None, dst=None):
             o = (self.outs if dst is None else dst)[i % nb]
             if model == "spd":
-                ops.spd_model_forward(table, self.batches[i % nb], scale, 1.0, out=o)
+                if spd_pack is not None and fl is None:      # Model's no-grad path: the packed table (one pack per table version)
+                    ops.spd_model_forward_packed(spd_pack.ensure(net.embeddings.embeds), self.batches[i % nb], scale, 1.0, out=o)
+                else:                                        # fl given: the reference pass of the dense kernel
+                    ops.spd_model_forward(table, self.batches[i % nb], scale, 1.0, out=o)
                 return
             ops.model_forward(table, self.batches[i % nb], model, metric, None, scale, 1.0, out=o,
                               flags=self.flags if fl is None else fl)
@@ -631,6 +636,7 @@ def main():
         return timed_groups(run_group, per_group)
 
     default_kernel = kernel_name(model, n, 0)
+    pack_us = None
     if fused is not None:
         # the timed region's kernel: launches of spl steps (the last one of what is left), strictly sequential on the
         # launch stream -- its average duration IS the event-bracketed repetition of the timed region over its launches
@@ -650,7 +656,6 @@ def main():
         k_timed = timed_groups(fused_group, reps * n_launches)
         timed_pairs_per_launch = my_pairs * args.steps / n_launches
         k_default = kernel_time(0)
-        pack_us = None
         if packed:          # what a table that changes before every call pays on top: one sympa_table_pack over the table
             pk = net.packed_table()
 
@@ -659,10 +664,15 @@ def main():
                 pk.ensure(net.embeddings.embeds)
             pack_us = timed_groups(repack, 1)[1] * 1e3
     else:
-        timed_kernel = kernel_name(model, n, flags & ops.FLAG_LOW_LDS)
-        k_timed = kernel_time(flags)
+        timed_kernel = kernel_name(model, n, flags & ops.FLAG_LOW_LDS, packed=spd_pack is not None)
+        k_timed = kernel_time(None if spd_pack is not None else flags)
         timed_pairs_per_launch = my_pairs
         k_default = k_timed if default_kernel == timed_kernel else kernel_time(0)
+        if spd_pack is not None:
+            def repack():
+                spd_pack.invalidate()
+                spd_pack.ensure(net.embeddings.embeds)
+            pack_us = timed_groups(repack, 1)[1] * 1e3
 
     if rank == 0:
         pairs_total = global_pairs * args.steps
@@ -799,11 +809,12 @@ def main():
             "throughput_frac_of_hbm_roof": (value / world) * bpp / (HBM_PEAK_GBS * 1e9),
         }
         rec["config"]["steps_per_launch"] = min(spl, args.steps) if fused is not None else 1
-        if fused is not None and pack_us is not None:
+        if pack_us is not None:
             rec["packed_table"] = {"pack_us": pack_us, "rows": nodes,
                                    "ms_per_step_if_the_table_changed_before_every_step": rec["ms_per_step"] + pack_us * 1e-3,
-                                   "note": "dims 5..8: the timed region reads the packed table (upper triangles + inverted Cholesky "
-                                           "factor per point, made once per table version: sympa_table_pack); the pack is NOT in the "
+                                   "note": "Siegel dims 5..8 / spd: the timed region reads the packed table (per point the upper triangles "
+                                           "+ inverted Cholesky factor, spd: the unit LDL^T factor; made once per table version: "
+                                           "sympa_table_pack / sympa_spd_table_pack); the pack is NOT in the "
                                            "timed region (the table does not change between the K steps, as in Runner.evaluate, "
                                            "runner.py:124-135) -- its cost is reported here"}
         rec["value_" + args.scaling] = value

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
             const int gg = q >> 2, side = (q >> 1) & 1, h = q & 1;
             const int row = __builtin_amdgcn_readlane(side ? row2 : row1, 16 * gg + t);
             const char* src = reinterpret_cast<const char*>(side ? a.base2 : a.base1) + (size_t)(unsigned)row * ROWB + voff[h];
+            // (fetching only the chunks of the SECOND point that reach its upper triangle -- 84 of 128 -- was measured: no gain,
+            // packed / dense 0.904 against 0.899 with whole images, profiles/r05_spd_packed_forward.txt)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 1024), 16, 0, 0);
         }
         if constexpr (PACKED) {          // D^-1/2 of the four first points: 128 bytes behind each image

@@ -1169,7 +1169,7 @@ class SpdPackedTable(PackedTable):
     @staticmethod
     def supported(table, model="spd"):
         return (table.is_cuda and table.dtype == torch.float64 and table.dim() == 3 and table.shape[1] == table.shape[2]
-                and SPD_PACKED_DIMS[0] <= table.shape[1] <= SPD_PACKED_DIMS[1] and table.is_contiguous())
+                and table.shape[1] in SPD_PACKED_DIMS and table.is_contiguous())
 
     def __init__(self, model="spd"):
         super().__init__("spd")
@@ -1195,7 +1195,7 @@ class SpdPackedTable(PackedTable):
             return self
         lib = _lib.load()
         if not SpdPackedTable.supported(table):
-            raise ValueError("SpdPackedTable: a contiguous float64 [N,n,n] device table, n = %d..%d" % SPD_PACKED_DIMS)
+            raise ValueError(f"SpdPackedTable: a contiguous float64 [N,n,n] device table, n in {sorted(SPD_PACKED_DIMS)}")
         num_rows, n = table.shape[0], table.shape[1]
         need = int(lib.sympa_spd_table_pack_bytes(num_rows, n))
         if self.pack is None or self.pack.numel() != need or self.pack.device != table.device:
@@ -1210,8 +1210,9 @@ class SpdPackedTable(PackedTable):
         return self
 
 
-# the packed spd forward is used where it measured faster and does not spill (profiles/r05_spd_packed_forward.txt)
-SPD_PACKED_DIMS = (16, 16)
+# the packed spd forward is used where it measured faster (profiles/r05_spd_packed_forward.txt: n = 13..15 spill at 256 registers
+# and lose 6-32 %; n = 6, 8 gain less than a pack costs); the C-ABI serves every n = 6..16
+SPD_PACKED_DIMS = frozenset({9, 10, 11, 12, 16})
 
 
 def spd_model_forward_packed(packed, triplets, scale=None, scale_coef=1.0, out=None):

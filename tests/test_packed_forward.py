@@ -237,7 +237,7 @@ def test_spd_packed_forward_against_mpmath_goldens(dev, monkeypatch, n):
     """The 50-digit evaluations of the published formula (tests/golden/spd_n*.npz) through the packed path: the tolerances of
     tests/test_spd.py::test_gpu_spd_against_mpmath_goldens (the factor is the one the dense kernel computes)."""
     from sympa_amd import ops
-    monkeypatch.setattr(ops, "SPD_PACKED_DIMS", (6, 16))
+    monkeypatch.setattr(ops, "SPD_PACKED_DIMS", frozenset(range(6, 17)))
     g = np.load(f"{GOLDEN}/spd_n{n}.npz")
     for case in g["case_names"]:
         x, y, want = torch.from_numpy(g[f"{case}__x"]), torch.from_numpy(g[f"{case}__y"]), g[f"{case}__dist_exact50"]
@@ -254,7 +254,7 @@ def test_spd_packed_forward_equals_dense_kernel_every_size(dev, monkeypatch, n):
     1e-12 and the oracle to 1e-10 on seeded tables of three scales, ragged batch, bad index, a point that is not positive definite."""
     from sympa_amd import ops
     from tests.helpers import spd_points
-    monkeypatch.setattr(ops, "SPD_PACKED_DIMS", (6, 16))
+    monkeypatch.setattr(ops, "SPD_PACKED_DIMS", frozenset(range(6, 17)))
     g = torch.Generator().manual_seed(3000 + n)
     N, b = 211, 333
     for s in (1e-3, 0.3, 0.8):

@@ -9,7 +9,7 @@ import torch  # noqa: E402
 
 from sympa_amd import data, ops  # noqa: E402
 
-ops.SPD_PACKED_DIMS = (6, 16)            # (the binding's default restricts the packed path to the dims where it is the faster one)
+ops.SPD_PACKED_DIMS = frozenset(range(6, 17))            # (the binding's default restricts the packed path to the dims where it is the faster one)
 dev = torch.device("cuda:0")
 shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or \
     [(16, 100000, 1048576)] + [(n, 100000, 262144) for n in (15, 14, 13, 12, 11, 10, 9, 8, 6)]
