@@ -65,7 +65,7 @@ extern "C" {
 #define SYMPA_FLAG_FUSE 8 /* sympa_model_forward_batches only (dims <= SYMPA_MAX_DIMS): up to SYMPA_MAX_FUSED_BATCHES
                              consecutive batches per kernel launch instead of one launch per batch */
 #define SYMPA_MAX_FUSED_BATCHES 32
-#define SYMPA_FLAG_COOP 32 /* A/B switch of the sixteen-lanes-per-pair layout (DESIGN.md sections 5, 8, 12):
+#define SYMPA_FLAG_COOP 32 /* A/B switch of the sixteen-lanes-per-pair layout (DESIGN.md sections 5, 8, 10):
                               forward, dims 6 and 8: run it instead of the one-pair-per-lane kernel (2-2.5x slower there);
                               backward entries, dims 5..8: the eight-lanes-per-pair kernels (two pairs per DPP row; the default
                               where measured faster: the fused step at n = 8, bounded n = 8 rows, bounded n = 7 fused);
@@ -99,7 +99,7 @@ const char* sympa_last_error(void);
 int sympa_max_dims(void);
 
 /* Kernel families whose default instantiations use the sixteen- / eight-lanes-per-pair layout with inline-asm DPP
- * instructions (DESIGN.md section 8: the compiler cannot see their hazards; the build scans the ISA, and a numerical self-check
+ * instructions (DESIGN.md section 11: the compiler cannot see their hazards; the build scans the ISA, and a numerical self-check
  * compares every instantiation with the one-lane kernel on first use -- sympa_amd/selfcheck.py).  An instantiation
  * (family, model, n) marked here is routed to the one-lane-per-pair / one-row-per-lane kernel by every entry point, whatever
  * the flags; model is SYMPA_MODEL_* (0 for the spd families).  Process-wide, thread-safe, no GPU call.  No reference

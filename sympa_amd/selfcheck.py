@@ -1,7 +1,7 @@
 """Numerical gate of the sixteen- / eight-lanes-per-pair kernels (inline-asm DPP, csrc/spd_coop.hpp).
 
 The compiler does not see the cross-lane reads inside those asm statements; the build scans every translation unit's
-ISA for the DPP hazard (tools/check_dpp_hazards.py), but DESIGN.md section 8 records kernels that scanned clean and
+ISA for the DPP hazard (tools/check_dpp_hazards.py), but docs/DESIGN_rounds_3_4.md section 13 records kernels that scanned clean and
 were still wrong.  So the scan is not trusted alone: the first time an instantiation (family, model, n) of that layout
 is used on a device, a small fixed batch goes through it AND through the one-lane-per-pair kernel of the same
 arithmetic; on disagreement the instantiation is routed to the one-lane kernel for the rest of the process

@@ -264,7 +264,7 @@ def test_generic_dims_fallback_kernel(dev, model, n):
         assert rel_err(got, so.manifold_dist(model, z1, z2, metric)) < 1e-8, (model, n, metric)
 
 
-@pytest.mark.parametrize("n", list(range(9, 17)))      # EVERY instantiation of the layout (DESIGN.md section 8)
+@pytest.mark.parametrize("n", list(range(9, 17)))      # EVERY instantiation of the layout (DESIGN.md section 11)
 @pytest.mark.parametrize("model", MODELS)
 def test_dims_9_to_16_cooperative_kernel(dev, model, n):
     """9 <= n <= 16: sixteen lanes per pair (csrc/siegel_coop.hpp), n < 16 padded with the point i I (upper) / 0 (bounded).

@@ -138,7 +138,7 @@ def test_gpu_spd16_cooperative_kernel_against_oracle_and_generic_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", list(range(6, 17)))     # EVERY instantiation of the layout (DESIGN.md section 8)
+@pytest.mark.parametrize("n", list(range(6, 17)))     # EVERY instantiation of the layout (DESIGN.md section 11)
 def test_gpu_spd_padded_cooperative_kernel(n):
     """6 <= n < 16 runs the sixteen-lanes-per-pair kernel on diag(X, I), diag(Y, I); FLAG_GENERIC forces the runtime-n
     kernel.  Both read only the upper triangle."""

@@ -137,7 +137,7 @@ def test_identical_points_and_exact_zero():
 
 def test_reflector_must_come_from_one_source():
     """Mixing lane k's row with the lanes' own column elements loses accuracy when the eliminated column is small
-    (DESIGN.md section 12): the row variant is measurably worse on the same inputs."""
+    (DESIGN.md section 10): the row variant is measurably worse on the same inputs."""
     g = torch.Generator().manual_seed(1616)
     x, y = spd_points(1000, N, 0.3, g), spd_points(1000, N, 0.3, g)
     want = so.spd_dist(x, y).numpy()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe for the unexplained wrong-result builds of the n = 16 sixteen-lanes backward kernels:
+"""Probe for the unexplained wrong-result builds of the n = 16 sixteen-lanes backward kernels (docs/DESIGN_rounds_3_4.md section 13):
    SYMPA_HIP_LIB=build_ab/<variant>.so python tools/miscompile_probe.py [n] [model]
 runs the rows-out backward and the fused scatter form of that build against the one-lane-per-pair kernel of the same
 build and prints the worst relative row error (1e-10 = fine, O(1) = the miscompilation)."""
