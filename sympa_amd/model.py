@@ -104,7 +104,7 @@ class Model(nn.Module):
         # dims 5..8 over the packed table once the same table version is seen a second time (ops.PackedTable)
         if 5 <= table.shape[-1] <= 8 and input_triplet.shape[0] >= PACKED_MIN_PAIRS:
             pk = self.packed_table()
-            if pk is not None and pk.current(table):
+            if pk is not None and pk.current(table, input_triplet.shape[0]):
                 return ops.model_forward_packed(pk, input_triplet, metric_name, weights, scale, self.scale_coef)
         return ops.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
 

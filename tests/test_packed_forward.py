@@ -330,3 +330,31 @@ def test_spd_packed_forward_full_size_and_model(dev):
         assert rel_err(c.cpu(), ops.spd_model_forward(m.embeddings.embeds.data, t, m.scale.data, m.scale_coef).cpu(), atol=1e-13) < 1e-12
         assert not torch.allclose(c, a)
     ops.check_status(dev)
+
+
+def test_bounded_model_packs_at_first_sight_on_large_calls(dev):
+    """The bounded model's dense kernel factors I - W W^H per pair; from 4 pairs per table row on, one pack + the packed kernel is
+    the faster route even for a single call: Model.forward packs at FIRST sight there (small calls still wait for the second)."""
+    from sympa_amd import data, ops
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "bounded", "finf", 7, 600
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.trained_like_table(600, 7, model="bounded", seed=3)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(1)
+    small = torch.randint(0, 600, (2000, 3), generator=g).to(dev)          # < 4 N pairs (and < PACKED_MIN_PAIRS)
+    big = torch.randint(0, 600, (8192, 3), generator=g).to(dev)            # >= 4 N
+    pk = m.packed_table()
+    with torch.no_grad():
+        m(small)
+        assert pk.repacks == 0
+        got = m(big)
+        assert pk.repacks == 1
+        want = ops.model_forward(m.embeddings.embeds.data, big, "bounded", "finf", None, m.scale.data, m.scale_coef)
+        assert rel_err(got.cpu(), want.cpu(), atol=1e-13) < 1e-12
+    ops.check_status(dev)
