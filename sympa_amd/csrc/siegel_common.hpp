@@ -77,6 +77,33 @@ __device__ __forceinline__ void ap_store(const DistArgs& a, const int64_t p, con
 }
 #endif
 
+// Arguments of the PERSISTENT forward kernels (siegel_packed_kernel.hpp): up to SYMPA_MAX_FUSED_BATCHES batches per launch, tiles
+// of 64 pairs numbered through the batches; every wave walks tiles t, t + grid, ...
+struct PackedArgs {
+    const double* pack;                               // the packed table (packed kernels) / the first points' rows (dense kernel)
+    const double* base2;                              // dense kernel: the second points' rows (the same table, or z2 of a dist call)
+    int identity;                                     // dense kernel: pair i reads rows (i, i) of (pack, base2): pre-gathered points
+    int64_t num_rows;
+    const int64_t* idx1[SYMPA_MAX_FUSED_BATCHES];     // src ids of batch k, element i at idx1[k][i * stride1]
+    const int64_t* idx2[SYMPA_MAX_FUSED_BATCHES];
+    double* out[SYMPA_MAX_FUSED_BATCHES];
+    int64_t b[SYMPA_MAX_FUSED_BATCHES];
+    unsigned tile_end[SYMPA_MAX_FUSED_BATCHES];       // exclusive prefix end of batch k, in tiles of 64 pairs
+    int64_t stride1, stride2;
+    const double* metric_w;
+    const double* scale;
+    double inv_scale_coef, inv_eps;
+    int32_t* status;
+    int metric;
+    int num_batches;
+    unsigned tiles;
+    int stagger;                                      // first round: CU j of every XCD starts j x 0.6 us late (tables beyond the L2s)
+};
+
+// siegel_packed.hip: the persistent DENSE forward of the upper model, dims 7, 8 (dense_forward_kernel): fills tile_end / tiles /
+// stagger from the batches already set in `a` (idx1 / idx2 / out / b for num_batches entries) and launches
+int launch_dense_persistent(PackedArgs& a, int n, hipStream_t s);
+
 // Registry of kernel instantiations of the inline-asm DPP layouts (sixteen / eight lanes per pair or row) that a numerical
 // self-check found to disagree with the one-lane kernels (C-ABI sympa_set_instance_fallback; sympa_amd/selfcheck.py runs the
 // check on first use of every instantiation): the dispatchers route those to the one-lane kernels.  family = SYMPA_FAMILY_*.

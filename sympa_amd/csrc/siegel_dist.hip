@@ -99,6 +99,33 @@ int launch(const DistArgs& a, int n, int model, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if ((a.flags & SYMPA_FLAG_COOP) && (n == 7 || n == 8)) return launch_siegel_coop_half(a, n, model, s);   // A/B only: eight lanes per pair
     if ((a.flags & SYMPA_FLAG_COOP) && n == 6) return launch_siegel_coop(a, n, model, s);                 // A/B only: sixteen
+    if (n >= 7 && n <= 8 && model == SYMPA_MODEL_UPPER && a.ap_cols == 0 && a.vvd == nullptr && a.batch_counter == nullptr &&
+        !(a.flags & (SYMPA_FLAG_ANY_ORDER | SYMPA_FLAG_GENERIC))) {
+        // round 5: persistent waves, prefetched tile head, in-place difference (siegel_packed_kernel.hpp dense_forward_kernel);
+        // the one-launch kernel of siegel_dist_kernel.hpp remains for the vector-valued distance, the all-pairs mode and the
+        // bounded model (whose large calls go through the packed table)
+        if (a.idx1 == nullptr && a.base1 == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
+        PackedArgs p;
+        std::memset(&p, 0, sizeof(p));
+        p.pack = a.base1;
+        p.base2 = a.base2;
+        p.identity = a.idx1 == nullptr ? 1 : 0;
+        p.num_rows = a.num_rows;
+        p.idx1[0] = a.idx1;
+        p.idx2[0] = a.idx2;
+        p.out[0] = a.out;
+        p.b[0] = a.b;
+        p.stride1 = a.idx1_stride;
+        p.stride2 = a.idx2_stride;
+        p.metric_w = a.metric_w;
+        p.scale = a.scale;
+        p.inv_scale_coef = a.inv_scale_coef;
+        p.inv_eps = a.inv_eps;
+        p.status = a.status;
+        p.metric = a.metric;
+        p.num_batches = 1;
+        return launch_dense_persistent(p, n, s);
+    }
     switch (n) {
         case 1: return launch_n<1>(a, model, s);
         case 2: return launch_n<2>(a, model, s);
@@ -164,6 +191,29 @@ int launch_multi(const double* table, int64_t num_rows, int n, const int64_t* co
     for (int i = k; i < SYMPA_MAX_FUSED_BATCHES; ++i) m.blk_end[i] = (unsigned)blocks;   // the search never lands there
     m.num_batches = k;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n >= 7 && n <= 8 && model == SYMPA_MODEL_UPPER && !(flags & (SYMPA_FLAG_ANY_ORDER | SYMPA_FLAG_GENERIC))) {
+        PackedArgs p;                       // the list form of the persistent dense forward (see launch())
+        std::memset(&p, 0, sizeof(p));
+        p.pack = table;
+        p.base2 = table;
+        p.num_rows = num_rows;
+        for (int i = 0; i < k; ++i) {
+            p.idx1[i] = m.trip[i];
+            p.idx2[i] = m.trip[i] + 1;
+            p.out[i] = m.out[i];
+            p.b[i] = m.b[i];
+        }
+        p.stride1 = stride;
+        p.stride2 = stride;
+        p.metric_w = metric_w;
+        p.scale = scale;
+        p.inv_scale_coef = 1.0 / scale_coef;
+        p.inv_eps = 1.0 / eps;
+        p.status = status;
+        p.metric = metric;
+        p.num_batches = k;
+        return launch_dense_persistent(p, n, s);
+    }
     switch (n) {
         case 1: return launch_multi_n<1>(m, (unsigned)blocks, model, s);
         case 2: return launch_multi_n<2>(m, (unsigned)blocks, model, s);

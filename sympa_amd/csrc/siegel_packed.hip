@@ -88,6 +88,36 @@ int launch_group(PackedArgs& a, int n, int model, const int64_t* const* idx1, co
 
 }  // namespace
 
+namespace sympa_hip {
+
+int launch_dense_persistent(PackedArgs& a, int n, hipStream_t s) {
+    uint64_t tiles = 0;
+    for (int i = 0; i < a.num_batches; ++i) {
+        tiles += (uint64_t)((a.b[i] + 63) / 64);
+        if (tiles > 0x7fffffffull) return fail(SYMPA_ERR_BAD_ARG, "batches too large for one launch");
+        a.tile_end[i] = (unsigned)tiles;
+    }
+    if (tiles == 0) return 0;
+    for (int i = a.num_batches; i < SYMPA_MAX_FUSED_BATCHES; ++i) {
+        a.tile_end[i] = (unsigned)tiles;
+        a.b[i] = 1;
+        a.idx1[i] = a.idx1[0];
+        a.idx2[i] = a.idx2[0];
+        a.out[i] = a.out[0];
+    }
+    a.tiles = (unsigned)tiles;
+    const unsigned cus = (unsigned)cu_count();
+    a.stagger = (n >= 7 && !a.identity && a.tiles >= 8 * cus && a.num_rows * (int64_t)(16 * n * n) >= ((int64_t)12 << 20)) ? 1 : 0;
+    switch (n) {
+        case 7: return launch_dense_forward<7>(a, cus, s);
+        case 8: return launch_dense_forward<8>(a, cus, s);
+        default: break;
+    }
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "persistent dense forward: dims 7, 8");
+}
+
+}  // namespace sympa_hip
+
 extern "C" {
 
 int64_t sympa_table_pack_bytes(int64_t num_rows, int n, int model) {
@@ -129,6 +159,7 @@ int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num
     PackedArgs a;
     std::memset(&a, 0, sizeof(a));
     a.pack = reinterpret_cast<const double*>(pack);
+    a.base2 = a.pack;
     a.num_rows = num_rows;
     a.stride1 = src_stride;
     a.stride2 = dst_stride;
@@ -155,6 +186,7 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
     PackedArgs a;
     std::memset(&a, 0, sizeof(a));
     a.pack = reinterpret_cast<const double*>(pack);
+    a.base2 = a.pack;
     a.num_rows = num_rows;
     a.stride1 = stride;
     a.stride2 = stride;

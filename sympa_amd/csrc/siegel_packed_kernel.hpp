@@ -87,24 +87,6 @@ __global__ __launch_bounds__(64) void table_pack_kernel(const double* __restrict
 }
 
 // ---- (2) pairs ----------------------------------------------------------------------------------------------------------------
-struct PackedArgs {
-    const double* pack;
-    int64_t num_rows;
-    const int64_t* idx1[SYMPA_MAX_FUSED_BATCHES];     // src ids of batch k, element i at idx1[k][i * stride1]
-    const int64_t* idx2[SYMPA_MAX_FUSED_BATCHES];
-    double* out[SYMPA_MAX_FUSED_BATCHES];
-    int64_t b[SYMPA_MAX_FUSED_BATCHES];
-    unsigned tile_end[SYMPA_MAX_FUSED_BATCHES];       // exclusive prefix end of batch k, in tiles of 64 pairs
-    int64_t stride1, stride2;
-    const double* metric_w;
-    const double* scale;
-    double inv_scale_coef, inv_eps;
-    int32_t* status;
-    int metric;
-    int num_batches;
-    unsigned tiles;
-    int stagger;                                      // first round: CU j of every XCD starts j x 0.6 us late (tables beyond the L2s)
-};
 
 // batch of tile t: binary search over <= 32 prefix ends (wave-uniform, scalar)
 __device__ __forceinline__ int packed_batch_of(const PackedArgs& a, const unsigned t) {
@@ -126,6 +108,11 @@ __device__ __forceinline__ void packed_ids_load(const PackedArgs& a, const unsig
     const unsigned t0 = (k == 0) ? 0u : a.tile_end[k - 1];
     const int64_t i = (int64_t)(t - t0) * 64 + (threadIdx.x & 63);
     const int64_t ii = i < a.b[k] ? i : a.b[k] - 1;
+    if (a.identity) {
+        x1 = ii;
+        x2 = ii;
+        return;
+    }
     x1 = __builtin_nontemporal_load(a.idx1[k] + ii * a.stride1);
     x2 = __builtin_nontemporal_load(a.idx2[k] + ii * a.stride2);
 }
@@ -141,22 +128,29 @@ __device__ __forceinline__ void packed_ids_check(const PackedArgs& a, int64_t x1
     r2 = (int)x2;
 }
 
+// One pass of the ring: sixteen rows of K 16-byte chunks each (row stride ROW_DOUBLES doubles), one LDS-DMA instruction per row (two
+// when K > 64), row j of the pass at buf + j * PITCH.  The row index comes from v_readlane: a scalar base address.
+template <int K, int ROW_DOUBLES, int PITCH>
+__device__ __forceinline__ void ring_pass_issue(const double* __restrict__ base, const int row, const int pass, v2d* __restrict__ buf) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int rr = __builtin_amdgcn_readlane(row, 16 * pass + j);
+        const double* src = base + (int64_t)rr * ROW_DOUBLES + 2 * lane;
+        if (K >= 64 || lane < K)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PITCH), 16, 0, 0);
+        if constexpr (K > 64) {
+            if (lane < K - 64)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 128), (lds_ptr_t)(buf + j * PITCH + 64), 16, 0, 0);
+        }
+    }
+}
+
 template <int N, int MODEL>
 __device__ __forceinline__ void packed_pass_issue(const double* __restrict__ base, const int row, const int pass,
                                                   v2d* __restrict__ buf) {
     using R = PackRow<N, MODEL>;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int j = 0; j < R::ROWS; ++j) {
-        const int rr = __builtin_amdgcn_readlane(row, 16 * pass + j);      // scalar row index, scalar base address
-        const double* src = base + (int64_t)rr * R::ROW_DOUBLES + 2 * lane;
-        if (R::K >= 64 || lane < R::K)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * R::PITCH), 16, 0, 0);
-        if constexpr (R::K > 64) {
-            if (lane < R::K - 64)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 128), (lds_ptr_t)(buf + j * R::PITCH + 64), 16, 0, 0);
-        }
-    }
+    ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(base, row, pass, buf);
 }
 
 // The rows of a pass back into registers (the sixteen lanes of the pass only).  SECOND = false: the row of the pair's SECOND point
@@ -306,6 +300,184 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
     }
 }
 
+// ---- the same structure over the reference's DENSE rows, upper model (round 5): persistent waves, prefetched tile head, the
+// first point's Re triangle subtracted from the second's in place -- what sympa_model_forward / sympa_siegel_dist_fwd run at dims
+// 7, 8 when no packed table is at hand (a table that changes before every call, training's forward, pre-gathered points).  Same
+// arithmetic as siegel_dist_kernel (Cholesky of both imaginary parts, two triangular solves, distance_from_h), same values.
+// Measured against it (profiles/r05_dense_persistent_ab.txt, 262 144 pairs of 45 500 rows): n = 8 144.9 -> 135.0 us, n = 7 118.1 ->
+// 110.3; n = 6 84.4 -> 88.6 and n = 5 57.4 -> 58.3 (their one-launch kernels already hold two waves per SIMD): dims 7, 8 only.
+template <int N>
+struct DenseRow {
+    static constexpr int K = N * N;                           // 16-byte chunks per [2, N, N] row
+    static constexpr int ROW_DOUBLES = 2 * N * N;
+    static constexpr int PITCH = (K % 2 == 1) ? K : K + 1;
+    static constexpr int BUF_SLOTS = 16 * PITCH;
+    static constexpr int WAVE_SLOTS = 2 * BUF_SLOTS;
+    static constexpr int TRI = N * (N + 1) / 2;
+    // element `half` of chunk c: plane, (i, j); kept when i <= j
+    static constexpr bool keep(int c, int half) {
+        const int f = 2 * c + half, g = f % (N * N);
+        return (g / N) <= (g % N);
+    }
+    static constexpr bool chunk_needed(int c) { return keep(c, 0) || keep(c, 1); }
+    static constexpr int plane(int c, int half) { return (2 * c + half) / (N * N); }
+    static constexpr int tri_of(int c, int half) {
+        const int g = (2 * c + half) % (N * N);
+        return sympa::tri_index(N, g / N, g % N);
+    }
+};
+
+// SECOND = false: the pair's second point: Re triangle -> xr, Im triangle -> y2.  SECOND = true, the first point: xr -= its Re
+// triangle (D = Z2 - Z1, real part), its Im triangle -> y1.  Chunks that hold no upper-triangle element are not read.
+template <int N, bool SECOND>
+__device__ __forceinline__ void dense_pass_read(const v2d* __restrict__ buf, const int pass, double (&xr)[DenseRow<N>::TRI],
+                                                double (&ya)[DenseRow<N>::TRI]) {
+    using R = DenseRow<N>;
+    const int lane = threadIdx.x & 63;
+    if ((lane >> 4) == pass) {
+        const v2d* mine = buf + (lane & 15) * R::PITCH;
+        constexpr int G = 12;
+#pragma unroll
+        for (int c0 = 0; c0 < R::K; c0 += G) {
+            v2d q[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (c0 + g < R::K && R::chunk_needed(c0 + g)) q[g] = mine[c0 + g];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int c = c0 + g;
+                if (c < R::K && R::chunk_needed(c)) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (R::keep(c, h)) {
+                            const double v = h ? q[g].y : q[g].x;
+                            if (R::plane(c, h) == 0) {
+                                if (SECOND) xr[R::tri_of(c, h)] -= v; else xr[R::tri_of(c, h)] = v;
+                            } else {
+                                ya[R::tri_of(c, h)] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(64, 1) void dense_forward_kernel(const PackedArgs a) {
+    using R = DenseRow<N>;
+    constexpr int TRI = R::TRI;
+    __shared__ v2d tile[R::WAVE_SLOTS];
+    v2d* buf0 = tile;
+    v2d* buf1 = tile + R::BUF_SLOTS;
+    if (a.stagger && blockIdx.x < 1024u) {
+        const int k = (int)((blockIdx.x >> 5) & 31u);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
+    }
+    unsigned t = blockIdx.x;
+    if (t >= a.tiles) return;
+    int r1, r2, st;
+    int64_t x1, x2;
+    packed_ids_load(a, t, x1, x2);
+    packed_ids_check(a, x1, x2, r1, r2, st);
+    ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(a.base2, r2, 0, buf0);      // passes 0..3: the second point, 4..7: the first
+    ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(a.base2, r2, 1, buf1);
+    unsigned tn = t + gridDim.x;
+    bool more = tn < a.tiles;
+    x1 = 0;
+    x2 = 0;
+    if (more) packed_ids_load(a, tn, x1, x2);
+    for (;;) {
+        __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0): passes 0, 1, the next ids, the previous tile's store
+        double dre[TRI], y2[TRI], y1[TRI];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) { dre[k] = 0.0; y2[k] = 0.0; y1[k] = 0.0; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s > 0) {
+                if (s + 1 < 8) wait_vmcnt<16>();
+                else wait_vmcnt<0>();
+            }
+            wave_lds_fence();
+            const v2d* cur = (s & 1) ? buf1 : buf0;
+            if (s < 4) dense_pass_read<N, false>(cur, s, dre, y2);
+            else dense_pass_read<N, true>(cur, s - 4, dre, y1);
+            if (s + 2 < 8) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                wave_lds_fence();
+                v2d* nxt = (s & 1) ? buf1 : buf0;
+                if (s + 2 < 4) ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(a.base2, r2, s + 2, nxt);
+                else ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(a.pack, r1, s + 2 - 4, nxt);
+            }
+        }
+        const unsigned tnn = tn + gridDim.x;
+        const bool more2 = more && tnn < a.tiles;
+        int n1 = 0, n2 = 0, nst = 0;
+        if (more) packed_ids_check(a, x1, x2, n1, n2, nst);
+        if (more) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            wave_lds_fence();
+            ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(a.base2, n2, 0, buf0);
+            ring_pass_issue<R::K, R::ROW_DOUBLES, R::PITCH>(a.base2, n2, 1, buf1);
+        }
+        if (more2) packed_ids_load(a, tnn, x1, x2);
+        // ---- arithmetic of tile t: as pair_distance_mats<N, MODEL_UPPER>
+        sympa::Herm<N> h;
+        bool ok;
+        {
+            sympa::CMat<N> e;
+            {
+                double ym[N][N];
+                sympa::Tri<N, false> l1, l2;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = i; j < N; ++j) ym[i][j] = y1[sympa::tri_index(N, i, j)];
+                ok = sympa::chol_real<N>(ym, l1);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = i; j < N; ++j) ym[i][j] = y2[sympa::tri_index(N, i, j)];
+                ok = sympa::chol_real<N>(ym, l2) && ok;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = i; j < N; ++j) {
+                        const double xr = dre[sympa::tri_index(N, i, j)];
+                        const double xi = y2[sympa::tri_index(N, i, j)] - y1[sympa::tri_index(N, i, j)];
+                        e.re[i][j] = xr; e.re[j][i] = xr;
+                        e.im[i][j] = xi; e.im[j][i] = xi;
+                    }
+                sympa::solve_left<N, false>(l1, e);
+                sympa::solve_right_t<N, false>(l2, e);
+            }
+            sympa::gram<N>(e, h);
+        }
+        int flags = st;
+        if (st & sympa::ST_BAD_INDEX) h.d[0] = __builtin_nan("");
+        const int kb = packed_batch_of(a, t);
+        const unsigned t0 = (kb == 0) ? 0u : a.tile_end[kb - 1];
+        const int64_t i = (int64_t)(t - t0) * 64 + (threadIdx.x & 63);
+        const bool live = i < a.b[kb];
+        double d = sympa::distance_from_h<N, sympa::MODEL_UPPER>(h, ok, a.metric, a.metric_w, a.inv_eps, nullptr, flags);
+        if (flags & sympa::ST_BAD_INDEX) d = __builtin_nan("");
+        if (a.scale != nullptr) d *= fmax(a.scale[0] * a.inv_scale_coef, 0.1);   // model.py:40-41
+        if (live) __builtin_nontemporal_store(d, a.out[kb] + i);
+        if (a.status != nullptr) {
+            const int flagged = (live && flags != 0) ? 1 : 0;
+            const unsigned long long m = __ballot(flagged);
+            if (m != 0ull) {
+                if (flagged) atomicOr(&a.status[0], flags);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&a.status[1], (int)__popcll(m));
+            }
+        }
+        if (!more) break;
+        t = tn; r1 = n1; r2 = n2; st = nst;
+        tn = tnn; more = more2;
+    }
+}
+
 template <int N, int MODEL>
 int launch_table_pack(const double* table, int64_t num_rows, double* pack, int32_t* status, hipStream_t s) {
     hipLaunchKernelGGL((table_pack_kernel<N, MODEL>), dim3((unsigned)((num_rows + 63) / 64)), dim3(64), 0, s, table, num_rows, pack,
@@ -326,6 +498,14 @@ template <int N, int MODEL>
 int launch_packed_forward(const PackedArgs& a, unsigned cus, hipStream_t s) {
     const unsigned res = resident_blocks(packed_forward_kernel<N, MODEL>, cus);
     hipLaunchKernelGGL((packed_forward_kernel<N, MODEL>), dim3(a.tiles < res ? a.tiles : res), dim3(64), 0, s, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+template <int N>
+int launch_dense_forward(const PackedArgs& a, unsigned cus, hipStream_t s) {
+    const unsigned res = resident_blocks(dense_forward_kernel<N>, cus);
+    hipLaunchKernelGGL((dense_forward_kernel<N>), dim3(a.tiles < res ? a.tiles : res), dim3(64), 0, s, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
