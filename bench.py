@@ -74,6 +74,8 @@ def kernel_name(model, n, low_lds, packed=False):
         return f"spd16_coop_kernel<{n}, {'true' if packed else 'false'}>" if n >= 6 else "spd_dist_kernel"
     if n > 8:
         return f"siegel_coop_kernel (n={n})"
+    if model == "upper" and n in (7, 8):         # the persistent dense forward (csrc/siegel_packed_kernel.hpp)
+        return f"dense_forward_kernel<{n}>"
     low = bool(low_lds) and n in (2, 4)          # DmaTile<N>::ENABLED (csrc/siegel_gather.hpp)
     return f"siegel_dist_kernel<{n}, {MODEL_ID[model]}, {'true' if low else 'false'}>"
 
