@@ -63,7 +63,8 @@ def _worker(rank, world, port, results):
                 merged_s[r::world] = outs_s[r]
             results["strong_equal"] = bool(torch.equal(merged_s, full_s)) and mine_s.shape[0] * world == batch
             flat = sorted(i for s in all_shards for i in s)
-            results["sampler_cover"] = sorted(set(flat)) == list(range(1001)) and len(flat) == 1002
+            per = -(-1001 // world)                    # DistributedSampler pads the list to a multiple of the world size
+            results["sampler_cover"] = sorted(set(flat)) == list(range(1001)) and len(flat) == per * world
             results["sampler_sizes"] = [len(s) for s in all_shards]
     finally:
         dist.destroy_process_group()
@@ -77,6 +78,18 @@ def test_two_rank_sharding_over_gloo():
     assert results["union_equal"] and results["dist_equal"] and results["strong_equal"]
     assert results["max"] == 2.0
     assert results["sampler_cover"] and results["sampler_sizes"] == [501, 501]
+
+
+def test_eight_rank_sharding_over_gloo():
+    """World size 8 (round-4 review: rank::8 had never run): the interleave, the strong-scaling shards of 256 / 8 pairs and the
+    sampler's padding of 1 001 triplets to 8 x 126."""
+    world = 8
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    assert results["union_equal"] and results["dist_equal"] and results["strong_equal"]
+    assert results["max"] == 8.0
+    assert results["sampler_cover"] and results["sampler_sizes"] == [126] * 8
 
 
 def _grad_worker(rank, world, port, results):
@@ -222,6 +235,17 @@ def test_bench_gpus_n_launches_its_own_ranks_and_relays_one_json_line():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["steps"] == 20 and rec["warmup"] == 5
     assert rec["max_over_ranks"] == 2.0
+
+
+def test_bench_gpus_8_launches_eight_ranks():
+    """The 8-GPU command of the driver's scaling run, with the gloo stub as rank body: eight ranks, one JSON line."""
+    import json
+    p = _run_bench_self_launch({}, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == 8 and rec["max_over_ranks"] == 8.0
 
 
 def test_bench_self_launch_propagates_a_failing_rank():
