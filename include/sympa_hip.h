@@ -179,26 +179,17 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
  * instead of triangular solves).
  * sympa_model_forward_batches_packed: the list form (sympa_model_forward_batches); up to SYMPA_MAX_FUSED_BATCHES consecutive batches
  * share a launch; one stream. */
- /* workspace (both forward entries below; caller-owned device scratch, 16-byte aligned, may be NULL): with at least
- * sympa_model_forward_packed_workspace_bytes(b, n, model) bytes the upper model at dims 7, 8 runs as TWO kernels with two waves per
- * SIMD each (csrc/siegel_packed_split.hpp): a front kernel with two LANES per pair -- the real factors of the upper model never
- * mix the planes of E = A1 (Z2 - Z1) A2^T, so lane 2p forms Re E and lane 2p + 1 Im E of pair p, 64 doubles each; H = E^H E with
- * two exchanges through DPP moves -- writes H (n^2 doubles per pair) to the workspace, the eigen kernel (one pair per lane, 170
- * registers) reads it back.  Returns 0 where no kernel uses one; NULL / too small: the one-kernel form.  The list entry groups
- * consecutive batches as far as their tiles fit the workspace (at least one batch must fit, else the one-kernel form runs). */
 int64_t sympa_table_pack_bytes(int64_t num_rows, int n, int model);
-int64_t sympa_model_forward_packed_workspace_bytes(int64_t b, int n, int model);
 int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes, int32_t* status,
                      void* stream);
 int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
                                int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                                const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
-                               int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream);
+                               int32_t* status, int flags, void* stream);
 int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n,
                                        const int64_t* const* triplets, int64_t stride, const int64_t* b, int num_batches,
                                        int model, int metric, const double* metric_w, double eps, const double* scale,
-                                       double scale_coef, double* const* out, int32_t* status, void* workspace,
-                                       int64_t workspace_bytes, int flags, void* stream);
+                                       double scale_coef, double* const* out, int32_t* status, int flags, void* stream);
 
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
  * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):

@@ -25,7 +25,6 @@ SYMBOLS = (
     "sympa_table_pack_bytes",
     "sympa_table_pack",
     "sympa_model_forward_packed",
-    "sympa_model_forward_packed_workspace_bytes",
     "sympa_model_forward_batches_packed",
     "sympa_all_pairs_dist",
     "sympa_all_pairs_workspace_bytes",
@@ -276,13 +275,11 @@ def load():
     lib.sympa_model_forward_packed.restype = C.c_int
     lib.sympa_model_forward_packed.argtypes = [
         C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_i64_p, C.c_int64, _c_i64_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
-        _c_double_p, C.c_double, _c_double_p, C.c_double, _c_double_p, _c_i32_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-    lib.sympa_model_forward_packed_workspace_bytes.restype = C.c_int64
-    lib.sympa_model_forward_packed_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
+        _c_double_p, C.c_double, _c_double_p, C.c_double, _c_double_p, _c_i32_p, C.c_int, C.c_void_p]
     lib.sympa_model_forward_batches_packed.restype = C.c_int
     lib.sympa_model_forward_batches_packed.argtypes = [
         C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
-        _c_double_p, C.c_double, _c_double_p, C.c_double, C.c_void_p, _c_i32_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        _c_double_p, C.c_double, _c_double_p, C.c_double, C.c_void_p, _c_i32_p, C.c_int, C.c_void_p]
     lib.sympa_spd_table_pack_bytes.restype = C.c_int64
     lib.sympa_spd_table_pack_bytes.argtypes = [C.c_int64, C.c_int]
     lib.sympa_spd_table_pack.restype = C.c_int

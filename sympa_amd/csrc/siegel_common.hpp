@@ -90,7 +90,6 @@ struct PackedArgs {
     int64_t b[SYMPA_MAX_FUSED_BATCHES];
     unsigned tile_end[SYMPA_MAX_FUSED_BATCHES];       // exclusive prefix end of batch k, in tiles of 64 pairs
     int64_t stride1, stride2;
-    double* ws;                                       // split form (siegel_packed_split.hpp): [tiles][n^2 + 1][64] fp64, else NULL
     const double* metric_w;
     const double* scale;
     double inv_scale_coef, inv_eps;
@@ -104,9 +103,6 @@ struct PackedArgs {
 // siegel_packed.hip: the persistent DENSE forward of the upper model, dims 7, 8 (dense_forward_kernel): fills tile_end / tiles /
 // stagger from the batches already set in `a` (idx1 / idx2 / out / b for num_batches entries) and launches
 int launch_dense_persistent(PackedArgs& a, int n, hipStream_t s);
-// siegel_packed_split.hip: the two-kernel packed forward (two lanes per pair in the front kernel), upper model, dims 7, 8
-int64_t packed_split_workspace_bytes(int64_t b, int n, int model);
-int launch_packed_split_n(const PackedArgs& a, int n, hipStream_t s);
 
 // Registry of kernel instantiations of the inline-asm DPP layouts (sixteen / eight lanes per pair or row) that a numerical
 // self-check found to disagree with the one-lane kernels (C-ABI sympa_set_instance_fallback; sympa_amd/selfcheck.py runs the

@@ -49,7 +49,7 @@ int check_common(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, 
 
 // one launch over the batches [i0, i0 + cnt) (cnt <= SYMPA_MAX_FUSED_BATCHES)
 int launch_group(PackedArgs& a, int n, int model, const int64_t* const* idx1, const int64_t* const* idx2, const int64_t* b,
-                 double* const* out, int cnt, hipStream_t s, const bool split = false) {
+                 double* const* out, int cnt, hipStream_t s) {
     uint64_t tiles = 0;
     int k = 0;
     for (int i = 0; i < cnt; ++i) {
@@ -76,7 +76,6 @@ int launch_group(PackedArgs& a, int n, int model, const int64_t* const* idx1, co
     // staggered first round (siegel_dist_kernel.hpp): dims 7, 8, upper model, tables beyond the L2s, two rounds or more
     a.stagger = (n >= 7 && model == SYMPA_MODEL_UPPER && a.tiles >= 8 * grid &&
                  a.num_rows * (int64_t)pack_row_doubles(n, model) * 8 >= ((int64_t)12 << 20)) ? 1 : 0;
-    if (split) return launch_packed_split_n(a, n, s);          // a.ws set by the caller: the two-kernel form
     switch (n) {
         case 5: return forward_n<5>(a, grid, model, s);
         case 6: return forward_n<6>(a, grid, model, s);
@@ -149,7 +148,7 @@ int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, vo
 int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
                                int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                                const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
-                               int32_t* status, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
+                               int32_t* status, int flags, void* stream) {
     (void)flags;
     if (b < 0) return fail(SYMPA_ERR_BAD_ARG, "negative batch size");
     if (b == 0) return 0;
@@ -170,19 +169,13 @@ int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num
     a.inv_eps = 1.0 / eps;
     a.status = status;
     a.metric = metric;
-    const int64_t need = packed_split_workspace_bytes(b, n, model);
-    const bool split = workspace != nullptr && need > 0 && workspace_bytes >= need && !(reinterpret_cast<uintptr_t>(workspace) & 15);
-    a.ws = split ? reinterpret_cast<double*>(workspace) : nullptr;
-    return launch_group(a, n, model, &src, &dst, &b, &out, 1, reinterpret_cast<hipStream_t>(stream), split);
+    return launch_group(a, n, model, &src, &dst, &b, &out, 1, reinterpret_cast<hipStream_t>(stream));
 }
-
-int64_t sympa_model_forward_packed_workspace_bytes(int64_t b, int n, int model) { return packed_split_workspace_bytes(b, n, model); }
 
 int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n,
                                        const int64_t* const* triplets, int64_t stride, const int64_t* b, int num_batches,
                                        int model, int metric, const double* metric_w, double eps, const double* scale,
-                                       double scale_coef, double* const* out, int32_t* status, void* workspace,
-                                       int64_t workspace_bytes, int flags, void* stream) {
+                                       double scale_coef, double* const* out, int32_t* status, int flags, void* stream) {
     (void)flags;
     if (num_batches < 0) return fail(SYMPA_ERR_BAD_ARG, "bad batch list");
     if (num_batches == 0) return 0;
@@ -204,14 +197,7 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
     a.status = status;
     a.metric = metric;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // groups of up to SYMPA_MAX_FUSED_BATCHES consecutive batches per launch; with a workspace (upper, dims 7, 8): per launch PAIR,
-    // as far as the tiles of a group fit it -- launches of one stream run in order, so the next group's front kernel reuses the
-    // workspace after this group's eigen kernel
-    const int64_t tile_bytes = (int64_t)(n * n + 1) * 64 * 8;
-    const bool can_split = workspace != nullptr && packed_split_workspace_bytes(64, n, model) > 0 &&
-                           !(reinterpret_cast<uintptr_t>(workspace) & 15);
-    const int64_t ws_tiles = can_split ? workspace_bytes / tile_bytes : 0;
-    a.ws = reinterpret_cast<double*>(workspace);
+    // groups of up to SYMPA_MAX_FUSED_BATCHES consecutive batches per launch
     const int64_t* idx1[SYMPA_MAX_FUSED_BATCHES];
     const int64_t* idx2[SYMPA_MAX_FUSED_BATCHES];
     int i0 = 0;
@@ -224,15 +210,13 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
             if (bi > 0 && (triplets[i0 + cnt] == nullptr || out[i0 + cnt] == nullptr)) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
             const int64_t t = (bi + 63) / 64;
             if (tiles + t > (int64_t)0x7fffffff) break;
-            if (ws_tiles > 0 && t <= ws_tiles && tiles + t > ws_tiles) break;        // this group's workspace is full
             tiles += t;
             idx1[cnt] = triplets[i0 + cnt];
             idx2[cnt] = triplets[i0 + cnt] + 1;
             ++cnt;
         }
         if (cnt == 0) return fail(SYMPA_ERR_BAD_ARG, "batch too large for one launch");
-        const bool split = ws_tiles > 0 && tiles <= ws_tiles && tiles > 0;          // (a batch larger than the workspace: one kernel)
-        const int rc2 = launch_group(a, n, model, idx1, idx2, b + i0, out + i0, cnt, s, split);
+        const int rc2 = launch_group(a, n, model, idx1, idx2, b + i0, out + i0, cnt, s);
         if (rc2 != 0) return rc2;
         i0 += cnt;
     }

@@ -323,10 +323,6 @@ def table_changed(param):
     torch.autograd.graph.increment_version(param)
 
 
-PACKED_SPLIT_MIN_PAIRS = int(os.environ.get("SYMPA_PACKED_SPLIT_MIN", "16384"))
-PACKED_SPLIT_LIST_PAIRS = int(os.environ.get("SYMPA_PACKED_SPLIT_LIST", "262144"))      # workspace cap of the list form, in pairs
-
-
 class PackedTable:
     """The packed image of a Siegel table for the INDEXED forward, dims 5..8 (C-ABI sympa_table_pack): one contiguous row per point
     -- the upper triangles of both planes and the inverted Cholesky factor -- made ONCE per table version and reused by every
@@ -351,20 +347,6 @@ class PackedTable:
     def invalidate(self):
         self.key = None
         self._seen = None
-
-    def split_workspace(self, b):
-        """The scratch of the two-kernel packed forward (C-ABI sympa_model_forward_packed_workspace_bytes; upper model, dims 7, 8:
-        (n^2 + 1) * 8 bytes per pair), grow-only and owned by the pack: every launch pair on one stream reuses it.  None where no
-        kernel uses one, below PACKED_SPLIT_MIN_PAIRS (two launches cost more than they save) and under SYMPA_NO_PACKED_SPLIT=1."""
-        if self.model != "upper" or self.n < 7 or b < PACKED_SPLIT_MIN_PAIRS or os.environ.get("SYMPA_NO_PACKED_SPLIT"):
-            return None
-        need = int(_lib.load().sympa_model_forward_packed_workspace_bytes(int(b), self.n, MODEL_IDS[self.model]))
-        if need == 0:
-            return None
-        ws = getattr(self, "_ws", None)
-        if ws is None or ws.numel() < need or ws.device != self.pack.device:
-            ws = self._ws = torch.empty(need, dtype=torch.uint8, device=self.pack.device)
-        return ws
 
     @staticmethod
     def _key_of(table):
@@ -433,13 +415,11 @@ def model_forward_packed(packed, triplets, metric="riem", weights=None, scale=No
         sc = scale if (scale.device == dev and scale.dtype == torch.float64) else scale.detach().to(device=dev, dtype=torch.float64)
         sc_ptr = sc.data_ptr()
     tp = triplets.data_ptr()
-    ws = packed.split_workspace(b)
     with torch.cuda.device(dev):
         rc = lib.sympa_model_forward_packed(packed.pack.data_ptr(), packed.bytes, packed.num_rows, n, tp, stride, tp + 8, stride, b,
                                             mid, METRIC_IDS[metric], None if w is None else w.data_ptr(),
                                             1e-5 if eps is None else float(eps), sc_ptr, float(scale_coef), out.data_ptr(),
-                                            _status_buf(dev).data_ptr(), None if ws is None else ws.data_ptr(),
-                                            0 if ws is None else ws.numel(), 0, torch.cuda.current_stream(dev).cuda_stream)
+                                            _status_buf(dev).data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _lib.check(rc)
     if _debug:
@@ -470,7 +450,6 @@ class PackedBatchedForward:
         self.dev = table.device
         self.n = table.shape[2]
         self.k = len(batches)
-        self.total = sum(((t.shape[0] + 63) // 64) * 64 for t in batches)
         self.stride = stride or 2
         C = ctypes
         self.trip = (C.c_void_p * max(self.k, 1))(*[t.data_ptr() for t in batches])
@@ -494,16 +473,12 @@ class PackedBatchedForward:
             return
         pk = self.packed.ensure(self.table)
         C = ctypes
-        ws = getattr(self, "workspace", None)
-        if ws is None:
-            ws = pk.split_workspace(min(self.total, PACKED_SPLIT_LIST_PAIRS)) if self.total else None
         with torch.cuda.device(self.dev):
             rc = self.lib.sympa_model_forward_batches_packed(
                 pk.pack.data_ptr(), pk.bytes, pk.num_rows, self.n, C.addressof(self.trip), self.stride, C.addressof(self.b), self.k,
                 MODEL_IDS[pk.model], self.metric, None if self.w is None else self.w.data_ptr(), self.eps,
                 None if self.sc is None else self.sc.data_ptr(), self.scale_coef, C.addressof(self.out), self.status.data_ptr(),
-                None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), 0,
-                torch.cuda.current_stream(self.dev).cuda_stream)
+                0, torch.cuda.current_stream(self.dev).cuda_stream)
         if rc != 0:
             _lib.check(rc)
         if _debug:
