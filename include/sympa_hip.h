@@ -167,7 +167,8 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
  * (upper) / I - W W^H = C C^H (bounded) -- and writes one contiguous row per point: the upper triangles of both planes and the
  * INVERTED factor (row stride sympa_table_pack_bytes(1, n, model) bytes: 864 at n = 8 upper, where the reference row is 1 024).
  * The pair kernels then need no Cholesky and no solve: E = A1 (Z2 - Z1) A2^T.  A point outside the manifold is reported through
- * `status` here (SYMPA_ST_NOT_PD) and flags every pair it enters later.
+ * `status` here (SYMPA_ST_NOT_PD; `status` may be NULL) and flags every pair it enters later.  (sympa_amd passes NULL: the
+ * reference's assertions sit in dist, siegel_manifold.py:64-66, so a point no batch touches raises nothing there.)
  *   pack   caller-owned device buffer, 16-byte aligned, sympa_table_pack_bytes(num_rows, n, model) bytes (0 = this build has no
  *          packed path for these dims / model: use sympa_model_forward); valid until the table changes (the caller keeps the
  *          version: sympa_amd/model.py repacks when the ManifoldParameter's version counter has moved).

@@ -277,7 +277,6 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
             sympa::gram<N>(e, h);
         }
         int flags = st | (ok ? 0 : sympa::ST_NOT_PD);
-        if (st & sympa::ST_BAD_INDEX) h.d[0] = __builtin_nan("");
         const int kb = packed_batch_of(a, t);
         const unsigned t0 = (kb == 0) ? 0u : a.tile_end[kb - 1];
         const int64_t i = (int64_t)(t - t0) * 64 + (threadIdx.x & 63);
@@ -455,7 +454,6 @@ __global__ __launch_bounds__(64, 1) void dense_forward_kernel(const PackedArgs a
             sympa::gram<N>(e, h);
         }
         int flags = st;
-        if (st & sympa::ST_BAD_INDEX) h.d[0] = __builtin_nan("");
         const int kb = packed_batch_of(a, t);
         const unsigned t0 = (kb == 0) ? 0u : a.tile_end[kb - 1];
         const int64_t i = (int64_t)(t - t0) * 64 + (threadIdx.x & 63);

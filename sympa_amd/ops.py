@@ -382,10 +382,12 @@ class PackedTable:
         need = int(lib.sympa_table_pack_bytes(num_rows, n, MODEL_IDS[self.model]))
         if self.pack is None or self.pack.numel() != need or self.pack.device != table.device:
             self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
-        status = _status_buf(table.device)
+        # no status word for the pack: a point outside the manifold is reported by the PAIRS it enters (its inverted diagonal is
+        # stored as NaN), like the reference, whose assertions sit in dist (siegel_manifold.py:64-66) -- a bad row no batch touches
+        # raises nothing there either
         with torch.cuda.device(table.device):
             rc = lib.sympa_table_pack(table.data_ptr(), num_rows, n, MODEL_IDS[self.model], self.pack.data_ptr(), need,
-                                      status.data_ptr(), torch.cuda.current_stream(table.device).cuda_stream)
+                                      None, torch.cuda.current_stream(table.device).cuda_stream)
         _lib.check(rc)
         self.key, self._src = key, st
         self.num_rows, self.n, self.bytes = num_rows, n, need
@@ -1205,7 +1207,7 @@ class SpdPackedTable(PackedTable):
             self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
         with torch.cuda.device(table.device):
             rc = lib.sympa_spd_table_pack(table.data_ptr(), num_rows, n, self.pack.data_ptr(), need,
-                                          _status_buf(table.device).data_ptr(), torch.cuda.current_stream(table.device).cuda_stream)
+                                          None, torch.cuda.current_stream(table.device).cuda_stream)     # (as PackedTable.ensure)
         _lib.check(rc)
         self.key, self._src = key, table.untyped_storage()
         self.num_rows, self.n, self.bytes = num_rows, n, need
