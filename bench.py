@@ -80,6 +80,14 @@ def kernel_name(model, n, low_lds, packed=False):
     return f"siegel_dist_kernel<{n}, {MODEL_ID[model]}, {'true' if low else 'false'}>"
 
 
+def packed_kernel_name(model, n):
+    """The kernel sympa_model_forward_packed / _batches_packed launch (csrc/siegel_packed.hip): upper model at dims 7, 8: two lanes per
+    pair in the front, two waves per SIMD (siegel_packed2_kernel.hpp); else one pair per lane (siegel_packed_kernel.hpp)."""
+    if model == "upper" and n in (7, 8):
+        return f"packed_forward2_kernel<{n}>"
+    return f"packed_forward_kernel<{n}, {MODEL_ID[model]}>"
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -645,8 +653,7 @@ def main():
         n_launches = (args.steps + spl - 1) // spl
         packed = spl == ops.MAX_FUSED_BATCHES and net.packed_table() is not None and my_pairs * args.steps >= 4096
         # dims 5..8: Model.forward_batches runs the list over the PACKED table (one pack per table version, ops.PackedTable)
-        timed_kernel = (f"packed_forward_kernel<{n}, {MODEL_ID[model]}>" if packed
-                        else f"siegel_dist_multi_kernel<{n}, {MODEL_ID[model]}>")
+        timed_kernel = (packed_kernel_name(model, n) if packed else f"siegel_dist_multi_kernel<{n}, {MODEL_ID[model]}>")
         # >= 8 event-bracketed groups (average and median), not one sample.  A group is enough back-to-back repetitions of
         # the timed region's launches (>= 64 launches) that the host-side cost of a call hides behind the kernels of the
         # previous one: the quotient is then the kernel's own duration, the figure rocprofv3 --kernel-trace reports
@@ -709,7 +716,7 @@ def main():
             t_live = time.perf_counter()
             counters = live_counters(child, timed_kernel.split(" (")[0])
             t_live = time.perf_counter() - t_live
-            persistent = timed_kernel.startswith("packed_forward_kernel")
+            persistent = timed_kernel.startswith("packed_forward")
             if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
                 if persistent:      # (the child's launches are the parent's as long as both run whole 32-step groups)
                     live = (2.0 * counters["FETCH_SIZE/dispatch"] + counters["WRITE_SIZE/dispatch"]) * 1024.0
@@ -720,7 +727,7 @@ def main():
         # work-items per pair of the timed kernel's grid: the spd kernel's grid is one work-item per pair (a wave serves its
         # 64 pairs four at a time, sixteen lanes each, over sixteen rounds); the Siegel dims 9..16 kernels launch sixteen
         lanes_per_pair = 16 if (model != "spd" and n > 8) else 1
-        if counters.get("SQ_WAVES") and timed_kernel.startswith("packed_forward_kernel"):
+        if counters.get("SQ_WAVES") and timed_kernel.startswith("packed_forward"):
             # persistent waves, each walking many tiles of 64 pairs: wave-instructions per PAIR from the per-dispatch totals,
             # expressed as "per wave of 64 pairs" like the other kernels
             valu_per_wave = counters["SQ_INSTS_VALU/dispatch"] / timed_pairs_per_launch * 64.0
