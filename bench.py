@@ -81,10 +81,7 @@ def kernel_name(model, n, low_lds, packed=False):
 
 
 def packed_kernel_name(model, n):
-    """The kernel sympa_model_forward_packed / _batches_packed launch (csrc/siegel_packed.hip): upper model at dims 7, 8: two lanes per
-    pair in the front, two waves per SIMD (siegel_packed2_kernel.hpp); else one pair per lane (siegel_packed_kernel.hpp)."""
-    if model == "upper" and n in (7, 8):
-        return f"packed_forward2_kernel<{n}>"
+    """The kernel sympa_model_forward_packed / _batches_packed launch (csrc/siegel_packed.hip, siegel_packed_kernel.hpp)."""
     return f"packed_forward_kernel<{n}, {MODEL_ID[model]}>"
 
 

@@ -103,8 +103,6 @@ struct PackedArgs {
 // siegel_packed.hip: the persistent DENSE forward of the upper model, dims 7, 8 (dense_forward_kernel): fills tile_end / tiles /
 // stagger from the batches already set in `a` (idx1 / idx2 / out / b for num_batches entries) and launches
 int launch_dense_persistent(PackedArgs& a, int n, hipStream_t s);
-// siegel_packed2.hip: the packed forward of the upper model at dims 7, 8 with two waves per SIMD (siegel_packed2_kernel.hpp)
-int launch_packed_forward2_n(const PackedArgs& a, int n, unsigned cus, hipStream_t s);
 
 // Registry of kernel instantiations of the inline-asm DPP layouts (sixteen / eight lanes per pair or row) that a numerical
 // self-check found to disagree with the one-lane kernels (C-ABI sympa_set_instance_fallback; sympa_amd/selfcheck.py runs the

@@ -76,10 +76,6 @@ int launch_group(PackedArgs& a, int n, int model, const int64_t* const* idx1, co
     // staggered first round (siegel_dist_kernel.hpp): dims 7, 8, upper model, tables beyond the L2s, two rounds or more
     a.stagger = (n >= 7 && model == SYMPA_MODEL_UPPER && a.tiles >= 8 * grid &&
                  a.num_rows * (int64_t)pack_row_doubles(n, model) * 8 >= ((int64_t)12 << 20)) ? 1 : 0;
-    // upper model, dims 7, 8: two lanes per pair in the front, two waves per SIMD (siegel_packed2_kernel.hpp)
-#ifndef SYMPA_PACKED_ONE_WAVE          // (tools/build_variant.sh: the one-pair-per-lane kernel for an A/B)
-    if (model == SYMPA_MODEL_UPPER && (n == 7 || n == 8)) return launch_packed_forward2_n(a, n, grid, s);
-#endif
     switch (n) {
         case 5: return forward_n<5>(a, grid, model, s);
         case 6: return forward_n<6>(a, grid, model, s);
