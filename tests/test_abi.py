@@ -129,4 +129,12 @@ def test_every_translation_unit_passed_the_dpp_hazard_scan():
     lines = {l.split()[0]: l.strip() for l in open(report) if l.strip() and not l.startswith("#")}
     units = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
     assert sorted(lines) == units
-    assert all(l.endswith("clean") for l in lines.values()), [l for l in lines.values() if not l.endswith("clean")]
+    dpp = {u: l.split(";")[0].strip() for u, l in lines.items()}
+    assert all(l.endswith("clean") for l in dpp.values()), [l for l in dpp.values() if not l.endswith("clean")]
+    # ... and (round 5, tools/dma_reload_check.py) no LDS-DMA instruction of any unit sits behind a scratch reload: such a reload
+    # is followed by s_waitcnt vmcnt(0) and serialises the gather, one round trip per row
+    import re
+    for u, l in lines.items():
+        m = re.search(r"(\d+) LDS-DMA instructions, (\d+) behind a scratch reload", l)
+        assert m, f"{u}: no LDS-DMA scan in the report (rebuild with __graft_entry__.build())"
+        assert int(m.group(2)) == 0, l
