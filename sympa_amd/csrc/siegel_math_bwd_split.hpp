@@ -19,9 +19,11 @@
 // [entry][pair]: every load and store of the workspace is a contiguous 512 bytes per wave.
 //
 // Difference from pair_backward: the eigenvalues that enter phi are the QL's (accurate to eps ||H||), not the Rayleigh
-// quotients ||E v_i||^2 -- E is gone when the vectors exist.  An eigenvalue below ~1e-12 lambda_max therefore loses
-// relative accuracy in phi_i ~ lambda_i^-1/2 (riem: phi_i ~ v_i dv_i / d stays 2 / d whatever lambda_i > 0 is); the dispatcher keeps
-// the lanes-per-pair kernel reachable (SYMPA_FLAG_GENERIC / no workspace) and the tests compare the two.
+// quotients ||E v_i||^2 -- E is gone when the vectors exist.  A small eigenvalue therefore carries the relative error
+// eps lambda_max / lambda_i into phi_i ~ lambda_i^-1/2 (fone / fmin / wsum; measured against the one-stage adjoint, profiles/
+// r05_split_graded_spectrum.txt: 5e-9 of the gradient at lambda_min / lambda_max = 1e-8, 7e-5 at 1e-12); riem and finf do not see it
+// (phi_i = 2 / (d (1 + lambda_i))): equal to rounding down to 1e-12.  The dispatcher keeps the one-stage kernels reachable
+// (SYMPA_FLAG_GENERIC / no workspace) and tests/test_backward_split.py pins both behaviours.
 #pragma once
 
 #include "siegel_math_bwd.hpp"
