@@ -236,3 +236,23 @@ def hostsim_tridiag_invit(d, e):
                                          P(z.ctypes.data), P(flag.ctypes.data))
     assert rc == 0
     return lam, z, flag
+
+
+def graded_pairs(b, n, grade, seed=5):
+    """Upper-model pairs whose E = L1^-1 (Z2 - Z1) L2^-T has singular values graded over 10^-grade (eigenvalues of H = E^H E over
+    10^-2 grade): Z2 = Z1 + (1 + 0.3 i) L1 Q diag(s) Q^T L1^T, s_k = 10^(-grade k / (n - 1)).  numpy [b, 2, n, n] each."""
+    g = torch.Generator().manual_seed(seed)
+    z1 = torch.zeros(b, 2, n, n, dtype=torch.float64)
+    z2 = torch.zeros_like(z1)
+    for i in range(b):
+        a = torch.randn(n, n, generator=g, dtype=torch.float64) * 0.3
+        y1 = torch.eye(n, dtype=torch.float64) + a @ a.T
+        x1 = torch.randn(n, n, generator=g, dtype=torch.float64)
+        x1 = 0.5 * (x1 + x1.T)
+        l1 = torch.linalg.cholesky(y1)
+        q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+        s = torch.tensor([10.0 ** (-grade * k / (n - 1)) for k in range(n)], dtype=torch.float64)
+        d = l1 @ (q * s) @ q.T @ l1.T
+        z1[i, 0], z1[i, 1] = x1, y1
+        z2[i, 0], z2[i, 1] = x1 + d, y1 + 0.3 * d
+    return z1.numpy(), z2.numpy()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN, METRICS, MODELS, T, hostsim_dist_bwd, hostsim_dist_bwd_split, points
+from tests.helpers import GOLDEN, METRICS, MODELS, T, graded_pairs, hostsim_dist_bwd, hostsim_dist_bwd_split, points
 
 TOL = 1e-8
 
@@ -71,26 +71,6 @@ def test_hostsim_split_backward_identical_points_and_nonfinite():
     bad[1, 0, 2, 3] = bad[1, 0, 3, 2] = np.nan
     out, g1, g2, _, st = hostsim_dist_bwd_split(bad, z.numpy(), np.ones(4), "upper", "riem")
     assert np.isnan(out[1]) and st != 0 and np.all(np.isfinite(out[[0, 2, 3]]))
-
-
-def graded_pairs(b, n, grade, seed=5):
-    """Upper-model pairs whose E = L1^-1 (Z2 - Z1) L2^-T has singular values graded over 10^-grade (eigenvalues of H = E^H E over
-    10^-2 grade): Z2 = Z1 + (1 + 0.3 i) L1 Q diag(s) Q^T L1^T, s_k = 10^(-grade k / (n - 1))."""
-    g = torch.Generator().manual_seed(seed)
-    z1 = torch.zeros(b, 2, n, n, dtype=torch.float64)
-    z2 = torch.zeros_like(z1)
-    for i in range(b):
-        a = torch.randn(n, n, generator=g, dtype=torch.float64) * 0.3
-        y1 = torch.eye(n, dtype=torch.float64) + a @ a.T
-        x1 = torch.randn(n, n, generator=g, dtype=torch.float64)
-        x1 = 0.5 * (x1 + x1.T)
-        l1 = torch.linalg.cholesky(y1)
-        q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
-        s = torch.tensor([10.0 ** (-grade * k / (n - 1)) for k in range(n)], dtype=torch.float64)
-        d = l1 @ (q * s) @ q.T @ l1.T
-        z1[i, 0], z1[i, 1] = x1, y1
-        z2[i, 0], z2[i, 1] = x1 + d, y1 + 0.3 * d
-    return z1.numpy(), z2.numpy()
 
 
 @pytest.mark.parametrize("n", [6, 8])

@@ -761,3 +761,27 @@ def test_thin_torch_binding_equals_the_ctypes_binding(dev):
     ops.model_forward(table, torch.tensor([[0, 500]], device=dev))
     with pytest.raises(IndexError):
         ops.check_status(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4, 8])
+def test_forward_on_graded_spectra_against_the_oracle(dev, n):
+    """tests/test_hostsim_parity.py::test_forward_on_graded_spectra_against_the_oracle through the HIP kernels (n = 8: the persistent
+    dense kernel and, over a packed table, the packed kernel)."""
+    from oracle import siegel_oracle as so
+    from sympa_amd import ops
+    from tests.helpers import graded_pairs
+    for grade, tol in ((2, 1e-13), (4, 1e-11), (6, 1e-9), (8, 1e-7)):
+        z1, z2 = graded_pairs(70, n, grade)
+        t1, t2 = torch.from_numpy(z1), torch.from_numpy(z2)
+        for metric in ("riem", "fone", "fmin"):
+            ref = so.manifold_dist("upper", t1, t2, metric, None, False)
+            got = ops.siegel_dist_forward(t1.to(dev), t2.to(dev), "upper", metric).cpu()
+            assert float((got - ref).abs().max() / ref.abs().max()) < tol, (n, grade, metric)
+            if n == 8:
+                table = torch.cat((t1, t2)).to(dev)
+                trip = torch.stack((torch.arange(70), torch.arange(70) + 70), 1).to(dev)
+                pk = ops.PackedTable("upper").ensure(table)
+                got = ops.model_forward_packed(pk, trip, metric).cpu()
+                assert float((got - ref).abs().max() / ref.abs().max()) < tol, (n, grade, metric, "packed")
+    ops.check_status(dev)

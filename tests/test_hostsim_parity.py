@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import siegel_oracle as so
-from tests.helpers import GOLDEN, METRICS, MODELS, T, hostsim_dist, points, rel_err
+from tests.helpers import GOLDEN, METRICS, MODELS, T, graded_pairs, hostsim_dist, points, rel_err
 
 TOL = 1e-9
 # 'far' (and the tail of 's1.0' at n=8) = the regime 1 - d in [1e-8, 1e-5] where the reference's own fp64 evaluation carries ~1e-7
@@ -158,3 +158,16 @@ def test_generic_arithmetic_against_reference_goldens(model, n):
             # d(x, x): exactly 0 here, ~1e-15 per component in the reference (up to 2(n-1) n of them under fmin)
             atol = 1e-10 if case == "same" else 1e-12
             assert rel_err(out, g[f"{case}__{metric}"], atol=atol) < tol, (model, n, case, metric)
+
+
+@pytest.mark.parametrize("n", [4, 6, 8])
+def test_forward_on_graded_spectra_against_the_oracle(n):
+    """Pairs whose sinh^2(v_i / 2) spread over 1e-4 .. 1e-16 (tests/helpers.py::graded_pairs): the kernels take the eigenvalues of
+    H = E^H E, the reference (and the oracle) the singular values of the Cayley image through a 2n x 2n symeig -- different routes to
+    the small v_i.  Measured 1e-15 at a spread of 1e-4, 1e-8 at 1e-16; the tolerance of the path is 1e-4."""
+    for grade, tol in ((2, 1e-13), (4, 1e-11), (6, 1e-9), (8, 1e-7)):
+        z1, z2 = graded_pairs(12, n, grade)
+        for metric in ("riem", "fone", "fmin", "finf"):
+            got, st = hostsim_dist(z1, z2, "upper", metric)[:2]
+            ref = so.manifold_dist("upper", torch.from_numpy(z1), torch.from_numpy(z2), metric, None, False).numpy()
+            assert np.abs(got - ref).max() / np.abs(ref).max() < tol, (n, grade, metric)
