@@ -105,6 +105,79 @@ SYMPA_UNROLL
     }
 }
 
+// The source-side rows of a wave with runs of equal source ids MERGED (SYMPA_FLAG_MERGE_SRC): the rows are staged as above, then
+// lane e walks the wave's pairs in order with entry e of the running sum and stores it into the slot of the pair that ENDS a run
+// (its id differs from the next pair's, or it is the wave's last live pair); the other slots of a run are not written.  Summation
+// in pair order: bitwise reproducible.  `id`: the pair's RAW source id (an out-of-range id is a run of its own unless repeated:
+// what the host's slot list computes from the same ids, ops.sorted_slots).
+template <int N>
+__device__ __forceinline__ void store_rows_merged(const sympa::CMat<N>& g, const int64_t id, double* __restrict__ out_wave,
+                                                  double* __restrict__ tile, const bool zero, const int live_pairs) {
+    constexpr int ROWD = ScatterTile<N>::ROWD, PITCH = ScatterTile<N>::PITCH;
+    static_assert(!ScatterTile<N>::BY_PLANE, "whole rows through the tile: n <= 6");
+    const int lane = threadIdx.x & 63;
+    wave_lds_fence();
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            tile[lane * PITCH + i * N + j] = zero ? 0.0 : g.re[i][j];
+            tile[lane * PITCH + N * N + i * N + j] = zero ? 0.0 : g.im[i][j];
+        }
+    wave_lds_fence();
+    const int lo = (int)(id & 0xffffffffll), hi = (int)(id >> 32);
+    const bool differs = __shfl_down(lo, 1) != lo || __shfl_down(hi, 1) != hi;
+    const bool ends = lane < live_pairs && (lane + 1 >= live_pairs || differs);
+    const unsigned long long end_mask = __ballot(ends);                  // wave-uniform
+    if constexpr (ROWD <= 32) {
+        // both halves of the wave at once: lanes 0..31 walk pairs 0..31, lanes 32..63 pairs 32..63 (entry e = lane & 31).  The run
+        // that crosses the middle: the lower half's unfinished sum is added IN FRONT of the upper half's first run, whose store waits
+        // until the loop is over.  Reads in groups of eight ahead of the sums (the LDS latency of a lone wave, 64 times over, was
+        // 2.7 us of a 21 us step at configs[0]).
+        const int h = lane >> 5, e = lane & 31;
+        const bool on = e < ROWD;
+        const unsigned half_mask = (unsigned)(end_mask >> (32 * h));      // per lane: my half's run ends
+        double acc = 0.0, first_sum = 0.0;
+        int first_pos = -1;
+#pragma unroll
+        for (int q0 = 0; q0 < 32; q0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = on ? tile[(32 * h + q0 + j) * PITCH + e] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j;
+                acc += v[j];
+                if ((half_mask >> q) & 1u) {
+                    if (h == 1 && first_pos < 0) {
+                        first_sum = acc;
+                        first_pos = 32 + q;
+                    } else if (on) {
+                        __builtin_nontemporal_store(acc, out_wave + (int64_t)(32 * h + q) * ROWD + e);
+                    }
+                    acc = 0.0;
+                }
+            }
+        }
+        const double carry = __shfl(acc, e);           // the lower half's unfinished run (0 when pair 31 ended one)
+        if (h == 1 && first_pos >= 0 && on) __builtin_nontemporal_store(carry + first_sum, out_wave + (int64_t)first_pos * ROWD + e);
+    } else {
+        for (int e0 = 0; e0 < ROWD; e0 += 64) {
+            const int e = e0 + lane;
+            const bool on = e < ROWD;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int p = 0; p < live_pairs; ++p) {
+                acc += on ? tile[p * PITCH + e] : 0.0;
+                if ((end_mask >> p) & 1ull) {                                 // scalar condition
+                    if (on) __builtin_nontemporal_store(acc, out_wave + (int64_t)p * ROWD + e);
+                    acc = 0.0;
+                }
+            }
+        }
+    }
+}
+
 // n >= 7: the scatter tile of a wave is 25-33 KB (one plane at a time), so a block is one wave and four blocks share
 // a CU; the adjoint's working
 // set (E, H, its eigenvectors, the adjoints of all of them) does not fit the register file and spills to scratch.
@@ -146,9 +219,11 @@ __global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, SCATTER>())) voi
 
     int st = 0;
     int64_t r1 = ii, r2 = ii;
+    int64_t raw1 = ii;                           // (the merged rows form compares the ids as given)
     if (f.idx1 != nullptr) {
         r1 = f.idx1[ii * f.idx1_stride];
         r2 = f.idx2[ii * f.idx2_stride];
+        raw1 = r1;
         if (r1 < 0 || r1 >= f.num_rows || r2 < 0 || r2 >= f.num_rows) {
             st |= sympa::ST_BAD_INDEX;
             r1 = 0;
@@ -222,7 +297,8 @@ SYMPA_UNROLL
         const int64_t wave_first = i - (threadIdx.x & 63);
         const int64_t left = f.b - wave_first;
         const int live_pairs = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
-        store_rows_coalesced<N>(g1, a.g1 + wave_first * ROW, dtile, bad, live_pairs);
+        if (f.flags & SYMPA_FLAG_MERGE_SRC) store_rows_merged<N>(g1, raw1, a.g1 + wave_first * ROW, dtile, bad, live_pairs);
+        else store_rows_coalesced<N>(g1, a.g1 + wave_first * ROW, dtile, bad, live_pairs);
         store_rows_coalesced<N>(g2, a.g2 + wave_first * ROW, dtile, bad, live_pairs);
     } else if (live) {
 SYMPA_UNROLL

@@ -98,6 +98,7 @@ FLAG_COOP = 32        # dims 6, 8: force the sixteen-lanes-per-pair kernel (A/B)
 FLAG_NO_SYMMETRY = 16  # all_pairs_dist(packed=True): evaluate (i, j) and (j, i) separately
 FLAG_SPLIT = 64        # backward, dims 5..8: the split (two-kernel) backward wherever it is built (default: upper model, dims 7, 8)
 FLAG_FUSE = 8         # BatchedForward: up to MAX_FUSED_BATCHES consecutive batches per kernel launch
+FLAG_MERGE_SRC = 128  # model_train_backward(grad_rows=...), dims <= 6: runs of equal source ids inside a wave leave as ONE row
 MAX_FUSED_BATCHES = 32
 
 
@@ -906,15 +907,24 @@ def model_train_backward(table, triplets, graph_dist, batch, loss, model="upper"
     return loss
 
 
-def sorted_slots(row_index_lists, num_rows):
+def sorted_slots(row_index_lists, num_rows, merged_src=0):
     """The lists the deterministic gradient accumulation adds in (segment_sum_rows_): for every batch s, the slots
     0 .. 2b-1 of its per-pair gradient rows (slot k < b: row src[k]; slot b + k: row dst[k]) sorted by table row -- stable,
     so inside a table row the slots stay in batch order -- and the CSR pointers of the table rows into that list.
     row_index_lists: int64 [steps, 2b] (table row of every slot).  Returns (order int32 [steps, 2b], rowptr int32
-    [steps, num_rows + 1]).  Torch ops on the device the indices live on: one sort per EPOCH, not per step."""
+    [steps, num_rows + 1]).  Torch ops on the device the indices live on: one sort per EPOCH, not per step.
+    merged_src = b: the rows were written with FLAG_MERGE_SRC -- of every run of equal source ids inside a wave (64 consecutive
+    pairs) only the LAST slot holds a row (the run's sum): the other source slots are left out of the lists."""
     keys = row_index_lists
     if keys.dim() == 1:
         keys = keys.unsqueeze(0)
+    if merged_src:
+        b = int(merged_src)
+        src = keys[:, :b]
+        pos = torch.arange(b, device=keys.device)
+        ends = torch.ones_like(src, dtype=torch.bool)
+        ends[:, :-1] = (src[:, 1:] != src[:, :-1]) | ((pos[:-1] & 63) == 63)
+        keys = torch.cat((torch.where(ends, src, torch.full_like(src, num_rows)), keys[:, b:]), dim=1)    # (num_rows: beyond rowptr)
     sorted_rows, order = torch.sort(keys, dim=1, stable=True)
     bounds = torch.arange(num_rows + 1, device=keys.device, dtype=keys.dtype).unsqueeze(0).expand(keys.shape[0], -1)
     rowptr = torch.searchsorted(sorted_rows.contiguous(), bounds.contiguous(), right=False)

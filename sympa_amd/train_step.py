@@ -24,7 +24,21 @@ from sympa_amd import data, ops
 from sympa_amd.manifolds.metrics import MetricType
 
 
-def batches_want_source_order(model, batch_size=None):
+def merges_source_rows(model, deterministic, batch_size=None):
+    """True where the deterministic rows form merges runs of equal source ids inside a wave before it writes them (round 5:
+    SYMPA_FLAG_MERGE_SRC, csrc/siegel_bwd_kernel.hpp::store_rows_merged; Siegel models, dims <= 6): 45 % fewer gradient rows written and
+    read back at the headline shape when the batches are sorted by source (deterministic step 55.3 -> 51.4 us, configs[2] 60.7 ->
+    57.4, configs[1] 38.8 -> 37.9).  From SYMPA_MERGE_SRC_MIN = 4 096 pairs per batch on: the merge is ~2 us of LDS latency for a
+    wave with nothing else to do (configs[0], 512 pairs: 21.7 -> 23.8 us).  SYMPA_NO_MERGE_SRC=1 switches it off."""
+    if not deterministic or os.environ.get("SYMPA_NO_MERGE_SRC"):
+        return False
+    if batch_size is not None and int(batch_size) < int(os.environ.get("SYMPA_MERGE_SRC_MIN", "4096")):
+        return False
+    table = model.embeddings.embeds
+    return getattr(model.manifold, "model_name", "") in ("upper", "bounded") and table.dim() == 4 and int(table.shape[-1]) <= 6
+
+
+def batches_want_source_order(model, batch_size=None, deterministic=False):
     """True where the backward's scatter merges consecutive pairs with the same source row -- the split backward of the upper
     model at dims 8 (csrc/siegel_bwd_split_kernel.hpp) and the three-kernel spd backward at dims 9..16 (spd_coop_bwd3_kernel.hpp):
     there a batch sorted by its first column (data.sort_batches_by_source) is 10-15 % faster.  Everywhere else the sorted order puts
@@ -37,6 +51,8 @@ def batches_want_source_order(model, batch_size=None):
     name = getattr(man, "model_name", "")
     if os.environ.get("SYMPA_NO_BATCH_SORT"):
         return False
+    if merges_source_rows(model, deterministic, batch_size):          # the rows form adds no atomics: the sorted order only shortens the lists
+        return True
     if name == "upper" and dims == 8:
         floor = int(os.environ.get("SYMPA_SIEGEL_BWD_WORKSPACE_MIN", "1024"))
     elif name == "spd" and 9 <= dims <= 16:
@@ -119,6 +135,9 @@ class GraphedTrainStep:
             self.rowptr = torch.zeros(steps, n_rows + 1, dtype=torch.int32, device=dev)
         self.graph = None            # the captured launches hold the old addresses
 
+    def _merge_flags(self):
+        return ops.FLAG_MERGE_SRC if merges_source_rows(self.model, self.deterministic, self.batch_size) else 0
+
     def _bwd_ws(self, table, b):
         """The persistent scratch of the split Siegel backward for batches of b pairs (None where no kernel uses one): a replayed
         graph must not allocate, so it is made once per batch size and kept."""
@@ -153,7 +172,8 @@ class GraphedTrainStep:
             return
         ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                  None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                 grad_rows=self.rows, step_counter=counter, wave_partials=self.partials, workspace=self._bwd_ws(table, b))
+                                 grad_rows=self.rows, step_counter=counter, wave_partials=self.partials, workspace=self._bwd_ws(table, b),
+                                 flags=self._merge_flags())
         ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=counter,
                               wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
                               loss=self.loss, grad_scale=gs, grad_weights=gw, sq_partials=self.sq_partials)
@@ -263,8 +283,8 @@ class GraphedTrainStep:
             partials = torch.empty((b + 63) // 64, 2 + n, dtype=torch.float64, device=table.device)
             ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_rows=rows, wave_partials=partials, workspace=self._bwd_ws(table, b))
-            order, rowptr = ops.sorted_slots(torch.cat((ids[:, 0], ids[:, 1])), table.shape[0])
+                                     grad_rows=rows, wave_partials=partials, workspace=self._bwd_ws(table, b), flags=self._merge_flags())
+            order, rowptr = ops.sorted_slots(torch.cat((ids[:, 0], ids[:, 1])), table.shape[0], merged_src=b if self._merge_flags() else 0)
             ops.segment_sum_rows_(table.grad, rows, order, rowptr, wave_partials=partials, num_waves=(b + 63) // 64,
                                   partial_stride=2 + n, loss=loss, grad_scale=gs, grad_weights=gw,
                                   sq_partials=self.sq_partials)
@@ -376,7 +396,7 @@ class GraphedTrainStep:
             self.counter.zero_()
             if self.deterministic:
                 order, rowptr = ops.sorted_slots(torch.cat((self.ids[:b, 0], self.ids[:b, 1])),
-                                                 self.model.embeddings.embeds.shape[0])
+                                                 self.model.embeddings.embeds.shape[0], merged_src=b if self._merge_flags() else 0)
                 self.order[0].copy_(order[0])
                 self.rowptr[0].copy_(rowptr[0])
         self._ready()
@@ -397,14 +417,14 @@ class GraphedTrainStep:
         steps = total // b
         if total > self.capacity:
             self._alloc_epoch(total)
-        if batches_want_source_order(self.model, b):      # the order inside a batch is free: equal source rows adjacent
+        if batches_want_source_order(self.model, b, self.deterministic):      # the order inside a batch is free: equal source rows adjacent
             triplets = data.sort_batches_by_source(triplets, b)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
         if self.deterministic and steps > 0:
             used = self.ids[:steps * b].view(steps, b, 2)
             order, rowptr = ops.sorted_slots(torch.cat((used[:, :, 0], used[:, :, 1]), dim=1),
-                                             self.model.embeddings.embeds.shape[0])
+                                             self.model.embeddings.embeds.shape[0], merged_src=b if self._merge_flags() else 0)
             self.order[:steps].copy_(order)
             self.rowptr[:steps].copy_(rowptr)
         self.counter.zero_()
@@ -526,6 +546,9 @@ class DistributedTrainStep:
             self.rowptr = torch.zeros(steps, self.model.embeddings.embeds.shape[0] + 1, dtype=torch.int32, device=self.device)
         self.graphs = None
 
+    def _merge_flags(self):
+        return ops.FLAG_MERGE_SRC if merges_source_rows(self.model, self.deterministic, self.batch_size) else 0
+
     def _bwd_ws(self, table, b):
         """The persistent scratch of the split Siegel backward for batches of b pairs (None where no kernel uses one): a replayed
         graph must not allocate, so it is made once per batch size and kept."""
@@ -570,7 +593,8 @@ class DistributedTrainStep:
         elif self.deterministic:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_rows=self.rows, step_counter=self.counter, wave_partials=self.partials, workspace=self._bwd_ws(table, b))
+                                     grad_rows=self.rows, step_counter=self.counter, wave_partials=self.partials, workspace=self._bwd_ws(table, b),
+                                     flags=self._merge_flags())
             ops.segment_sum_rows_(table.grad, self.rows, self.order, self.rowptr, step_counter=self.counter,
                                   wave_partials=self.partials, num_waves=(b + 63) // 64, partial_stride=2 + table.shape[2],
                                   loss=self.loss, grad_scale=gs, grad_weights=gw)
@@ -667,7 +691,7 @@ class DistributedTrainStep:
         total = triplets.shape[0]
         if total > self.capacity:
             self._alloc(total)
-        if batches_want_source_order(self.model, self.batch_size):      # the order inside a batch is free
+        if batches_want_source_order(self.model, self.batch_size, self.deterministic):      # the order inside a batch is free
             triplets = data.sort_batches_by_source(triplets, self.batch_size)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
@@ -675,7 +699,8 @@ class DistributedTrainStep:
         if self.deterministic and steps > 0:       # ONE stable sort per epoch: the order the segmented sums add in
             used = self.ids[:steps * self.batch_size].view(steps, self.batch_size, 2)
             order, rowptr = ops.sorted_slots(torch.cat((used[:, :, 0], used[:, :, 1]), dim=1),
-                                             self.model.embeddings.embeds.shape[0])
+                                             self.model.embeddings.embeds.shape[0],
+                                             merged_src=self.batch_size if self._merge_flags() else 0)
             self.order[:steps].copy_(order)
             self.rowptr[:steps].copy_(rowptr)
         self.counter.zero_()
