@@ -99,9 +99,15 @@ __global__ __launch_bounds__(64, 2) void spd_bwd3_front_kernel(const SpdBwdArgs 
             for (int j = 0; j < M - 1; ++j)
                 if (j < r && r < M) mine[j] = vk[j];
         }
-        if (r == 0) {                                            // group-uniform values: lane 0's copy
+        // group-uniform values (every lane holds all of them): lane r stores entry r -- three 128-byte stores per pair instead of
+        // 48 eight-byte ones from lane 0
+        if (r < M) {
+            double bkr = bk[0], dr = d[0], er = e[0];
 #pragma unroll
-            for (int j = 0; j < M; ++j) { slot[W::BK + j] = bk[j]; slot[W::D + j] = d[j]; slot[W::E + j] = e[j]; }
+            for (int j = 1; j < M; ++j) { bkr = (r == j) ? bk[j] : bkr; dr = (r == j) ? d[j] : dr; er = (r == j) ? e[j] : er; }
+            slot[W::BK + r] = bkr;
+            slot[W::D + r] = dr;
+            slot[W::E + r] = er;
         }
     }
 }
@@ -125,6 +131,9 @@ __global__ __launch_bounds__(64) void spd_bwd3_eig_kernel(const int64_t b, doubl
     const bool conv = sympa::tridiag_ql_lockstep<M>(w, e2);
     sympa::sort_ascending<M>(w);
     double* const out = ws + i * W::SLOT;                        // (a dead lane's slot exists: whole chunks are allocated)
+    // (the eigenvectors leave lane by lane, M eight-byte stores of 64 different lines each: staging a vector of all 64 pairs in the
+    // LDS and writing whole 128-byte vectors was measured -- 1.49 -> 1.60 ms per 1 M pairs: the lone wave waits for its own LDS round
+    // trip per vector, the stores it saves were overlapped anyway)
     bool small_blocks = true;
     small_blocks = sympa::tridiag_eigvecs_invit<M>(dk, ek, w, [&](auto IC, const double (&x)[M]) {
         constexpr int k = decltype(IC)::value;
