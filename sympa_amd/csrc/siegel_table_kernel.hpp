@@ -226,8 +226,18 @@ __global__ __launch_bounds__(FB) void fused_step_kernel(const FusedStepArgs a) {
     double coef = 1.0;
     if (a.max_norm > 0.0 && a.sq_in != nullptr) {
         if (wave == 0) {
+            // lane l adds partials l, l + 64, ... in index order (eight loads in flight: a few thousand partials are a chain of
+            // dependent L2 round trips otherwise), then the xor tree -- the same bits in every block
             double t = 0.0;
-            for (int k = lane; k < a.sq_in_count; k += 64) t += a.sq_in[k];
+            int k = lane;
+            for (; k + 7 * 64 < a.sq_in_count; k += 8 * 64) {
+                double x[8];
+SYMPA_UNROLL
+                for (int j = 0; j < 8; ++j) x[j] = a.sq_in[k + 64 * j];
+SYMPA_UNROLL
+                for (int j = 0; j < 8; ++j) t += x[j];
+            }
+            for (; k < a.sq_in_count; k += 64) t += a.sq_in[k];
 SYMPA_UNROLL
             for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
             if (lane == 0) total_s = t;
