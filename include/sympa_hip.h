@@ -364,8 +364,7 @@ int sympa_model_train_backward(const double* table, int64_t num_rows, int n, con
 
 /* Deterministic counterpart of sympa_scatter_add_flat_rows ("sort-by-row + segmented sum"):
  *   grad_table[r] (= | +=, by `accumulate`) alpha * sum_{p in [rowptr[r], rowptr[r + 1])} rows[order[p]]     r = 0 .. num_rows - 1
- * added in a FIXED order derived from `order` (four lanes per element: lane s adds the slots p0 + s, p0 + s + 4, ... in list order,
- * then (s0 + s1) + (s2 + s3)), no atomics: every element is written by exactly one thread, rows nobody touched are
+ * added in the order of `order`, no atomics: every element is written by exactly one thread, rows nobody touched are
  * written as 0 when accumulate = 0 (no zeroing pass).  order: int32 slot numbers (rows of `rows`, row_doubles each)
  * sorted by table row -- stable, so the order inside a row is the batch order; rowptr: int32 [num_rows + 1].  With
  * step_counter c (device int64, may be NULL) the lists of batch c are used: order + c * order_stride, rowptr + c *

@@ -90,7 +90,6 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_rows_kernel(const double* _
 // the same bits; untouched rows are written as 0 (accumulate = 0): no separate zeroing pass either.
 // The last block (when wave_partials is given) adds the per-wave sums of the loss, of d loss / d scale and of
 // d loss / d w_k that the backward kernel left (siegel_bwd_kernel.hpp) in a fixed order as well.
-constexpr int SEG_LANES = 4;        // lanes per (table row, element) of segment_sum_rows_kernel: a power of two <= 64
 __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* __restrict__ rows, const int32_t* __restrict__ order,
                                                                  const int32_t* __restrict__ rowptr, int64_t num_rows, int rowd,
                                                                  int64_t order_stride, const int64_t* __restrict__ counter,
@@ -127,39 +126,31 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
     const int64_t c = counter != nullptr ? counter[0] : 0;
     order += c * order_stride;
     rowptr += c * (num_rows + 1);
-    // SEG_LANES lanes per (table row, element): lane `sub` of the group adds the slots p0 + sub, p0 + sub + SEG_LANES, ... in list
-    // order, then the group's partial sums are added in a fixed tree ((s0 + s1) + (s2 + s3)) -- a fixed order like before, with a
-    // quarter of the dependent loads per thread (round 5: 10.5 -> see profiles/r05_training_path.txt; the chain of a thread was
-    // ~14 slots = two rounds of index load + row load)
-    const int64_t tt = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int64_t t = tt / SEG_LANES;               // (row, element)
-    const int sub = (int)(tt - t * SEG_LANES);
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = t < num_rows * rowd;      // no early return: the block's tree below needs every thread at its barriers
     double v = 0.0;
-    {
+    if (in_range) {
+        const int64_t r = t / rowd;
+        const int e = (int)(t - r * rowd);
+        const int p0 = rowptr[r], p1 = rowptr[r + 1];
         double s = 0.0;
-        if (in_range) {
-            const int64_t r = t / rowd;
-            const int e = (int)(t - r * rowd);
-            const int p0 = rowptr[r], p1 = rowptr[r + 1];
-            int p = p0 + sub;
-            for (; p + 3 * SEG_LANES < p1; p += 4 * SEG_LANES) {       // four loads in flight, added in list order
-                double x[4];
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {       // eight loads in flight, added in list order
+            double x[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = rows[(int64_t)order[p + k * SEG_LANES] * rowd + e];
+            for (int k = 0; k < 8; ++k) x[k] = rows[(int64_t)order[p + k] * rowd + e];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s += x[k];
-            }
-            for (; p < p1; p += SEG_LANES) s += rows[(int64_t)order[p] * rowd + e];
+            for (int k = 0; k < 8; ++k) s += x[k];
         }
-        // the group's tree (every lane of the wave takes part: the shuffles are not under the branch)
-#pragma unroll
-        for (int off = 1; off < SEG_LANES; off <<= 1) s += __shfl_xor(s, off);
-        if (in_range && sub == 0) {
-            s *= alpha;
-            v = accumulate ? grad[t] + s : s;
-            grad[t] = v;
+        for (; p + 4 <= p1; p += 4) {
+            const double v0 = rows[(int64_t)order[p] * rowd + e], v1 = rows[(int64_t)order[p + 1] * rowd + e];
+            const double v2 = rows[(int64_t)order[p + 2] * rowd + e], v3 = rows[(int64_t)order[p + 3] * rowd + e];
+            s = ((s + v0) + v1) + v2 + v3;
         }
+        for (; p < p1; ++p) s += rows[(int64_t)order[p] * rowd + e];
+        s *= alpha;
+        v = accumulate ? grad[t] + s : s;
+        grad[t] = v;
     }
     if (sq_partials != nullptr) {
         // squared norm of the finished gradient, one partial per block in a fixed tree: the optimiser kernel adds the
@@ -333,7 +324,7 @@ int sympa_scatter_add_flat_rows(const double* rows, const int64_t* idx, int64_t 
 
 int64_t sympa_segment_sum_partials(int64_t num_rows, int row_doubles) {
     if (num_rows <= 0 || row_doubles < 1) return 0;
-    return (num_rows * row_doubles * SEG_LANES + BLOCK - 1) / BLOCK + 1;
+    return (num_rows * row_doubles + BLOCK - 1) / BLOCK + 1;
 }
 
 int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32_t* rowptr, int64_t num_rows, int row_doubles,
@@ -343,13 +334,13 @@ int sympa_segment_sum_rows(const double* rows, const int32_t* order, const int32
     if (num_rows <= 0 || row_doubles < 1 || row_doubles > 2 * SYMPA_MAX_DIMS_GENERIC * SYMPA_MAX_DIMS_GENERIC)
         return fail(SYMPA_ERR_BAD_ARG, "bad table shape");
     if (rows == nullptr || order == nullptr || rowptr == nullptr || grad_table == nullptr) return fail(SYMPA_ERR_BAD_ARG, "null buffer");
-    if (num_rows * row_doubles * SEG_LANES > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "table too large for one launch");
+    if (num_rows * row_doubles > (int64_t)0x7fffffff * BLOCK) return fail(SYMPA_ERR_BAD_ARG, "table too large for one launch");
     if (wave_partials != nullptr && (num_waves < 0 || num_weights < 0 || partial_stride < 2 + num_weights || loss == nullptr ||
                                      (num_weights > 0 && grad_w == nullptr)))
         return fail(SYMPA_ERR_BAD_ARG, "bad partial-sum arguments");
     if (sq_partials != nullptr && wave_partials == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "sq_partials needs wave_partials (the scalar gradients enter the clip norm)");
-    const unsigned row_blocks = (unsigned)((num_rows * row_doubles * SEG_LANES + BLOCK - 1) / BLOCK);
+    const unsigned row_blocks = (unsigned)((num_rows * row_doubles + BLOCK - 1) / BLOCK);
     const unsigned grid = row_blocks + (wave_partials != nullptr ? 1u : 0u);
     hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows, order,
                        rowptr, num_rows, row_doubles, order_stride, step_counter, alpha, accumulate, grad_table, wave_partials,

@@ -934,9 +934,8 @@ def sorted_slots(row_index_lists, num_rows, merged_src=0):
 def segment_sum_rows_(grad_table, rows, order, rowptr, alpha=1.0, accumulate=False, step_counter=None,
                       wave_partials=None, num_waves=0, partial_stride=0, loss=None, grad_scale=None, grad_weights=None,
                       sq_partials=None):
-    """grad_table[r] (= | +=) alpha * sum of rows[order[p]], p in [rowptr[r], rowptr[r + 1]), added in a FIXED order (four
-    interleaved sub-lists, each in list order, then (s0 + s1) + (s2 + s3)): the deterministic counterpart of scatter_add_rows_
-    (C-ABI sympa_segment_sum_rows).  order / rowptr from sorted_slots();
+    """grad_table[r] (= | +=) alpha * sum of rows[order[p]], p in [rowptr[r], rowptr[r + 1]), added in list order: the
+    deterministic counterpart of scatter_add_rows_ (C-ABI sympa_segment_sum_rows).  order / rowptr from sorted_slots();
     with step_counter the lists of batch step_counter[0] are used.  wave_partials: the per-wave sums model_train_backward
     left; they are added to loss / grad_scale / grad_weights in a fixed order."""
     lib = _lib.load()

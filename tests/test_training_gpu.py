@@ -248,7 +248,7 @@ def test_deterministic_gradient_accumulation(model, n):
     """SURVEY 8f-1's alternative to atomics: per-pair gradient rows (coalesced through the LDS tile) + segmented sum in a
     precomputed order + fixed-order scalar sums.  Two runs give bit-identical embeds.grad, loss and scale gradient; they
     equal the fp64-atomic scatter to 1e-12 (relative to the largest entry); a small case equals the sum evaluated
-    in the kernel's documented fixed order on the host bit for bit; the step-counter window picks the right batch."""
+    sequentially in slot order on the host bit for bit; the step-counter window picks the right batch."""
     from sympa_amd import data, ops
     dev = torch.device("cuda:0")
     nodes, b, steps = 211, 4099 if n < 8 else 1500, 3
@@ -307,16 +307,15 @@ def test_deterministic_gradient_accumulation(model, n):
             assert abs(float(a1[1] - loss)) < tol * abs(float(loss)) and abs(float(a1[2] - gs)) < 10 * tol * abs(float(gs))
             if metric == "wsum":
                 assert float((a1[3] - gw).abs().max()) < 10 * tol * float(gw.abs().max())
-    # bit for bit the documented fixed order (rows of the last det() call, batch 2): four interleaved sub-lists of a table row's
-    # slots, each added in list order, then the tree (s0 + s1) + (s2 + s3)  (csrc/siegel_table.hip: SEG_LANES = 4)
+    # bit for bit the sequential sum in slot order (rows of the last det() call, batch 2)
     rows_c = a1[4].cpu().reshape(2 * b, -1)
     o, rp = order[2].cpu(), rowptr[2].cpu()
     want = torch.zeros(nodes, rows_c.shape[1], dtype=torch.float64)
     for r in range(0, nodes, 17):
-        sub = [torch.zeros(rows_c.shape[1], dtype=torch.float64) for _ in range(4)]
-        for k, p in enumerate(range(int(rp[r]), int(rp[r + 1]))):
-            sub[k % 4] = sub[k % 4] + rows_c[int(o[p])]
-        want[r] = (sub[0] + sub[1]) + (sub[2] + sub[3])
+        s = torch.zeros(rows_c.shape[1], dtype=torch.float64)
+        for p in range(int(rp[r]), int(rp[r + 1])):
+            s = s + rows_c[int(o[p])]
+        want[r] = s
         assert torch.equal(a1[0][r].cpu().reshape(-1), want[r]), r
     # accumulate / alpha
     acc = torch.ones_like(table)
