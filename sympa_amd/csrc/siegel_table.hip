@@ -155,13 +155,17 @@ __global__ __launch_bounds__(BLOCK) void segment_sum_rows_kernel(const double* _
     if (sq_partials != nullptr) {
         // squared norm of the finished gradient, one partial per block in a fixed tree: the optimiser kernel adds the
         // partials in index order and needs neither its own pass over the gradient nor a grid barrier
-        red[threadIdx.x] = v * v;
+        // (a fixed tree: the xor tree of every wave, then the waves in index order -- one barrier instead of eight)
+        double q = v * v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
         __syncthreads();
-        for (int off = BLOCK / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = red[0];
+            for (int w = 1; w < BLOCK / 64; ++w) t += red[w];
+            sq_partials[blockIdx.x] = t;
         }
-        if (threadIdx.x == 0) sq_partials[blockIdx.x] = red[0];
     }
 }
 
