@@ -76,12 +76,13 @@ extern "C" {
                              * wherever it is built -- by default it runs only where it measured faster than the one-launch kernels
                              * (upper model, dims 7 and 8: profiles/r04_n8_backward_split.txt) */
 #define SYMPA_FLAG_NO_SYMMETRY 16 /* sympa_all_pairs_dist_packed: evaluate both (i, j) and (j, i) even for the full matrix */
-#define SYMPA_FLAG_MERGE_SRC 128 /* sympa_model_train_backward in the per-pair rows form (grad_rows), dims <= 6: consecutive pairs of a
-                                  * wave (64 pairs) with the SAME source id are summed in pair order and written ONCE, into the source
-                                  * row slot of the LAST pair of the run; the other source slots of the run are NOT written.  For
-                                  * batches sorted by their first column (~13 pairs per source row at the headline shape) that is 45 %
-                                  * fewer rows written and read back; the caller's segmented sum must leave the unwritten slots out
-                                  * (sympa_amd.ops.sorted_slots(..., merged_src=batch)).  Bitwise reproducible like the plain rows form. */
+#define SYMPA_FLAG_MERGE_SRC 128 /* sympa_model_train_backward, dims <= 6: consecutive pairs of a wave (64 pairs) with the SAME source id
+                                  * are summed in pair order inside the wave's LDS tile.  Rows form (grad_rows): the sum is written ONCE,
+                                  * into the source row slot of the LAST pair of the run, the other source slots of the run are NOT
+                                  * written -- the caller's segmented sum must leave them out (sympa_amd.ops.sorted_slots(...,
+                                  * merged_src=batch)); bitwise reproducible like the plain rows form.  Scatter form (grad_table): one
+                                  * atomic row per run.  For batches sorted by their first column (~13 pairs per source row at the
+                                  * headline shape) that is 45 % fewer rows through memory. */
 
 #define SYMPA_MAX_DIMS 8          /* largest n with a register-resident forward kernel in this build */
 #define SYMPA_MAX_DIMS_BACKWARD 16 /* largest n with a backward kernel in this build: n <= 6 one pair per lane in registers;

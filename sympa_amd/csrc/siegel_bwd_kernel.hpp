@@ -34,9 +34,12 @@ struct ScatterTile {
     static constexpr int WAVE_DOUBLES = 64 * PITCH;
 };
 
+// merge = true (SYMPA_FLAG_MERGE_SRC, whole-row tiles: n <= 6): runs of consecutive pairs with the same row are summed inside the
+// tile first -- the sum stays in the row of the run's LAST pair, the other rows of the run become zero, and the loop below skips
+// zeros: one atomic row per run instead of one per pair (batches sorted by source: ~13 pairs per source row at the headline shape).
 template <int N>
 __device__ __forceinline__ void scatter_add_rows(const sympa::CMat<N>& g, const int row, double* __restrict__ grad,
-                                                 double* __restrict__ tile, const bool live) {
+                                                 double* __restrict__ tile, const bool live, const bool merge = false) {
     constexpr int ROWD = ScatterTile<N>::ROWD, PITCH = ScatterTile<N>::PITCH;
     const int lane = threadIdx.x & 63;
     if constexpr (ScatterTile<N>::BY_PLANE) {
@@ -70,6 +73,34 @@ SYMPA_UNROLL
             tile[lane * PITCH + N * N + i * N + j] = live ? g.im[i][j] : 0.0;
         }
     wave_lds_fence();
+    if constexpr (!ScatterTile<N>::BY_PLANE) {
+        if (merge) {                                                  // wave-uniform
+            // (the shuffle runs in ALL lanes, outside the ||: behind a short-circuit it executes under a divergent branch and a lane
+            // whose neighbour is inactive reads 0)
+            const int next_row = __shfl_down(row, 1);
+            const bool ends = (lane == 63) | (next_row != row);
+            const unsigned long long end_mask = __ballot(ends);
+            for (int e0 = 0; e0 < ROWD; e0 += 64) {
+                const int e = e0 + lane;
+                const bool on = e < ROWD;
+                double acc = 0.0;
+#pragma unroll
+                for (int p0 = 0; p0 < 64; p0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = on ? tile[(p0 + j) * PITCH + e] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc += v[j];
+                        const bool end = (end_mask >> (p0 + j)) & 1ull;       // scalar
+                        if (on) tile[(p0 + j) * PITCH + e] = end ? acc : 0.0;
+                        acc = end ? 0.0 : acc;
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
+    }
 #pragma unroll 4
     for (int t = 0; t < ROWD; ++t) {
         const int gidx = t * 64 + lane;
@@ -126,8 +157,9 @@ SYMPA_UNROLL
         }
     wave_lds_fence();
     const int lo = (int)(id & 0xffffffffll), hi = (int)(id >> 32);
-    const bool differs = __shfl_down(lo, 1) != lo || __shfl_down(hi, 1) != hi;
-    const bool ends = lane < live_pairs && (lane + 1 >= live_pairs || differs);
+    const int next_lo = __shfl_down(lo, 1), next_hi = __shfl_down(hi, 1);      // (both in all lanes: no short-circuit around a shuffle)
+    const bool differs = (next_lo != lo) | (next_hi != hi);
+    const bool ends = (lane < live_pairs) & ((lane + 1 >= live_pairs) | differs);
     const unsigned long long end_mask = __ballot(ends);                  // wave-uniform
     if constexpr (ROWD <= 32) {
         // both halves of the wave at once: lanes 0..31 walk pairs 0..31, lanes 32..63 pairs 32..63 (entry e = lane & 31).  The run
@@ -288,7 +320,7 @@ SYMPA_UNROLL
             scatter_add_rows_outlined<N>(g1, (int)r1, a.g1, dtile, live && !bad);
             scatter_add_rows_outlined<N>(g2, (int)r2, a.g2, dtile, live && !bad);
         } else {
-            scatter_add_rows<N>(g1, (int)r1, a.g1, dtile, live && !bad);
+            scatter_add_rows<N>(g1, (int)r1, a.g1, dtile, live && !bad, (f.flags & SYMPA_FLAG_MERGE_SRC) != 0);
             scatter_add_rows<N>(g2, (int)r2, a.g2, dtile, live && !bad);
         }
     } else if constexpr (ROWS_TILE) {

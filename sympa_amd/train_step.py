@@ -27,14 +27,17 @@ from sympa_amd.manifolds.metrics import MetricType
 
 
 def merges_source_rows(model, deterministic, batch_size=None):
-    """True where the deterministic rows form merges runs of equal source ids inside a wave before it writes them (round 5:
-    SYMPA_FLAG_MERGE_SRC, csrc/siegel_bwd_kernel.hpp::store_rows_merged; Siegel models, dims <= 6): 45 % fewer gradient rows written and
-    read back at the headline shape when the batches are sorted by source (deterministic step 55.3 -> 51.4 us, configs[2] 60.7 ->
-    57.4, configs[1] 38.8 -> 37.9).  From SYMPA_MERGE_SRC_MIN = 4 096 pairs per batch on: the merge is ~2 us of LDS latency for a
-    wave with nothing else to do (configs[0], 512 pairs: 21.7 -> 23.8 us).  SYMPA_NO_MERGE_SRC=1 switches it off."""
-    if not deterministic or os.environ.get("SYMPA_NO_MERGE_SRC"):
+    """True where the training backward of the Siegel models at dims <= 6 merges runs of equal source ids inside a wave (round 5:
+    SYMPA_FLAG_MERGE_SRC, csrc/siegel_bwd_kernel.hpp) -- the deterministic rows form writes ONE row per run (store_rows_merged: 45 %
+    fewer gradient rows written and read back at the headline shape), the atomic form sums the run in its LDS tile and adds one row
+    (scatter_add_rows) -- on batches sorted by source (load_epoch).  Measured, per step: deterministic 55.3 -> 49.9 us at the headline
+    shape, configs[2] 60.7 -> 55.4, configs[1] (8 192 pairs) 38.8 -> 38.2, configs[0] (512 pairs) 21.7 -> 23.8: from 4 096 pairs per
+    batch; atomic 63.1 -> 58.4 / 66.7 -> 63.6, but 32.9 -> 35.1 at 8 192 pairs: from 32 768.  SYMPA_MERGE_SRC_MIN=<pairs> moves both
+    thresholds, SYMPA_NO_MERGE_SRC=1 switches the merging off."""
+    if os.environ.get("SYMPA_NO_MERGE_SRC"):
         return False
-    if batch_size is not None and int(batch_size) < int(os.environ.get("SYMPA_MERGE_SRC_MIN", "4096")):
+    floor = int(os.environ.get("SYMPA_MERGE_SRC_MIN", "4096" if deterministic else "32768"))
+    if batch_size is not None and int(batch_size) < floor:
         return False
     table = model.embeddings.embeds
     return getattr(model.manifold, "model_name", "") in ("upper", "bounded") and table.dim() == 4 and int(table.shape[-1]) <= 6
@@ -170,7 +173,8 @@ class GraphedTrainStep:
         if not self.deterministic:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_table=table.grad, step_counter=counter, workspace=self._bwd_ws(table, b))
+                                     grad_table=table.grad, step_counter=counter, workspace=self._bwd_ws(table, b),
+                                     flags=self._merge_flags())
             return
         ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                  None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
@@ -279,7 +283,7 @@ class GraphedTrainStep:
         if b > 0 and not self.deterministic:
             ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_table=table.grad, workspace=self._bwd_ws(table, b))
+                                     grad_table=table.grad, workspace=self._bwd_ws(table, b), flags=self._merge_flags())
         elif b > 0:
             rows = torch.empty(2 * b, 2, n, n, dtype=torch.float64, device=table.device)
             partials = torch.empty((b + 63) // 64, 2 + n, dtype=torch.float64, device=table.device)
@@ -603,7 +607,8 @@ class DistributedTrainStep:
         else:
             ops.model_train_backward(table.data, self.ids, self.gd, b, self.loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
-                                     grad_table=table.grad, step_counter=self.counter, workspace=self._bwd_ws(table, b))
+                                     grad_table=table.grad, step_counter=self.counter, workspace=self._bwd_ws(table, b),
+                                     flags=self._merge_flags())
 
     def _exchange(self):
         ex = self.ex

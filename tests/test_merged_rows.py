@@ -123,3 +123,36 @@ def test_gpu_graphed_deterministic_step_with_merged_rows(dev, model, metric, mon
     plain, off = run()
     assert not off
     assert float((merged - plain).abs().max()) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,n,b", [("upper", 4, 4096), ("bounded", 4, 1000), ("upper", 5, 333), ("bounded", 6, 130), ("upper", 2, 65),
+                                       ("upper", 3, 1)])
+@pytest.mark.parametrize("sort", [True, False])
+def test_gpu_merged_atomic_scatter_equals_the_plain_scatter(dev, model, n, b, sort):
+    """The scatter form with SYMPA_FLAG_MERGE_SRC (runs summed in the wave's LDS tile, one atomic row per run) against the plain
+    scatter: the same table gradient to rounding (fp64 atomics are unordered either way), loss and scalar gradients too."""
+    from sympa_amd import data, ops
+    nodes = 40
+    g = torch.Generator().manual_seed(23 * n + b)
+    table = points(model, nodes, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b,), generator=g), torch.randint(0, nodes, (b,), generator=g),
+                        torch.randint(1, 9, (b,), generator=g)), 1)
+    if sort:
+        trip = data.sort_batches_by_source(trip, b)
+    trip[min(b - 1, 3), 0] = trip[0, 0]                       # (a run of its own in the middle of another row's run)
+    trip = trip.to(dev)
+    gd = trip[:, 2].to(torch.float64).contiguous()
+    scale = torch.full((1,), 0.9, dtype=torch.float64, device=dev)
+    res = {}
+    for name, flags in (("plain", 0), ("merged", ops.FLAG_MERGE_SRC)):
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        grad = torch.zeros_like(table)
+        ops.model_train_backward(table, trip, gd, b, loss, model, "riem", None, None, scale, gs, 1.0, 1.0, grad_table=grad, flags=flags)
+        res[name] = (grad.cpu(), loss.cpu(), gs.cpu())
+    ops.check_status(dev)
+    big = float(res["plain"][0].abs().max())
+    assert float((res["merged"][0] - res["plain"][0]).abs().max()) <= 1e-12 * big
+    assert abs(float(res["merged"][1] - res["plain"][1])) <= 1e-12 * abs(float(res["plain"][1]))
+    assert abs(float(res["merged"][2] - res["plain"][2])) <= 1e-11 * abs(float(res["plain"][2]))
