@@ -89,5 +89,9 @@ find $OUT/prof_train_cartesian -name "*kernel_stats.csv" | head -1 | xargs -r he
 WORKLOADS=custom-spd timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_spd -- python3 tools/train_step_time.py 10 > $OUT/prof_train_spd.log 2>&1
 find $OUT/prof_train_spd -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | cut -c1-200 | tee $OUT/train_spd_kernel_stats_head.txt
 timeout 900 bash tools/split_pmc.sh $TAG > $OUT/split_pmc.log 2>&1; tail -75 $OUT/split_pmc.log | cut -c1-160
+echo "== round 5: soak of the packed indexed forward, the LDS-DMA micro-benchmark"
+timeout 400 python3 tools/fuzz_packed.py 240 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/packed_soak.txt
+grep -q "fuzz ok" $OUT/packed_soak.txt || FAIL=1
+( cd tools/microbench && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o lds_dma_rate lds_dma_rate.hip > /dev/null 2>&1 ); timeout 120 ./tools/microbench/lds_dma_rate 2>&1 | tee $OUT/lds_dma_rate.txt | tail -4
 echo "== gpu_check status: FAIL=$FAIL"
 exit $FAIL
