@@ -156,3 +156,40 @@ def test_gpu_merged_atomic_scatter_equals_the_plain_scatter(dev, model, n, b, so
     assert float((res["merged"][0] - res["plain"][0]).abs().max()) <= 1e-12 * big
     assert abs(float(res["merged"][1] - res["plain"][1])) <= 1e-12 * abs(float(res["plain"][1]))
     assert abs(float(res["merged"][2] - res["plain"][2])) <= 1e-11 * abs(float(res["plain"][2]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["rows", "scatter"])
+def test_gpu_merged_forms_with_an_out_of_range_id(dev, form):
+    """An out-of-range source id inside a run: the pair contributes nothing and the status word raises IndexError, in both merged
+    forms as in the plain ones; the rest of the gradient is unchanged."""
+    from sympa_amd import data, ops
+    model, n, b, nodes = "upper", 4, 300, 20
+    g = torch.Generator().manual_seed(5)
+    table = points(model, nodes, n, 0.3, g).to(dev)
+    trip = torch.stack((torch.randint(0, nodes, (b,), generator=g), torch.randint(0, nodes, (b,), generator=g),
+                        torch.randint(1, 9, (b,), generator=g)), 1)
+    trip = data.sort_batches_by_source(trip, b)
+    trip[70, 0] = nodes + 3                                   # in the middle of a run of the second wave
+    trip[200, 1] = -1
+    trip = trip.to(dev)
+    gd = trip[:, 2].to(torch.float64).contiguous()
+    res = {}
+    for name, flags in (("plain", 0), ("merged", ops.FLAG_MERGE_SRC)):
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        grad = torch.zeros_like(table)
+        if form == "scatter":
+            ops.model_train_backward(table, trip, gd, b, loss, model, "riem", None, None, None, None, 1.0, 1.0, grad_table=grad, flags=flags)
+        else:
+            rows = torch.zeros(2 * b, 2, n, n, dtype=torch.float64, device=dev)
+            wp = torch.zeros((b + 63) // 64, 2 + n, dtype=torch.float64, device=dev)
+            ops.model_train_backward(table, trip, gd, b, loss, model, "riem", None, None, None, None, 1.0, 1.0, grad_rows=rows,
+                                     wave_partials=wp, flags=flags)
+            order, rowptr = ops.sorted_slots(torch.cat((trip[:, 0], trip[:, 1])), nodes, merged_src=b if flags else 0)
+            ops.segment_sum_rows_(grad, rows, order, rowptr, wave_partials=wp, num_waves=(b + 63) // 64, partial_stride=2 + n, loss=loss)
+        with pytest.raises(IndexError):
+            ops.check_status(dev)
+        res[name] = (grad.cpu(), loss.cpu())
+    assert torch.isfinite(res["merged"][0]).all()
+    assert float((res["merged"][0] - res["plain"][0]).abs().max()) <= 1e-12 * float(res["plain"][0].abs().max())
+    assert abs(float(res["merged"][1] - res["plain"][1])) <= 1e-12 * abs(float(res["plain"][1]))
