@@ -93,6 +93,16 @@ struct DmaTile {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// The LDS destination of a DMA instruction from a (generic) pointer into a __shared__ array: its low 32 bits ARE the LDS offset.
+// A plain cast to the LDS address space carries a null check -- s_cmp_lg_u64 / s_cselect per instruction, three scalar
+// instructions in front of every global_load_lds (round 5: 1 792 -> 947 scalar instructions per tile of the dims-8 packed forward
+// together with one lane mask per pass, profiles/r05_packed_forward.txt block 9).
+__device__ __forceinline__ lds_ptr_t lds_dest(const void* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    return (lds_ptr_t)(unsigned)reinterpret_cast<unsigned long long>(p);
+#pragma clang diagnostic pop
+}
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // (Masking the lanes of the 4 chunks per row that hold only lower-triangle entries off the DMA instruction
@@ -118,7 +128,7 @@ struct DmaIssue {
         // address arithmetic per instruction (tables of n <= 4 are limited to 4 GiB, checked on the host)
         const unsigned off = (unsigned)rr * (unsigned)(16 * N * N) + (unsigned)(16 * c);
         const char* src = reinterpret_cast<const char*>(base) + off;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(side + J * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(side + J * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
         if constexpr (J + 1 < C) DmaIssue<N, J + 1>::run(base, row, c, side);
     }
 };
@@ -209,7 +219,7 @@ struct DmaIssuePass4 {
         const int rr = group_bcast<16, 4 * P + J>(row);
         const unsigned off = (unsigned)rr * 256u + (unsigned)(16 * c);
         const char* src = reinterpret_cast<const char*>(base) + off;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + J * DmaTile<4>::INSTR_SLOTS), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + J * DmaTile<4>::INSTR_SLOTS), 16, 0, 0);
         if constexpr (J + 1 < 4) DmaIssuePass4<P, J + 1>::run(base, row, c, buf);
     }
 };
@@ -358,6 +368,23 @@ __device__ __forceinline__ void pass_issue(const double* __restrict__ base, cons
                                            v2d* __restrict__ buf, const int my_chunk) {
     constexpr int K = PassTile<N, MASKED>::K;
     const int lane = threadIdx.x & 63;
+#ifndef SYMPA_OLD_PASS_ISSUE          // (tools/build_variant.sh: the per-instruction form for an A/B)
+    if constexpr (!MASKED) {
+        // one lane mask around the pass instead of a save / restore of EXEC per instruction; the row indices are read in front of
+        // it (behind the branch the compiler may compute `row` for the active lanes only, and a pass reads lanes K..63 as well)
+        int rr[PassTile<N>::ROWS];
+#pragma unroll
+        for (int j = 0; j < PassTile<N>::ROWS; ++j) rr[j] = __builtin_amdgcn_readlane(row, 16 * pass + j);
+        if (K == 64 || lane < K) {
+#pragma unroll
+            for (int j = 0; j < PassTile<N>::ROWS; ++j) {
+                const double* src = base + (int64_t)rr[j] * (2 * N * N) + 2 * my_chunk;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
+            }
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < PassTile<N>::ROWS; ++j) {
         // full rows (upper model): v_readlane -- the source lane is a compile-time constant, the row index arrives in a scalar
@@ -368,7 +395,7 @@ __device__ __forceinline__ void pass_issue(const double* __restrict__ base, cons
         const int rr = MASKED ? __shfl(row, 16 * pass + j) : __builtin_amdgcn_readlane(row, 16 * pass + j);
         const double* src = base + (int64_t)rr * (2 * N * N) + 2 * my_chunk;
         if (K == 64 || lane < K)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
     }
 }
 

@@ -133,15 +133,27 @@ __device__ __forceinline__ void packed_ids_check(const PackedArgs& a, int64_t x1
 template <int K, int ROW_DOUBLES, int PITCH>
 __device__ __forceinline__ void ring_pass_issue(const double* __restrict__ base, const int row, const int pass, v2d* __restrict__ buf) {
     const int lane = threadIdx.x & 63;
+    // (lds_dest: no null check per instruction; ONE lane mask around the sixteen instructions of the pass instead of one save / restore
+    // of EXEC each.  The sixteen row indices are read BEFORE the mask: v_readlane itself does not look at EXEC, but behind the branch
+    // the compiler is free to compute `row` for the active lanes only -- lanes K..63 then hold garbage, and a pass reads them.
+    // Dims 8 upper: 1 792 -> ~950 scalar instructions per tile)
+    int rr[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int rr = __builtin_amdgcn_readlane(row, 16 * pass + j);
-        const double* src = base + (int64_t)rr * ROW_DOUBLES + 2 * lane;
-        if (K >= 64 || lane < K)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + j * PITCH), 16, 0, 0);
-        if constexpr (K > 64) {
-            if (lane < K - 64)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 128), (lds_ptr_t)(buf + j * PITCH + 64), 16, 0, 0);
+    for (int j = 0; j < 16; ++j) rr[j] = __builtin_amdgcn_readlane(row, 16 * pass + j);
+    if (K >= 64 || lane < K) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double* src = base + (int64_t)rr[j] * ROW_DOUBLES + 2 * lane;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PITCH), 16, 0, 0);
+        }
+    }
+    if constexpr (K > 64) {
+        if (lane < K - 64) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double* src = base + (int64_t)rr[j] * ROW_DOUBLES + 2 * lane;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 128), lds_dest(buf + j * PITCH + 64), 16, 0, 0);
+            }
         }
     }
 }
