@@ -25,6 +25,10 @@
 #pragma once
 #include "siegel_common.hpp"
 
+#ifndef SYMPA_PACKED_STAGGER_SLEEP
+#define SYMPA_PACKED_STAGGER_SLEEP 20      // x 64 cycles per step of the staggered first round (tools/build_variant.sh for an A/B)
+#endif
+
 namespace sympa_hip {
 
 template <int N, int MODEL>
@@ -222,10 +226,12 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
     v2d* buf1 = tile + R::BUF_SLOTS;
     // staggered first round, as in siegel_dist_kernel.hpp (tables beyond the L2s: CU j of every XCD starts j x 0.5 us late, the
     // waves stay out of step from there on; upper n = 8: 135.9 -> 126.9 us)
+#ifndef SYMPA_PACKED_STAGGER_LATE
     if (a.stagger && blockIdx.x < 1024u) {
         const int k = (int)((blockIdx.x >> 5) & 31u);
-        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
     }
+#endif
     unsigned t = blockIdx.x;
     if (t >= a.tiles) return;
     int r1, r2, st;
@@ -234,6 +240,12 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
     packed_ids_check(a, x1, x2, r1, r2, st);
     packed_pass_issue<N, MODEL>(a.pack, r2, 0, buf0);        // passes 0..3: the pair's second point, 4..7: the first
     packed_pass_issue<N, MODEL>(a.pack, r2, 1, buf1);
+#ifdef SYMPA_PACKED_STAGGER_LATE          // (A/B: the first tile's head in flight while the wave sleeps)
+    if (a.stagger && blockIdx.x < 1024u) {
+        const int k = (int)((blockIdx.x >> 5) & 31u);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
+    }
+#endif
     // the ids of the NEXT tile are always one tile ahead of the passes that need them (loaded behind the previous prefetch)
     unsigned tn = t + gridDim.x;
     bool more = tn < a.tiles;                      // wave-uniform
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(64, 1) void dense_forward_kernel(const PackedArgs a
     v2d* buf1 = tile + R::BUF_SLOTS;
     if (a.stagger && blockIdx.x < 1024u) {
         const int k = (int)((blockIdx.x >> 5) & 31u);
-        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(20);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
     }
     unsigned t = blockIdx.x;
     if (t >= a.tiles) return;
