@@ -25,8 +25,12 @@
 #pragma once
 #include "siegel_common.hpp"
 
+// x 64 cycles per step of the staggered first round (tools/build_variant.sh -DSYMPA_PACKED_STAGGER_SLEEP=<k> for an A/B; measured on
+// the final build of round 5, 262 144 pairs of 45 500 rows: n = 8 0 / 6 / 12 / 16 / 20 / 28 / 40 -> 129.7 / 124.1 / 117.7 / 116.9 /
+// 116.6 / 121.9 / 131.4 us, n = 7 0 / 12 / 16 / 20 / 28 -> 99.0 / 90.3 / 90.3 / 93.5 / 99.5 us; sleeping AFTER the first tile's head
+// is in flight: no better)
 #ifndef SYMPA_PACKED_STAGGER_SLEEP
-#define SYMPA_PACKED_STAGGER_SLEEP 20      // x 64 cycles per step of the staggered first round (tools/build_variant.sh for an A/B)
+#define SYMPA_PACKED_STAGGER_SLEEP (N >= 8 ? 20 : 16)
 #endif
 
 namespace sympa_hip {
@@ -226,12 +230,10 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
     v2d* buf1 = tile + R::BUF_SLOTS;
     // staggered first round, as in siegel_dist_kernel.hpp (tables beyond the L2s: CU j of every XCD starts j x 0.5 us late, the
     // waves stay out of step from there on; upper n = 8: 135.9 -> 126.9 us)
-#ifndef SYMPA_PACKED_STAGGER_LATE
     if (a.stagger && blockIdx.x < 1024u) {
         const int k = (int)((blockIdx.x >> 5) & 31u);
         for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
     }
-#endif
     unsigned t = blockIdx.x;
     if (t >= a.tiles) return;
     int r1, r2, st;
@@ -240,12 +242,6 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
     packed_ids_check(a, x1, x2, r1, r2, st);
     packed_pass_issue<N, MODEL>(a.pack, r2, 0, buf0);        // passes 0..3: the pair's second point, 4..7: the first
     packed_pass_issue<N, MODEL>(a.pack, r2, 1, buf1);
-#ifdef SYMPA_PACKED_STAGGER_LATE          // (A/B: the first tile's head in flight while the wave sleeps)
-    if (a.stagger && blockIdx.x < 1024u) {
-        const int k = (int)((blockIdx.x >> 5) & 31u);
-        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
-    }
-#endif
     // the ids of the NEXT tile are always one tile ahead of the passes that need them (loaded behind the previous prefetch)
     unsigned tn = t + gridDim.x;
     bool more = tn < a.tiles;                      // wave-uniform
