@@ -103,6 +103,17 @@ __device__ __forceinline__ lds_ptr_t lds_dest(const void* p) {
     return (lds_ptr_t)(unsigned)reinterpret_cast<unsigned long long>(p);
 #pragma clang diagnostic pop
 }
+// The same from a SCALAR offset: a wave's tile starts at (threadIdx.x >> 6) * WAVE_SLOTS -- wave-uniform, but a vector value to the
+// compiler, so every DMA instruction paid a v_mad + v_readfirstlane for its M0.  lds_offset_uniform() says it once per gather.
+__device__ __forceinline__ unsigned lds_offset_uniform(const void* p) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<unsigned long long>(p));
+}
+__device__ __forceinline__ lds_ptr_t lds_dest_at(const unsigned offset) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    return (lds_ptr_t)offset;
+#pragma clang diagnostic pop
+}
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // (Masking the lanes of the 4 chunks per row that hold only lower-triangle entries off the DMA instruction
@@ -121,14 +132,14 @@ __device__ __forceinline__ int group_bcast(const int v) {
 template <int N, int J>
 struct DmaIssue {
     static __device__ __forceinline__ void run(const double* __restrict__ base, const int row, const int c,
-                                               v2d* __restrict__ side) {
+                                               const unsigned side) {
         constexpr int C = DmaTile<N>::C;
         const int rr = group_bcast<C, J>(row);
         // 32-bit byte offset from the (wave-uniform) table base: scalar base + vector offset addressing, no 64-bit
         // address arithmetic per instruction (tables of n <= 4 are limited to 4 GiB, checked on the host)
         const unsigned off = (unsigned)rr * (unsigned)(16 * N * N) + (unsigned)(16 * c);
         const char* src = reinterpret_cast<const char*>(base) + off;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(side + J * DmaTile<N>::INSTR_SLOTS), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest_at(side + (unsigned)(J * DmaTile<N>::INSTR_SLOTS) * 16u), 16, 0, 0);
         if constexpr (J + 1 < C) DmaIssue<N, J + 1>::run(base, row, c, side);
     }
 };
@@ -138,7 +149,7 @@ __device__ __forceinline__ void dma_issue(const double* __restrict__ base, const
     constexpr int C = DmaTile<N>::C;
     const int lane = threadIdx.x & 63;
     const int c = lane % C;
-    DmaIssue<N, 0>::run(base, row, c, side);
+    DmaIssue<N, 0>::run(base, row, c, lds_offset_uniform(side));
 }
 
 template <int N>
@@ -215,11 +226,11 @@ __device__ __forceinline__ void gather_pair_dma_low(const double* __restrict__ b
 template <int P, int J>
 struct DmaIssuePass4 {
     static __device__ __forceinline__ void run(const double* __restrict__ base, const int row, const int c,
-                                               v2d* __restrict__ buf) {
+                                               const unsigned buf) {
         const int rr = group_bcast<16, 4 * P + J>(row);
         const unsigned off = (unsigned)rr * 256u + (unsigned)(16 * c);
         const char* src = reinterpret_cast<const char*>(base) + off;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + J * DmaTile<4>::INSTR_SLOTS), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest_at(buf + (unsigned)(J * DmaTile<4>::INSTR_SLOTS) * 16u), 16, 0, 0);
         if constexpr (J + 1 < 4) DmaIssuePass4<P, J + 1>::run(base, row, c, buf);
     }
 };
@@ -257,8 +268,8 @@ __device__ __forceinline__ void pass4_step(const double* __restrict__ base1, con
     if constexpr (S + 1 < 8) {
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): reads of the buffer being refilled are complete
         wave_lds_fence();
-        if constexpr (S + 1 < 4) DmaIssuePass4<S + 1, 0>::run(base1, row1, c, nxt);
-        else DmaIssuePass4<S + 1 - 4, 0>::run(base2, row2, c, nxt);
+        if constexpr (S + 1 < 4) DmaIssuePass4<S + 1, 0>::run(base1, row1, c, lds_offset_uniform(nxt));
+        else DmaIssuePass4<S + 1 - 4, 0>::run(base2, row2, c, lds_offset_uniform(nxt));
         __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): the 4 DMAs of step S have landed
     } else {
         __builtin_amdgcn_s_waitcnt(0x0070);
@@ -277,7 +288,7 @@ __device__ __forceinline__ void gather_pair_pass4(const double* __restrict__ bas
 #pragma unroll
         for (int j = 0; j < 4; ++j) { z1.re[i][j] = 0.0; z1.im[i][j] = 0.0; z2.re[i][j] = 0.0; z2.im[i][j] = 0.0; }
     const int c = (threadIdx.x & 63) & 15;
-    DmaIssuePass4<0, 0>::run(base1, row1, c, tile);
+    DmaIssuePass4<0, 0>::run(base1, row1, c, lds_offset_uniform(tile));
     pass4_step<0>(base1, row1, base2, row2, tile, tile + PASS4_BUF_SLOTS, c, z1, z2);
 }
 
