@@ -124,8 +124,10 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // (C = 4: DPP quad_perm [j,j,j,j]) -- one VALU move instead of a ds_bpermute round trip through the LDS.
 template <int C, int J>
 __device__ __forceinline__ int group_bcast(const int v) {
-    if constexpr (C == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);
-    else if constexpr (C == 4) return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+    // (bound_ctrl = true: every lane has a valid source under these controls, so nothing changes in the result -- but the old value of
+    // the destination no longer matters and the compiler stops initialising the register in front of every DPP move)
+    if constexpr (C == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true);
+    else if constexpr (C == 4) return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, true);
     else return __shfl(v, J + C * ((int)(threadIdx.x & 63) / C));
 }
 
