@@ -128,6 +128,15 @@ SYMPA_UNROLL
             tile[lane * PITCH + N * N + i * N + j] = zero ? 0.0 : g.im[i][j];
         }
     wave_lds_fence();
+    if (live_pairs == 64) {                          // wave-uniform: a full wave needs no predicate (a save / restore of EXEC and a
+#pragma unroll 4                                       // branch per store otherwise: 256 scalar instructions per wave at n = 4)
+        for (int t = 0; t < ROWD; ++t) {
+            const int gidx = t * 64 + lane;
+            const int p = gidx / ROWD, e = gidx - p * ROWD;
+            __builtin_nontemporal_store(tile[p * PITCH + e], out_wave + gidx);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int t = 0; t < ROWD; ++t) {
         const int gidx = t * 64 + lane;
