@@ -381,35 +381,33 @@ __device__ __forceinline__ void pass_issue(const double* __restrict__ base, cons
                                            v2d* __restrict__ buf, const int my_chunk) {
     constexpr int K = PassTile<N, MASKED>::K;
     const int lane = threadIdx.x & 63;
-#ifndef SYMPA_OLD_PASS_ISSUE          // (tools/build_variant.sh: the per-instruction form for an A/B)
-    if constexpr (!MASKED) {
-        // one lane mask around the pass instead of a save / restore of EXEC per instruction; the row indices are read in front of
-        // it (behind the branch the compiler may compute `row` for the active lanes only, and a pass reads lanes K..63 as well)
-        int rr[PassTile<N>::ROWS];
+#ifndef SYMPA_OLD_PASS_ISSUE          // (tools/build_variant.sh -DSYMPA_OLD_PASS_ISSUE: the per-instruction form for an A/B)
+    // One lane mask around the pass instead of a save / restore of EXEC per instruction, the LDS destinations without a null check
+    // (lds_dest); the row indices are read (v_readlane: a scalar base address per row) IN FRONT of the mask -- behind the branch the
+    // compiler may compute `row` for the active lanes only, and a pass reads lanes K..63 as well.  Both models since the end of
+    // round 5: the masked gather of the bounded model used __shfl per instruction (a ds_bpermute + wait + v_readfirstlane each)
+    // because v_readlane alone had regressed its dims-8 kernel (245 -> 283 us); in this structure it gains -- bounded dense forward
+    // per 262 144 pairs: n = 7 201.7 -> 139.7 us, n = 6 101.1 -> 95.2, n = 5 64.3 -> 56.5, n = 8 237.9 -> 237.7; upper: block 9 of
+    // profiles/r05_packed_forward.txt.
+    int rr[PassTile<N>::ROWS];
 #pragma unroll
-        for (int j = 0; j < PassTile<N>::ROWS; ++j) rr[j] = __builtin_amdgcn_readlane(row, 16 * pass + j);
-        if (K == 64 || lane < K) {
+    for (int j = 0; j < PassTile<N>::ROWS; ++j) rr[j] = __builtin_amdgcn_readlane(row, 16 * pass + j);
+    if (K == 64 || lane < K) {
 #pragma unroll
-            for (int j = 0; j < PassTile<N>::ROWS; ++j) {
-                const double* src = base + (int64_t)rr[j] * (2 * N * N) + 2 * my_chunk;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
-            }
+        for (int j = 0; j < PassTile<N>::ROWS; ++j) {
+            const double* src = base + (int64_t)rr[j] * (2 * N * N) + 2 * my_chunk;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
         }
-        return;
     }
-#endif
+#else
 #pragma unroll
     for (int j = 0; j < PassTile<N>::ROWS; ++j) {
-        // full rows (upper model): v_readlane -- the source lane is a compile-time constant, the row index arrives in a scalar
-        // register and the row's base address is scalar arithmetic.  __shfl makes this a ds_bpermute + wait + v_readfirstlane per
-        // DMA instruction, 128 serialised LDS round trips per wave: upper n = 8 135.4 -> 130.8 us, n = 7 119.3 -> 114.7 per 262 144
-        // pairs (profiles/r05_packed_forward.txt).  The masked form (bounded model) keeps __shfl: with v_readlane its n = 8
-        // kernel allocates differently and runs 245 -> 283 us.
         const int rr = MASKED ? __shfl(row, 16 * pass + j) : __builtin_amdgcn_readlane(row, 16 * pass + j);
         const double* src = base + (int64_t)rr * (2 * N * N) + 2 * my_chunk;
         if (K == 64 || lane < K)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
     }
+#endif
 }
 
 template <int N, bool MASKED>
