@@ -344,6 +344,9 @@ extern "C" int sympa_hostsim_table(int op, int model, int n, const double* z, co
         case 2: return run_table<2>(op, model, z, g, out, b, lr, wd, eps, projected);
         case 3: return run_table<3>(op, model, z, g, out, b, lr, wd, eps, projected);
         case 4: return run_table<4>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 5: return run_table<5>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 6: return run_table<6>(op, model, z, g, out, b, lr, wd, eps, projected);
+        case 7: return run_table<7>(op, model, z, g, out, b, lr, wd, eps, projected);
         case 8: return run_table<8>(op, model, z, g, out, b, lr, wd, eps, projected);
         default: return -2;
     }

@@ -18,7 +18,7 @@ def relmax(got, want):
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 6, 7, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_hostsim_backward_matches_reference_autograd(model, n):
     g = np.load(f"{GOLDEN}/autograd_{model}_n{n}.npz")
@@ -104,7 +104,7 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 3, 4, 6, 7, 8, 12])     # 7: eight lanes per pair where default; 12: sixteen lanes per pair
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 12, 16])     # 5: QL with vectors; 7: eight lanes per pair where default; 12, 16: sixteen lanes
 @pytest.mark.parametrize("model", MODELS)
 def test_gpu_backward_golden(dev, model, n):
     from sympa_amd import ops

@@ -47,6 +47,35 @@ def test_golden_vectors_of_the_reference(dev, model, n):
             assert rel_err(vvd, g[f"{case}__vvd_exact50"]) < (1e-12 if model == "upper" else 1e-9)
 
 
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_far_golden_vectors_of_the_reference(dev, model, n):
+    """Round 6: the reference's clamp-regime (`far`) outputs at dims 5..8 (tools/make_golden.py --round6) through the dense
+    kernels AND the packed-table path, with the 50-digit evaluation of the reference formula for the vector-valued distance."""
+    from sympa_amd import ops
+    g = np.load(f"{GOLDEN}/dist_far_{model}_n{n}.npz")
+    for case in g["case_names"]:
+        z1, z2 = g[f"{case}__z1"], g[f"{case}__z2"]
+        b = z1.shape[0]
+        table = torch.cat((T(z1), T(z2))).to(dev)
+        ids = torch.stack((torch.arange(b), torch.arange(b) + b), 1).to(dev)
+        pack = ops.PackedTable(model)
+        for metric in METRICS:
+            # 1e-4 = north_star; it is the REFERENCE's fp64 error here (its riem against the 50-digit evaluation of its own formula
+            # reaches 8.8e-5 at n = 7, 8), see tests/test_hostsim_parity.py::test_golden_far
+            got = gpu_dist(z1, z2, model, metric, g["wsum_weights"])
+            assert rel_err(got, g[f"{case}__{metric}"]) < 1e-4, (model, n, case, metric)
+            w = T(g["wsum_weights"]).reshape(-1).to(dev)
+            packed = ops.model_forward_packed(pack.ensure(table), ids, metric, w)
+            ops.check_status(dev)
+            assert rel_err(packed.cpu(), g[f"{case}__{metric}"]) < 1e-4, (model, n, case, metric, "packed")
+            if metric == "riem":
+                exact = np.sqrt((g[f"{case}__vvd_exact50"] ** 2).sum(1))
+                assert rel_err(got, exact) < 1e-9 and rel_err(packed.cpu(), exact) < 1e-8, (model, n, case)
+        _, vvd = gpu_dist(z1, z2, model, "riem", vvd=True)
+        assert rel_err(vvd, g[f"{case}__vvd_exact50"]) < 1e-8, (model, n, case)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("model", MODELS)
 def test_against_oracle_seeded(dev, model, n):

@@ -12,6 +12,11 @@ TOL = 1e-9
 # 'far' (and the tail of 's1.0' at n=8) = the regime 1 - d in [1e-8, 1e-5] where the reference's own fp64 evaluation carries ~1e-7
 # error (see vvd_exact50); there we hold 1e-6 against the reference and 1e-12 against the exact value.
 TOL_FAR_VS_REFERENCE = 1e-6
+TOL_FAR_REFERENCE_LARGE_N = 1e-4     # dims 5..8 (tests/golden/dist_far_*): see test_golden_far
+
+
+def out_riem(z1, z2, model):
+    return hostsim_dist(z1, z2, model, "riem")[0]
 
 
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
@@ -30,6 +35,26 @@ def test_golden(model, n):
             # the disc representation itself), so 1e-9 there; upper model: 1e-12
             tol_exact = 1e-12 if model == "upper" else 1e-9
             assert rel_err(vvd, g[f"{case}__vvd_exact50"]) < tol_exact, (model, n, case)
+
+
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", MODELS)
+def test_golden_far(model, n):
+    """Round 6: the reference's `far` (clamp-regime) outputs at dims 5..8 and their 50-digit evaluation."""
+    g = np.load(f"{GOLDEN}/dist_far_{model}_n{n}.npz")
+    for case in g["case_names"]:
+        z1, z2 = g[f"{case}__z1"], g[f"{case}__z2"]
+        exact = g[f"{case}__vvd_exact50"]
+        for metric in METRICS:
+            out, vvd, st = hostsim_dist(z1, z2, model, metric, g["wsum_weights"])
+            assert st == 0
+            # against the reference: north_star's 1e-4.  What is left IS the reference's own fp64 error in this regime: its riem
+            # against the 50-digit evaluation of its own formula reaches 8.8e-5 at n = 7, 8 (2.2e-6 at n = 6) ...
+            assert rel_err(out, g[f"{case}__{metric}"]) < TOL_FAR_REFERENCE_LARGE_N, (model, n, case, metric)
+        # ... while the kernels' arithmetic holds 1e-8 against that evaluation (QL is accurate to eps * lambda_max absolutely: the
+        # smallest of eigenvalues spread over 1e10 keeps ~9 digits; Jacobi at n <= 4 keeps full relative accuracy)
+        assert rel_err(vvd, exact) < 1e-8, (model, n, case)
+        assert rel_err(out_riem(z1, z2, model), np.sqrt((exact ** 2).sum(1))) < 1e-9, (model, n, case)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])

@@ -40,7 +40,22 @@ def test_dist_matches_reference(golden_dir, model, n):
                                                               (got - want).abs().max().item())
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+@pytest.mark.parametrize("model", ["upper", "bounded"])
+def test_dist_far_matches_reference(golden_dir, model, n):
+    """Round 6: the clamp regime (1 - d ~ 1e-5 .. 1e-8) at dims 5..8, tools/make_golden.py --round6.  The reference's own fp64
+    evaluation carries ~1e-7 there (two LAPACK builds of the same formula differ by that much: see vvd_exact50), hence 1e-6."""
+    g = np.load(os.path.join(golden_dir, f"dist_far_{model}_n{n}.npz"))
+    w = T(g["wsum_weights"])
+    for case in g["case_names"]:
+        z1, z2 = T(g[f"{case}__z1"]), T(g[f"{case}__z2"])
+        for metric in METRICS:
+            got = so.manifold_dist(model, z1, z2, metric, w)
+            want = T(g[f"{case}__{metric}"])
+            assert close(got, want, rtol=1e-6, atol=1e-12), (model, n, case, metric, (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
 def test_primitives_match_reference(golden_dir, n):
     g = np.load(os.path.join(golden_dir, f"primitives_n{n}.npz"))
     zs, anyc, nonsym = T(g["upper_pts"]), T(g["csym"]), T(g["nonsym"])

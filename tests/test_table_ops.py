@@ -14,7 +14,7 @@ def relmax(got, want):
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
 def test_hostsim_against_reference_goldens(n):
     g = np.load(f"{GOLDEN}/primitives_n{n}.npz")
     assert relmax(hostsim_table("egrad2rgrad", "upper", g["upper_pts"], g["grad_in"])[0], g["upper_egrad2rgrad"]) < 1e-13
@@ -56,7 +56,7 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])     # 5, 6, 7: round 6 (tools/make_golden.py --round6)
 def test_gpu_manifold_methods_against_goldens(dev, n):
     from sympa_amd.manifolds import BoundedDomainManifold, UpperHalfManifold
     g = np.load(f"{GOLDEN}/primitives_n{n}.npz")

@@ -105,6 +105,60 @@ def mp_exact_vvd(model, z1, z2, eps="1e-5", dps=50):
     return np.array(out)
 
 
+def primitives_blob(n, g, sm, cay, tak, UH, BD):
+    """inputs and reference outputs of the primitives / manifold methods at dimension n (drawn from g in a fixed order)."""
+    b = 16
+    zs = upper_points(b, n, 0.5, g)
+    anyc = sm.to_symmetric(torch.randn(b, 2, n, n, generator=g))
+    nonsym = torch.randn(b, 2, n, n, generator=g)
+    realonly = anyc.clone(); realonly[:, 1] = 0
+    imagonly = anyc.clone(); imagonly[:, 0] = 0
+    prim = {
+        "upper_pts": zs.numpy(),
+        "csym": anyc.numpy(),
+        "nonsym": nonsym.numpy(),
+        "inverse_csym": sm.inverse(anyc).numpy(),
+        "inverse_nonsym": sm.inverse(nonsym).numpy(),
+        "inverse_realonly": sm.inverse(realonly).numpy(),
+        "inverse_imagonly": sm.inverse(imagonly).numpy(),
+        "matrix_sqrt_imag": sm.matrix_sqrt(sm.imag(zs)).numpy(),
+        "cayley_upper": cay.cayley_transform(zs).numpy(),
+        "bmm": sm.bmm(anyc, nonsym).numpy(),
+        "bmm3": sm.bmm3(anyc, nonsym, anyc).numpy(),
+        "compound": sm.to_compound_symmetric(anyc).numpy(),
+        "takagi_values": tak.TakagiFactorization(n, return_eigenvectors=False).factorize(anyc).numpy(),
+    }
+    bounded_pts = cay.cayley_transform(zs)
+    prim["inverse_cayley_of_cayley"] = cay.inverse_cayley_transform(bounded_pts).numpy()
+    vals, s = tak.TakagiFactorization(n, return_eigenvectors=True).factorize(anyc)
+    diag = sm.diag_embed(vals)
+    prim["takagi_reconstruction"] = sm.bmm3(sm.conjugate(s), diag, sm.conj_trans(s)).numpy()
+    # projection of symmetric matrices with some negative eigenvalues
+    ysym = sym(torch.randn(b, n, n, generator=g))
+    proj, keep = sm.positive_conjugate_projection(ysym)
+    prim["pcp_in"] = ysym.numpy(); prim["pcp_out"] = proj.numpy(); prim["pcp_keep"] = keep.numpy()
+    # manifold ops the optimiser calls
+    u = torch.randn(b, 2, n, n, generator=g)
+    up = UH(dims=n)
+    bd = BD(dims=n)
+    prim["grad_in"] = u.numpy()
+    prim["upper_egrad2rgrad"] = up.egrad2rgrad(zs, u).numpy()
+    prim["bounded_egrad2rgrad"] = bd.egrad2rgrad(bounded_pts, u).numpy()
+    off = torch.randn(b, 2, n, n, generator=g)     # generic non-symmetric, Y indefinite
+    prim["projx_in"] = off.numpy()
+    prim["upper_projx"] = up.projx(off).numpy()
+    # intended bounded projx (bounded_domain.py:55-84) via the eigenvector Takagi variant
+    big = sm.to_symmetric(torch.randn(b, 2, n, n, generator=g))
+    bvals, bs = tak.TakagiFactorization(n, return_eigenvectors=True).factorize(big)
+    eps = 1e-5
+    dtil = sm.diag_embed(torch.clamp(bvals, max=1 - eps))
+    ztil = sm.bmm3(sm.conjugate(bs), dtil, sm.conj_trans(bs))
+    keepb = torch.all(bvals < 1 - eps, dim=-1, keepdim=True)
+    prim["bounded_projx_in"] = big.numpy()
+    prim["bounded_projx"] = torch.where(keepb.unsqueeze(-1).unsqueeze(-1).expand_as(big), big, ztil).numpy()
+    return prim
+
+
 def main():
     torch.set_default_dtype(torch.float64)
     sm, cay, tak, UH, BD, met = ref_shim.import_reference()
@@ -137,56 +191,7 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"dist_{model}_n{n}.npz"), **blob)
 
         # ---- primitives (pin the oracle function by function)
-        b = 16
-        zs = upper_points(b, n, 0.5, g)
-        anyc = sm.to_symmetric(torch.randn(b, 2, n, n, generator=g))
-        nonsym = torch.randn(b, 2, n, n, generator=g)
-        realonly = anyc.clone(); realonly[:, 1] = 0
-        imagonly = anyc.clone(); imagonly[:, 0] = 0
-        prim = {
-            "upper_pts": zs.numpy(),
-            "csym": anyc.numpy(),
-            "nonsym": nonsym.numpy(),
-            "inverse_csym": sm.inverse(anyc).numpy(),
-            "inverse_nonsym": sm.inverse(nonsym).numpy(),
-            "inverse_realonly": sm.inverse(realonly).numpy(),
-            "inverse_imagonly": sm.inverse(imagonly).numpy(),
-            "matrix_sqrt_imag": sm.matrix_sqrt(sm.imag(zs)).numpy(),
-            "cayley_upper": cay.cayley_transform(zs).numpy(),
-            "bmm": sm.bmm(anyc, nonsym).numpy(),
-            "bmm3": sm.bmm3(anyc, nonsym, anyc).numpy(),
-            "compound": sm.to_compound_symmetric(anyc).numpy(),
-            "takagi_values": tak.TakagiFactorization(n, return_eigenvectors=False).factorize(anyc).numpy(),
-        }
-        bounded_pts = cay.cayley_transform(zs)
-        prim["inverse_cayley_of_cayley"] = cay.inverse_cayley_transform(bounded_pts).numpy()
-        vals, s = tak.TakagiFactorization(n, return_eigenvectors=True).factorize(anyc)
-        diag = sm.diag_embed(vals)
-        prim["takagi_reconstruction"] = sm.bmm3(sm.conjugate(s), diag, sm.conj_trans(s)).numpy()
-        # projection of symmetric matrices with some negative eigenvalues
-        ysym = sym(torch.randn(b, n, n, generator=g))
-        proj, keep = sm.positive_conjugate_projection(ysym)
-        prim["pcp_in"] = ysym.numpy(); prim["pcp_out"] = proj.numpy(); prim["pcp_keep"] = keep.numpy()
-        # manifold ops the optimiser calls
-        u = torch.randn(b, 2, n, n, generator=g)
-        up = UH(dims=n)
-        bd = BD(dims=n)
-        prim["grad_in"] = u.numpy()
-        prim["upper_egrad2rgrad"] = up.egrad2rgrad(zs, u).numpy()
-        prim["bounded_egrad2rgrad"] = bd.egrad2rgrad(bounded_pts, u).numpy()
-        off = torch.randn(b, 2, n, n, generator=g)     # generic non-symmetric, Y indefinite
-        prim["projx_in"] = off.numpy()
-        prim["upper_projx"] = up.projx(off).numpy()
-        # intended bounded projx (bounded_domain.py:55-84) via the eigenvector Takagi variant
-        big = sm.to_symmetric(torch.randn(b, 2, n, n, generator=g))
-        bvals, bs = tak.TakagiFactorization(n, return_eigenvectors=True).factorize(big)
-        eps = 1e-5
-        dtil = sm.diag_embed(torch.clamp(bvals, max=1 - eps))
-        ztil = sm.bmm3(sm.conjugate(bs), dtil, sm.conj_trans(bs))
-        keepb = torch.all(bvals < 1 - eps, dim=-1, keepdim=True)
-        prim["bounded_projx_in"] = big.numpy()
-        prim["bounded_projx"] = torch.where(keepb.unsqueeze(-1).unsqueeze(-1).expand_as(big), big, ztil).numpy()
-        np.savez_compressed(os.path.join(OUT, f"primitives_n{n}.npz"), **prim)
+        np.savez_compressed(os.path.join(OUT, f"primitives_n{n}.npz"), **primitives_blob(n, g, sm, cay, tak, UH, BD))
 
         # ---- autograd goldens (for the backward kernel), moderate scale, distinct eigenvalues
         if n <= 4:
@@ -341,8 +346,51 @@ def dist_goldens_more(dims=(5, 6, 7, 12, 16)):
             print(f"  {os.path.basename(path)}  {os.path.getsize(path)} B")
 
 
+def goldens_round6():
+    """Round 6 (review item 8): the holes left by the earlier sets, each from its own RNG stream so that every existing fixture
+    stays byte-identical: reference-autograd goldens at n = 5 (QL with eigenvectors, one pair per lane) and n = 16 (sixteen lanes
+    per pair); primitives at n = 5, 6, 7; the `far` (clamp regime, 1 - d ~ 1e-5 .. 1e-8) case of `dist` at n = 5..8, with the
+    50-digit evaluation of the reference formula beside it (dist_far_{model}_n{n}.npz)."""
+    torch.set_default_dtype(torch.float64)
+    sm, cay, tak, UH, BD, met = ref_shim.import_reference()
+    autograd_goldens_large(dims=(5, 16))
+    for n in (5, 6, 7):
+        g = torch.Generator().manual_seed(20261004 + 1000 * n)
+        path = os.path.join(OUT, f"primitives_n{n}.npz")
+        np.savez_compressed(path, **primitives_blob(n, g, sm, cay, tak, UH, BD))
+        print(f"  {os.path.basename(path)}  {os.path.getsize(path)} B")
+    for n in (5, 6, 7, 8):
+        g = torch.Generator().manual_seed(20261005 + 1000 * n)
+        wsum_w = torch.linspace(-0.5, 1.5, n).reshape(1, n)
+        cases = {"far": (upper_points(12, n, 2.0, g), upper_points(12, n, 2.0, g)),
+                 "far1.5": (upper_points(12, n, 1.5, g), upper_points(12, n, 1.5, g))}
+        for model in ("upper", "bounded"):
+            blob = {"wsum_weights": wsum_w.numpy(), "case_names": np.array(sorted(cases))}
+            for name in sorted(cases):
+                z1, z2 = cases[name]
+                if model == "bounded":
+                    z1, z2 = cay.cayley_transform(z1), cay.cayley_transform(z2)
+                    z1, z2 = sm.to_symmetric(z1), sm.to_symmetric(z2)
+                blob[f"{name}__z1"] = z1.numpy()
+                blob[f"{name}__z2"] = z2.numpy()
+                blob[f"{name}__vvd_exact50"] = mp_exact_vvd(model, z1, z2)
+                for metric in METRICS:
+                    man = (UH if model == "upper" else BD)(dims=n, metric=met.MetricType.from_str(metric))
+                    if metric == "wsum":
+                        with torch.no_grad():
+                            man.metric.weights.copy_(wsum_w)
+                    with torch.no_grad():
+                        d = man.dist(z1, z2)
+                    blob[f"{name}__{metric}"] = d.detach().numpy()
+            path = os.path.join(OUT, f"dist_far_{model}_n{n}.npz")
+            np.savez_compressed(path, **blob)
+            print(f"  {os.path.basename(path)}  {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
-    if "--dist-more" in sys.argv:
+    if "--round6" in sys.argv:
+        goldens_round6()
+    elif "--dist-more" in sys.argv:
         dist_goldens_more()
     elif "--autograd-more" in sys.argv:          # round 3: dims 7 (eight lanes per pair) and 12 (sixteen lanes per pair)
         autograd_goldens_large(dims=(7, 12))
