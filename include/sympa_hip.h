@@ -190,6 +190,24 @@ int sympa_model_forward_batches(const double* table, int64_t num_rows, int n, co
 int64_t sympa_table_pack_bytes(int64_t num_rows, int n, int model);
 int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes, int32_t* status,
                      void* stream);
+
+/* Validity of a pack decided ON THE DEVICE (csrc/table_digest.hpp).  The reference writes its table through `.data`
+ * (sympa/embeddings.py:36-39 `self.embeds.data = self.manifold.projx(...)`; geoopt / torch-1.5 optimisers `p.data.add_(...)`), which
+ * no version counter sees, so a drop-in must not trust one.
+ * sympa_table_digest: one kernel reads `bytes` bytes at `data` (16-byte aligned, a multiple of 8) and sums a 64-bit position-
+ * weighted digest; its last block compares it with the one kept in `state` (caller-owned, SYMPA_DIGEST_STATE_BYTES of device memory,
+ * zeroed once by the caller), stores the new one and writes ((uint32_t*)state)[SYMPA_DIGEST_CHANGED_WORD] = 1 when the bytes
+ * changed since the previous call on this state (or with SYMPA_FLAG_DIGEST_FORCE), else 0.  No host synchronisation.
+ * sympa_table_pack_refresh = that digest of the table + sympa_table_pack whose blocks return at once when the word is 0: the pack
+ * is remade exactly when the table's bytes differ from those it was made from (first call on a zeroed state: always), on the
+ * stream, graph-capturable -- a replayed graph with an optimiser step in front repacks by itself.  Cost when nothing changed: one
+ * read of the table (measured: profiles/r06_pack_refresh.txt).  sympa_spd_table_pack_refresh: the same for sympa_spd_table_pack. */
+#define SYMPA_DIGEST_STATE_BYTES 32
+#define SYMPA_DIGEST_CHANGED_WORD 6
+#define SYMPA_FLAG_DIGEST_FORCE 1
+int sympa_table_digest(const void* data, int64_t bytes, void* state, int flags, void* stream);
+int sympa_table_pack_refresh(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes,
+                             void* digest_state, int flags, int32_t* status, void* stream);
 int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,
                                int64_t src_stride, const int64_t* dst, int64_t dst_stride, int64_t b, int model, int metric,
                                const double* metric_w, double eps, const double* scale, double scale_coef, double* out,
@@ -438,6 +456,8 @@ int sympa_spd_model_forward(const double* table, int64_t num_rows, int n, const 
  * flagged.  sympa_spd_table_pack_bytes returns 0 where no packed kernel exists (n < 6).  Replaces the per-pair factorisation inside
  * geoopt's SymmetricPositiveDefinite.dist (sympa/embeddings.py:70-72,142; parity UNPINNED like every spd entry). */
 int64_t sympa_spd_table_pack_bytes(int64_t num_rows, int n);
+int sympa_spd_table_pack_refresh(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, void* digest_state,
+                                 int flags, int32_t* status, void* stream);
 int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, int32_t* status,
                          void* stream);
 int sympa_spd_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,

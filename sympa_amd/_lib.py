@@ -24,6 +24,8 @@ SYMBOLS = (
     "sympa_model_forward_batches",
     "sympa_table_pack_bytes",
     "sympa_table_pack",
+    "sympa_table_digest",
+    "sympa_table_pack_refresh",
     "sympa_model_forward_packed",
     "sympa_model_forward_batches_packed",
     "sympa_all_pairs_dist",
@@ -53,6 +55,7 @@ SYMBOLS = (
     "sympa_spd_model_forward",
     "sympa_spd_table_pack_bytes",
     "sympa_spd_table_pack",
+    "sympa_spd_table_pack_refresh",
     "sympa_spd_model_forward_packed",
     "sympa_scatter_add_flat_rows",
     "sympa_spd_backward_rows",
@@ -272,6 +275,14 @@ def load():
     lib.sympa_table_pack_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
     lib.sympa_table_pack.restype = C.c_int
     lib.sympa_table_pack.argtypes = [_c_double_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, _c_i32_p, C.c_void_p]
+    lib.sympa_table_digest.restype = C.c_int
+    lib.sympa_table_digest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.sympa_table_pack_refresh.restype = C.c_int
+    lib.sympa_table_pack_refresh.argtypes = [_c_double_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                             _c_i32_p, C.c_void_p]
+    lib.sympa_spd_table_pack_refresh.restype = C.c_int
+    lib.sympa_spd_table_pack_refresh.argtypes = [_c_double_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, _c_i32_p,
+                                                 C.c_void_p]
     lib.sympa_model_forward_packed.restype = C.c_int
     lib.sympa_model_forward_packed.argtypes = [
         C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_i64_p, C.c_int64, _c_i64_p, C.c_int64, C.c_int64, C.c_int, C.c_int,

@@ -3,6 +3,7 @@
 // Compiled like siegel_dist_big.hip without the pre-RA machine scheduler (__graft_entry__.py: the fully unrolled dims-8 bodies keep
 // the source order).
 #include "siegel_packed_kernel.hpp"
+#include "table_digest.hpp"
 
 namespace {
 using namespace sympa_hip;
@@ -14,16 +15,39 @@ int pack_row_doubles(int n, int model) {
 }
 
 int cu_count() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
+    static int cached[16] = {0};          // by device ordinal: the attribute query is not free in front of a ~100 us kernel
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int cus = cached[dev];
+    if (cus <= 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
     return cus;
 }
 
 template <int N>
-int pack_n(const double* table, int64_t num_rows, int model, double* pack, int32_t* status, hipStream_t s) {
-    return model == SYMPA_MODEL_UPPER ? launch_table_pack<N, sympa::MODEL_UPPER>(table, num_rows, pack, status, s)
-                                      : launch_table_pack<N, sympa::MODEL_BOUNDED>(table, num_rows, pack, status, s);
+int pack_n(const double* table, int64_t num_rows, int model, double* pack, int32_t* status, const unsigned* guard, hipStream_t s) {
+    return model == SYMPA_MODEL_UPPER ? launch_table_pack<N, sympa::MODEL_UPPER>(table, num_rows, pack, status, guard, s)
+                                      : launch_table_pack<N, sympa::MODEL_BOUNDED>(table, num_rows, pack, status, guard, s);
+}
+
+int pack_any(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes, int32_t* status,
+             const unsigned* guard, hipStream_t s) {
+    if (!packed_dims_ok(n)) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed table: dims 5..8");
+    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
+    if (table == nullptr || num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (pack == nullptr || pack_bytes < sympa_table_pack_bytes(num_rows, n, model) || (reinterpret_cast<uintptr_t>(pack) & 15))
+        return fail(SYMPA_ERR_BAD_ARG, "packed table: a 16-byte aligned buffer of sympa_table_pack_bytes(num_rows, n, model) bytes");
+    double* p = reinterpret_cast<double*>(pack);
+    switch (n) {
+        case 5: return pack_n<5>(table, num_rows, model, p, status, guard, s);
+        case 6: return pack_n<6>(table, num_rows, model, p, status, guard, s);
+        case 7: return pack_n<7>(table, num_rows, model, p, status, guard, s);
+        case 8: return pack_n<8>(table, num_rows, model, p, status, guard, s);
+        default: break;
+    }
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed table: dims 5..8");
 }
 
 template <int N>
@@ -128,21 +152,19 @@ int64_t sympa_table_pack_bytes(int64_t num_rows, int n, int model) {
 
 int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes, int32_t* status,
                      void* stream) {
+    return pack_any(table, num_rows, n, model, pack, pack_bytes, status, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int sympa_table_pack_refresh(const double* table, int64_t num_rows, int n, int model, void* pack, int64_t pack_bytes,
+                             void* digest_state, int flags, int32_t* status, void* stream) {
     if (!packed_dims_ok(n)) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed table: dims 5..8");
-    if (model != SYMPA_MODEL_UPPER && model != SYMPA_MODEL_BOUNDED) return fail(SYMPA_ERR_BAD_ARG, "unknown model");
     if (table == nullptr || num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
-    if (pack == nullptr || pack_bytes < sympa_table_pack_bytes(num_rows, n, model) || (reinterpret_cast<uintptr_t>(pack) & 15))
-        return fail(SYMPA_ERR_BAD_ARG, "packed table: a 16-byte aligned buffer of sympa_table_pack_bytes(num_rows, n, model) bytes");
+    if (digest_state == nullptr) return fail(SYMPA_ERR_BAD_ARG, "pack refresh: null digest state");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    double* p = reinterpret_cast<double*>(pack);
-    switch (n) {
-        case 5: return pack_n<5>(table, num_rows, model, p, status, s);
-        case 6: return pack_n<6>(table, num_rows, model, p, status, s);
-        case 7: return pack_n<7>(table, num_rows, model, p, status, s);
-        case 8: return pack_n<8>(table, num_rows, model, p, status, s);
-        default: break;
-    }
-    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "packed table: dims 5..8");
+    const int rc = launch_table_digest(table, num_rows * (int64_t)(16 * n * n), digest_state, (flags & SYMPA_FLAG_DIGEST_FORCE) ? 1 : 0, s);
+    if (rc != 0) return rc;
+    return pack_any(table, num_rows, n, model, pack, pack_bytes, status,
+                    reinterpret_cast<const unsigned*>(digest_state) + DIGEST_GUARD_WORD, s);
 }
 
 int sympa_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,

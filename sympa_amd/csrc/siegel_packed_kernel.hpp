@@ -56,8 +56,11 @@ constexpr int packed_dims_ok(int n) { return n >= 5 && n <= 8; }
 // ---- (1) pack ---------------------------------------------------------------------------------------------------------------
 template <int N, int MODEL>
 __global__ __launch_bounds__(64) void table_pack_kernel(const double* __restrict__ table, const int64_t num_rows,
-                                                        double* __restrict__ pack, int32_t* status) {
+                                                        double* __restrict__ pack, int32_t* status, const unsigned* guard) {
     using R = PackRow<N, MODEL>;
+    // sympa_table_pack_refresh: the digest kernel in front (table_digest.hpp) left 0 here when the table's bytes are those the
+    // pack was made from -- nothing to do (wave-uniform scalar load)
+    if (guard != nullptr && __builtin_nontemporal_load(guard) == 0u) return;
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t ii = i < num_rows ? i : num_rows - 1;
     sympa::CMat<N> z;
@@ -497,18 +500,26 @@ __global__ __launch_bounds__(64, 1) void dense_forward_kernel(const PackedArgs a
 }
 
 template <int N, int MODEL>
-int launch_table_pack(const double* table, int64_t num_rows, double* pack, int32_t* status, hipStream_t s) {
+int launch_table_pack(const double* table, int64_t num_rows, double* pack, int32_t* status, const unsigned* guard, hipStream_t s) {
     hipLaunchKernelGGL((table_pack_kernel<N, MODEL>), dim3((unsigned)((num_rows + 63) / 64)), dim3(64), 0, s, table, num_rows, pack,
-                       status);
+                       status, guard);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 
 // persistent grid: as many one-wave blocks as the chip holds at once (registers / LDS of the instantiation)
+// (asked of the runtime ONCE per kernel instantiation and device: the query sits in front of a ~100 us kernel and inside graph
+// captures otherwise -- round-5 advice)
 template <class K>
 unsigned resident_blocks(K kern, unsigned cus) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    static int cached[16] = {0};          // per instantiation of this template, by device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int per_cu = cached[dev];
+    if (per_cu <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        cached[dev] = per_cu;
+    }
     return cus * (unsigned)per_cu;
 }
 

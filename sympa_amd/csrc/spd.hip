@@ -2,11 +2,14 @@
 #include "siegel_common.hpp"
 #include "spd_coop.hpp"
 #include "spd_math.hpp"
+#include "table_digest.hpp"
 
 namespace {
 using namespace sympa_hip;
 
-__global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const int n) {
+// `row`: doubles per table row -- n * n, or n (n + 1) over a PACKED table (sympa_spd_table_pack: the upper triangle of its n x n image
+// is the point, which is all spd_pair_distance reads): the one-lane kernel a demoted packed instantiation falls back to
+__global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const int n, const int64_t row) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = i < a.b;
     const int64_t ii = live ? i : a.b - 1;
@@ -20,7 +23,6 @@ __global__ __launch_bounds__(64) void spd_dist_kernel(const DistArgs a, const in
         r2 = a.idx2[ii * a.idx2_stride];
         if (r1 < 0 || r1 >= a.num_rows || r2 < 0 || r2 >= a.num_rows) { st |= sympa::ST_BAD_INDEX; r1 = 0; r2 = 0; }
     }
-    const int64_t row = (int64_t)n * n;
     sympa::SpdWork w;
     double d = sympa::spd_pair_distance(w, a.base1 + r1 * row, a.base2 + r2 * row, n, st);
     if (st & sympa::ST_BAD_INDEX) d = __builtin_nan("");
@@ -241,8 +243,9 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
 // definite: every pair it enters then comes out NaN and is flagged)
 template <int M>
 __global__ __launch_bounds__(64) void spd_pack_kernel(const double* __restrict__ table, const int64_t num_rows, double* __restrict__ pack,
-                                                      int32_t* status) {
+                                                      int32_t* status, const unsigned* guard) {
     using namespace spd_coop;
+    if (guard != nullptr && __builtin_nontemporal_load(guard) == 0u) return;      // sympa_spd_table_pack_refresh: table unchanged
     const int lane = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
     const int64_t i = (int64_t)blockIdx.x * GROUPS_PER_WAVE + g;
@@ -292,8 +295,10 @@ int launch_spd(const DistArgs& a, int n, void* stream, const bool packed = false
             default: break;
         }
     } else {
-        if (packed) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed forward: dims 6..16 (the sixteen-lanes-per-pair kernel)");
-        hipLaunchKernelGGL(spd_dist_kernel, grid, dim3(64), 0, s, a, n);
+        // (packed with the instantiation demoted by the self-check, sympa_set_instance_fallback: the one-lane kernel over the pack's
+        // images -- round-5 advice: the packed entry used to fail here while the dense entry fell back)
+        if (packed && n < 6) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed forward: dims 6..16");
+        hipLaunchKernelGGL(spd_dist_kernel, grid, dim3(64), 0, s, a, n, packed ? (int64_t)n * (n + 1) : (int64_t)n * n);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -348,8 +353,9 @@ int64_t sympa_spd_table_pack_bytes(int64_t num_rows, int n) {
     return num_rows * (int64_t)(n * (n + 1)) * 8;
 }
 
-int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, int32_t* status,
-                         void* stream) {
+namespace {
+int spd_pack_any(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, int32_t* status, const unsigned* guard,
+                 void* stream) {
     if (n < 6 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed table: dims 6..16");
     if (table == nullptr || num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
     if (pack == nullptr || pack_bytes < sympa_spd_table_pack_bytes(num_rows, n) || (reinterpret_cast<uintptr_t>(pack) & 15))
@@ -358,7 +364,7 @@ int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pac
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     double* p = reinterpret_cast<double*>(pack);
     switch (n) {
-#define SYMPA_SPD_PACK_CASE(MM) case MM: hipLaunchKernelGGL(spd_pack_kernel<MM>, grid, dim3(64), 0, s, table, num_rows, p, status); break;
+#define SYMPA_SPD_PACK_CASE(MM) case MM: hipLaunchKernelGGL(spd_pack_kernel<MM>, grid, dim3(64), 0, s, table, num_rows, p, status, guard); break;
         SYMPA_SPD_PACK_CASE(6) SYMPA_SPD_PACK_CASE(7) SYMPA_SPD_PACK_CASE(8) SYMPA_SPD_PACK_CASE(9) SYMPA_SPD_PACK_CASE(10)
         SYMPA_SPD_PACK_CASE(11) SYMPA_SPD_PACK_CASE(12) SYMPA_SPD_PACK_CASE(13) SYMPA_SPD_PACK_CASE(14) SYMPA_SPD_PACK_CASE(15)
         SYMPA_SPD_PACK_CASE(16)
@@ -367,6 +373,24 @@ int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pac
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+}  // namespace
+
+int sympa_spd_table_pack(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, int32_t* status,
+                         void* stream) {
+    return spd_pack_any(table, num_rows, n, pack, pack_bytes, status, nullptr, stream);
+}
+
+int sympa_spd_table_pack_refresh(const double* table, int64_t num_rows, int n, void* pack, int64_t pack_bytes, void* digest_state,
+                                 int flags, int32_t* status, void* stream) {
+    if (n < 6 || n > sympa::SPD_MAX_N) return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "spd packed table: dims 6..16");
+    if (table == nullptr || num_rows <= 0) return fail(SYMPA_ERR_BAD_ARG, "empty table");
+    if (digest_state == nullptr) return fail(SYMPA_ERR_BAD_ARG, "pack refresh: null digest state");
+    const int rc = launch_table_digest(table, num_rows * (int64_t)(8 * n * n), digest_state, (flags & SYMPA_FLAG_DIGEST_FORCE) ? 1 : 0,
+                                       reinterpret_cast<hipStream_t>(stream));
+    if (rc != 0) return rc;
+    return spd_pack_any(table, num_rows, n, pack, pack_bytes, status,
+                        reinterpret_cast<const unsigned*>(digest_state) + DIGEST_GUARD_WORD, stream);
 }
 
 int sympa_spd_model_forward_packed(const void* pack, int64_t pack_bytes, int64_t num_rows, int n, const int64_t* src,

@@ -33,7 +33,7 @@ class _SpdBatches:
         m = self.model
         pk = m.packed_table()
         if pk is not None and sum(int(t.shape[0]) for t in self.batches) >= PACKED_MIN_PAIRS:
-            pk.ensure(m.embeddings.embeds)          # (one tuple comparison while the table's version has not moved)
+            pk.ensure(m.embeddings.embeds)          # (key comparison + the device-side digest check: ops.PackedTable)
             for t, o in zip(self.batches, self.outs):
                 ops.spd_model_forward_packed(pk, t, m.scale.data, m.scale_coef, out=o)
             return
@@ -109,11 +109,14 @@ class Model(nn.Module):
         return ops.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
 
     def packed_table(self):
-        """The ops.PackedTable of this model's embedding table (dims 5..8 of the Siegel models, n = 16 of the spd model, on the GPU;
-        None elsewhere, with
-        `model.use_packed = False` or SYMPA_NO_PACKED=1): upper triangles + inverted Cholesky factor per point, made once per
-        table version (the ManifoldParameter's torch version counter, which every sympa_amd optimiser step moves) and shared by
-        forward() under no_grad, forward_batches() and evaluate()."""
+        """The ops.PackedTable of this model's embedding table (dims 5..8 of the Siegel models, n in ops.SPD_PACKED_DIMS of the spd
+        model, on the GPU; None elsewhere, with `model.use_packed = False` or SYMPA_NO_PACKED=1, or while the self-check has demoted
+        the spd forward of these dims): upper triangles + inverted Cholesky factor per point, made once per table state and shared by
+        forward() under no_grad, forward_batches() and evaluate().  Whether the pack still is the table's image is decided by the
+        host key (storage, shape, torch version counter) AND, unless `packed_table().strict = False`, by a digest of the table's bytes
+        computed on the device in front of every use (one read of the table, no synchronisation): `.data` writes that move no version
+        counter (embeddings.py:36-39, torch-1.5 optimisers) are seen.  Costs a second table-sized device buffer while it lives
+        (`packed_table().invalidate(release=True)` frees it)."""
         if not self.__dict__.get("use_packed", True) or os.environ.get("SYMPA_NO_PACKED"):
             return None
         table = self.embeddings.embeds

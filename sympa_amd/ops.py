@@ -326,12 +326,22 @@ def table_changed(param):
 
 class PackedTable:
     """The packed image of a Siegel table for the INDEXED forward, dims 5..8 (C-ABI sympa_table_pack): one contiguous row per point
-    -- the upper triangles of both planes and the inverted Cholesky factor -- made ONCE per table version and reused by every
+    -- the upper triangles of both planes and the inverted Cholesky factor -- made ONCE per table state and reused by every
     batch until the table changes (Runner.evaluate's loop, runner.py:124-135; the N forward calls of the mAP matrix, runner.py:
-    142-154; Model.forward, model.py:16-30).  `ensure(table)` repacks when the table's storage, offset, shape or torch version
-    counter (`ManifoldParameter._version`: every in-place torch op and every sympa_amd optimiser step moves it, see
-    `table_changed`) differs from what was packed; it keeps a reference to the packed storage, so a freed table's address cannot
-    come back under the same key.  In-place writes through `.data` aliases that torch does not track need `invalidate()`."""
+    142-154; Model.forward, model.py:16-30).
+
+    Validity (round 6) does not depend on the caller's idiom.  The host key -- storage, offset, shape, torch version counter -- sees
+    every tracked in-place op and every sympa_amd optimiser step (`table_changed`); a moved key repacks unconditionally.  Writes
+    through `.data` (`p.data.add_()` of a torch-1.5 / geoopt optimiser; embeddings.py:36-39 assigns `embeds.data`) move no counter,
+    so with `strict` (the default) an UNCHANGED key is not trusted either: C-ABI sympa_table_pack_refresh reads the table once on
+    the device (a 64-bit digest, ~10 us for configs[3]'s 46.6 MB), compares it with the digest the pack was made from and
+    repacks in the same stream when they differ -- no host synchronisation, and inside a hipGraph capture the pair of kernels
+    is recorded, so a replayed graph repacks by itself after an optimiser step.  `strict = False` (or SYMPA_PACK_TRUST_VERSION=1)
+    trusts the key alone.
+    Memory: the pack is a second table-sized device buffer (0.84 x the table at n = 8) and the pack keeps the table's storage alive
+    (a freed table's address cannot return under the same key); `invalidate(release=True)` drops both."""
+
+    strict = os.environ.get("SYMPA_PACK_TRUST_VERSION", "0") in ("", "0")
 
     @staticmethod
     def supported(table, model):
@@ -342,12 +352,21 @@ class PackedTable:
         self.model = model
         self.key = None
         self.pack = None
-        self.repacks = 0
+        self.state = None          # SYMPA_DIGEST_STATE_BYTES of device memory: the digest the pack was made from
+        self.repacks = 0           # launches that repack unconditionally (new key); device-decided repacks: `device_repacks()`
+        self.refreshes = 0         # digest + guarded-pack launches
         self._src = None
+        self._stream = None
 
-    def invalidate(self):
+    def invalidate(self, release=False):
         self.key = None
         self._seen = None
+        if release:
+            self.pack = self.state = self._src = None
+
+    def device_repacks(self):
+        """How many times the device found the table's bytes changed (or was forced) -- one host read, for tests and profiles."""
+        return 0 if self.state is None else int(self.state.view(torch.int32)[7])
 
     @staticmethod
     def _key_of(table):
@@ -355,44 +374,73 @@ class PackedTable:
                 table.device)
 
     def current(self, table, pairs=0):
-        """True when the pack is that of `table` as it is now.  Otherwise the table's state is remembered and the pack is made
-        the SECOND time the same state is seen: a caller that alternates optimiser steps with single forward calls never pays
-        for a pack it would use once, a caller that runs batch after batch over an unchanged table packs before its second
-        batch.  (`ensure` packs at once: the list forms -- forward_batches, evaluate -- know they have many batches.)
-        The bounded model packs at FIRST sight when the call has at least 4 pairs per table row: its dense kernel factors
-        I - W W^H per pair, and one pack + the packed kernel beats it even for a single call (n = 8, 262 144 pairs of 45 500 rows:
-        27 + 163 us against 245; profiles/r05_packed_forward.txt)."""
-        key = PackedTable._key_of(table)
-        if key == self.key:
-            return True
-        if getattr(self, "_seen", None) == key or (self.model == "bounded" and pairs >= 4 * table.shape[0]):
-            self.ensure(table)
-            return True
+        """True when the pack is (after the launches this call enqueues) that of `table` as it is now.  Otherwise the table's
+        state is remembered and the pack is made the SECOND time the same state is seen: a caller that alternates optimiser
+        steps with single forward calls never pays for a pack it would use once, a caller that runs batch after batch over an
+        unchanged table packs before its second batch.  (`ensure` packs at once: the list forms -- forward_batches, evaluate
+        -- know they have many batches.)  The bounded model packs at FIRST sight when the call has at least 4 pairs per table
+        row: its dense kernel factors I - W W^H per pair, and one pack + the packed kernel beats it even for a single call
+        (n = 8, 262 144 pairs of 45 500 rows: 27 + 163 us against 245; profiles/r05_packed_forward.txt).
+        Inside a stream capture a pack is only used when its buffers exist already (nothing is allocated into the graph's
+        pool); the recorded launches then carry the device-side validity check whatever `strict` says."""
+        key = self._key_of(table)
+        if key == self.key or getattr(self, "_seen", None) == key or \
+                (self.model == "bounded" and pairs >= 4 * table.shape[0]):
+            return self.ensure(table, _or_none=True) is not None
         self._seen = key
         return False
 
-    def ensure(self, table):
-        st = table.untyped_storage()
-        key = PackedTable._key_of(table)
-        if key == self.key:
-            return self
-        lib = _lib.load()
-        if not PackedTable.supported(table, self.model):
-            raise ValueError("PackedTable: a contiguous float64 [N,2,n,n] device table of a Siegel model, dims 5..8")
-        num_rows, n = table.shape[0], table.shape[2]
-        need = int(lib.sympa_table_pack_bytes(num_rows, n, MODEL_IDS[self.model]))
-        if self.pack is None or self.pack.numel() != need or self.pack.device != table.device:
-            self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
+    # -- the two C calls of the subclasses ---------------------------------------------------------------------------------
+    def _need_bytes(self, lib, table):
+        return int(lib.sympa_table_pack_bytes(table.shape[0], table.shape[2], MODEL_IDS[self.model]))
+
+    def _refresh(self, lib, table, need, force, stream):
         # no status word for the pack: a point outside the manifold is reported by the PAIRS it enters (its inverted diagonal is
         # stored as NaN), like the reference, whose assertions sit in dist (siegel_manifold.py:64-66) -- a bad row no batch touches
         # raises nothing there either
+        return lib.sympa_table_pack_refresh(table.data_ptr(), table.shape[0], table.shape[2], MODEL_IDS[self.model],
+                                            self.pack.data_ptr(), need, self.state.data_ptr(), 1 if force else 0, None, stream)
+
+    def _dims_of(self, table):
+        return table.shape[2]
+
+    def ensure(self, table, strict=None, _or_none=False):
+        key = self._key_of(table)
+        same = key == self.key
+        capturing = torch.cuda.is_current_stream_capturing()
+        strict = self.strict if strict is None else strict
+        if same and not strict and not capturing:
+            return self
+        lib = _lib.load()
+        if not type(self).supported(table, self.model):
+            raise ValueError(f"{type(self).__name__}: a contiguous float64 device table of the '{self.model}' model at packed dims")
+        need = self._need_bytes(lib, table)
+        fresh = self.pack is None or self.pack.numel() != need or self.pack.device != table.device
+        if fresh:
+            if capturing:
+                # buffers allocated now would belong to the graph's pool and the host key would describe a pack that does not
+                # exist yet (capture runs nothing): the dense kernels serve this capture
+                if _or_none:
+                    return None
+                raise RuntimeError("PackedTable.ensure inside a stream capture needs a pack made before the capture")
+            self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
+            self.state = torch.zeros(32, dtype=torch.uint8, device=table.device)
+            self._stream = None
+        cur = torch.cuda.current_stream(table.device)
+        if self._stream is not None and self._stream != cur and not capturing:
+            # the pack was last written on another stream: order this one behind everything enqueued there
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+            cur.wait_event(ev)
         with torch.cuda.device(table.device):
-            rc = lib.sympa_table_pack(table.data_ptr(), num_rows, n, MODEL_IDS[self.model], self.pack.data_ptr(), need,
-                                      None, torch.cuda.current_stream(table.device).cuda_stream)
+            rc = self._refresh(lib, table, need, fresh or not same, cur.cuda_stream)
         _lib.check(rc)
-        self.key, self._src = key, st
-        self.num_rows, self.n, self.bytes = num_rows, n, need
-        self.repacks += 1
+        self.refreshes += 1
+        if not capturing:          # (a capture runs nothing: the key keeps describing what really is in the buffer)
+            if not same:
+                self.repacks += 1
+            self.key, self._src, self._stream = key, table.untyped_storage(), cur
+            self.num_rows, self.n, self.bytes = table.shape[0], self._dims_of(table), need
         return self
 
 
@@ -1178,13 +1226,17 @@ def spd_model_forward(table, triplets, scale=None, scale_coef=1.0, out=None, fla
 
 class SpdPackedTable(PackedTable):
     """PackedTable of the spd model (C-ABI sympa_spd_table_pack, n = 6..16): per point the n x n image [point's upper triangle |
-    unit factor Lh of x = Lh D Lh^T in the strict lower triangle] + D^-1/2, made once per table version -- the pair kernel then
-    skips the factorisation.  Same life cycle as PackedTable (`current` / `ensure` / `invalidate`)."""
+    unit factor Lh of x = Lh D Lh^T in the strict lower triangle] + D^-1/2, made once per table state -- the pair kernel then
+    skips the factorisation.  Same life cycle and device-side validity as PackedTable (`current` / `ensure` / `invalidate`).
+    Not offered (`supported` is False, Model.forward keeps the dense entry) while the self-check has demoted the sixteen-lanes
+    spd forward of these dims (selfcheck.py; the C entry itself then runs the one-lane kernel over the pack)."""
 
     @staticmethod
     def supported(table, model="spd"):
-        return (table.is_cuda and table.dtype == torch.float64 and table.dim() == 3 and table.shape[1] == table.shape[2]
-                and table.shape[1] in SPD_PACKED_DIMS and table.is_contiguous())
+        if not (table.is_cuda and table.dtype == torch.float64 and table.dim() == 3 and table.shape[1] == table.shape[2]
+                and table.shape[1] in SPD_PACKED_DIMS and table.is_contiguous()):
+            return False
+        return not _lib.load().sympa_get_instance_fallback(_sc.SPD_FWD, 0, int(table.shape[1]))
 
     def __init__(self, model="spd"):
         super().__init__("spd")
@@ -1194,35 +1246,15 @@ class SpdPackedTable(PackedTable):
         return (table.untyped_storage().data_ptr(), table.storage_offset(), table.shape[0], table.shape[1], table._version,
                 table.device)
 
-    def current(self, table, pairs=0):
-        key = SpdPackedTable._key_of(table)
-        if key == self.key:
-            return True
-        if getattr(self, "_seen", None) == key:
-            self.ensure(table)
-            return True
-        self._seen = key
-        return False
+    def _need_bytes(self, lib, table):
+        return int(lib.sympa_spd_table_pack_bytes(table.shape[0], table.shape[1]))
 
-    def ensure(self, table):
-        key = SpdPackedTable._key_of(table)
-        if key == self.key:
-            return self
-        lib = _lib.load()
-        if not SpdPackedTable.supported(table):
-            raise ValueError(f"SpdPackedTable: a contiguous float64 [N,n,n] device table, n in {sorted(SPD_PACKED_DIMS)}")
-        num_rows, n = table.shape[0], table.shape[1]
-        need = int(lib.sympa_spd_table_pack_bytes(num_rows, n))
-        if self.pack is None or self.pack.numel() != need or self.pack.device != table.device:
-            self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
-        with torch.cuda.device(table.device):
-            rc = lib.sympa_spd_table_pack(table.data_ptr(), num_rows, n, self.pack.data_ptr(), need,
-                                          None, torch.cuda.current_stream(table.device).cuda_stream)     # (as PackedTable.ensure)
-        _lib.check(rc)
-        self.key, self._src = key, table.untyped_storage()
-        self.num_rows, self.n, self.bytes = num_rows, n, need
-        self.repacks += 1
-        return self
+    def _refresh(self, lib, table, need, force, stream):
+        return lib.sympa_spd_table_pack_refresh(table.data_ptr(), table.shape[0], table.shape[1], self.pack.data_ptr(), need,
+                                                self.state.data_ptr(), 1 if force else 0, None, stream)
+
+    def _dims_of(self, table):
+        return table.shape[1]
 
 
 # the packed spd forward is used where it measured faster (profiles/r05_spd_packed_forward.txt: n = 13..15 spill at 256 registers

@@ -124,9 +124,23 @@ def _check_spd_fwd(model, n, dev):
     from sympa_amd import ops
     table, trip, _ = _inputs("spd", n, dev, 333)
     fast = ops.spd_model_forward(table, trip)
+    # the PACKED instantiation (spd16_coop_kernel<M, true>) is a separate inline-asm DPP binary (reduce_pair_front_factored): checked
+    # through the raw C entries, whatever ops.SPD_PACKED_DIMS offers
+    lib = _lib.load()
+    need = int(lib.sympa_spd_table_pack_bytes(table.shape[0], n))
+    packed = None
+    if need > 0:
+        pack = torch.empty(need, dtype=torch.uint8, device=dev)
+        packed = torch.empty(trip.shape[0], dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.sympa_spd_table_pack(table.data_ptr(), table.shape[0], n, pack.data_ptr(), need, None, stream))
+        tp, stride = trip.data_ptr(), trip.stride(0)
+        _lib.check(lib.sympa_spd_model_forward_packed(pack.data_ptr(), need, table.shape[0], n, tp, stride, tp + 8, stride,
+                                                      trip.shape[0], None, 1.0, packed.data_ptr(), ops._status_buf(dev).data_ptr(),
+                                                      0, stream))
     with _OneLane(SPD_FWD, "spd", n):
         slow = ops.spd_model_forward(table, trip)
-    return [_close(fast, slow, 1e-8)]
+    return [_close(fast, slow, 1e-8)] + ([] if packed is None else [_close(packed, slow, 1e-8)])
 
 
 def _check_spd_bwd(model, n, dev):

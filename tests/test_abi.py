@@ -45,6 +45,21 @@ def test_argument_validation_without_gpu():
     assert lib.sympa_model_forward(one, 0, 4, one, 2, one, 2, 8, 0, 0, None, 1e-5, None, 1.0, one, None, 0, None) == -1
 
 
+def test_digest_and_refresh_entries_validate_their_arguments_without_gpu():
+    lib = _lib.load()
+    one, al = ctypes.c_void_p(8), ctypes.c_void_p(64)   # never dereferenced
+    assert lib.sympa_table_digest(None, 64, al, 0, None) == -1
+    assert lib.sympa_table_digest(al, 64, None, 0, None) == -1
+    assert lib.sympa_table_digest(al, 0, al, 0, None) == -1
+    assert lib.sympa_table_digest(al, 12, al, 0, None) == -1          # not a multiple of 8
+    assert lib.sympa_table_digest(one, 64, al, 0, None) == -1         # data not 16-byte aligned
+    assert lib.sympa_table_pack_refresh(al, 10, 4, 0, al, 1 << 20, al, 0, None, None) == -2      # dims outside 5..8
+    assert lib.sympa_table_pack_refresh(al, 10, 8, 0, al, 1 << 20, None, 0, None, None) == -1    # no digest state
+    assert lib.sympa_table_pack_refresh(al, 0, 8, 0, al, 1 << 20, al, 0, None, None) == -1       # empty table
+    assert lib.sympa_spd_table_pack_refresh(al, 10, 3, al, 1 << 20, al, 0, None, None) == -2
+    assert lib.sympa_spd_table_pack_refresh(al, 10, 16, al, 1 << 20, None, 0, None, None) == -1
+
+
 def test_radam_entry_points_validate_their_arguments_without_gpu():
     lib = _lib.load()
     one = ctypes.c_void_p(16)   # never dereferenced: validation happens before any launch

@@ -358,3 +358,221 @@ def test_bounded_model_packs_at_first_sight_on_large_calls(dev):
         want = ops.model_forward(m.embeddings.embeds.data, big, "bounded", "finf", None, m.scale.data, m.scale_coef)
         assert rel_err(got.cpu(), want.cpu(), atol=1e-13) < 1e-12
     ops.check_status(dev)
+
+
+# ---- round 6: validity of the pack decided on the device (C-ABI sympa_table_digest / sympa_table_pack_refresh) -------------------
+
+def test_table_digest_sees_every_change(dev):
+    """sympa_table_digest: `changed` is 1 on the first call over a zeroed state, 0 while the bytes stay, 1 after ANY word changed
+    (first, last, a single low bit, two words swapped), 1 with SYMPA_FLAG_DIGEST_FORCE; odd word counts; the change counter."""
+    import ctypes
+    from sympa_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def digest(buf, state, flags=0):
+        _lib.check(lib.sympa_table_digest(buf.data_ptr(), buf.numel() * 8, state.data_ptr(), flags, stream))
+        return int(state.view(torch.int32)[6])
+
+    g = torch.Generator().manual_seed(5)
+    for words in (2, 3, 777, 1 << 20, (1 << 22) + 1):
+        buf = torch.randn(words, generator=g, dtype=torch.float64).to(dev)
+        state = torch.zeros(32, dtype=torch.uint8, device=dev)
+        assert digest(buf, state) == 1
+        assert digest(buf, state) == 0 and digest(buf, state) == 0
+        for pos in (0, words - 1, words // 2):
+            bits = buf.view(torch.int64)
+            bits[pos] ^= 1                                    # one ulp of one word
+            assert digest(buf, state) == 1, (words, pos)
+            assert digest(buf, state) == 0
+        if words >= 3:
+            a, b = buf[0].clone(), buf[words - 1].clone()
+            buf[0], buf[words - 1] = b, a                     # same multiset of words, different places
+            assert digest(buf, state) == 1
+        assert digest(buf, state, flags=1) == 1               # SYMPA_FLAG_DIGEST_FORCE
+        assert digest(buf, state) == 0
+        assert int(state.view(torch.int32)[7]) == (6 if words >= 3 else 5)
+        assert int(state.view(torch.int32)[4]) == 0 and int(state.view(torch.int64)[1]) == 0     # counter / accumulator reset
+
+
+@pytest.mark.parametrize("kind", ["upper8", "bounded7", "spd16"])
+def test_data_writes_that_move_no_version_counter_are_seen(dev, kind):
+    """The reference's era writes tables through `.data` (embeddings.py:36-39; torch-1.5 / geoopt optimisers `p.data.add_()`): no
+    torch version counter moves.  Between two no_grad forwards such a write must give the NEW distances (against the oracle)
+    without any invalidate(); the device found the change by itself (`device_repacks`), the host key never moved (`repacks`)."""
+    from sympa_amd import data, ops
+    from sympa_amd.model import Model
+    name, n = {"upper8": ("upper", 8), "bounded7": ("bounded", 7), "spd16": ("spd", 16)}[kind]
+
+    class A:
+        manifold, metric, dims, num_points = name, "riem", n, 700
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = (data.spd_table(700, n, scale=0.3, seed=3) if name == "spd"
+                                    else data.trained_like_table(700, n, model=name, seed=3))
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(2)
+    trip = torch.randint(0, 700, (8192, 3), generator=g).to(dev)
+
+    def oracle_now():
+        tab = m.embeddings.embeds.data.cpu()
+        sel = trip[:256].cpu()
+        if name == "spd":
+            return so.spd_dist(tab[sel[:, 0]], tab[sel[:, 1]])
+        return so.model_forward(tab, sel, name, "riem", scale=m.scale.data.cpu(), scale_coef=1.0)
+
+    pk = m.packed_table()
+    assert pk is not None and pk.strict
+    with torch.no_grad():
+        m(trip); a = m(trip).clone()                      # second call: packed
+        assert pk.repacks == 1 and pk.device_repacks() == 1
+        assert rel_err(a[:256].cpu(), oracle_now()) < 1e-8
+        m(trip)
+        assert pk.device_repacks() == 1                   # unchanged table: digest equal, the pack kernel returned at once
+        v = m.embeddings.embeds._version
+        if name == "bounded":
+            m.embeddings.embeds.data.mul_(0.97)           # stays inside the domain
+        else:
+            m.embeddings.embeds.data.mul_(1.01)           # Y (spd: X) stays positive definite
+        assert m.embeddings.embeds._version == v          # ... and torch saw nothing
+        b = m(trip).clone()
+        assert pk.repacks == 1 and pk.device_repacks() == 2
+        assert rel_err(b[:256].cpu(), oracle_now()) < 1e-8
+        assert not torch.allclose(a, b)
+        # the list forms check too
+        m.embeddings.embeds.data[5].mul_(1.0 + 1e-9)      # one row, nine digits down
+        c = m.forward_batches([trip])[0].clone()
+        assert pk.device_repacks() == 3
+        if name == "spd":
+            want = ops.spd_model_forward(m.embeddings.embeds.data, trip, m.scale.data, m.scale_coef)
+        else:
+            want = ops.model_forward(m.embeddings.embeds.data, trip, name, "riem", None, m.scale.data, m.scale_coef)
+        assert rel_err(c.cpu(), want.cpu(), atol=1e-13) < 1e-11
+        # strict off: the key alone is trusted (the documented round-5 behaviour) -- the write is NOT seen
+        pk.strict = False
+        m.embeddings.embeds.data.mul_(0.99 if name == "bounded" else 1.02)
+        stale = m(trip)
+        assert torch.equal(stale, c) and pk.device_repacks() == 3
+        pk.strict = True
+        fresh = m(trip)
+        assert pk.device_repacks() == 4 and not torch.allclose(fresh, c)
+    ops.check_status(dev)
+
+
+def test_captured_forward_repacks_by_itself(dev):
+    """Round-5 advice: a forward captured into a hipGraph while the pack was current recorded only the pair kernel; replays after
+    an optimiser step read a stale pack.  Now the capture records digest + guarded pack + pair kernel: a replay after the table
+    changed (through torch, through `.data`, through the raw-pointer optimiser) gives the new distances.  A capture BEFORE any pack
+    exists allocates nothing into the graph's pool: it records the dense kernel."""
+    from sympa_amd import data, ops
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, metric, dims, num_points = "upper", "fone", 8, 600
+        scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+    m = Model(A)
+    with torch.no_grad():
+        m.embeddings.embeds.data = data.trained_like_table(600, 8, model="upper", seed=3)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(2)
+    trip = torch.randint(0, 600, (8192, 3), generator=g).to(dev)
+
+    def dense():
+        return ops.model_forward(m.embeddings.embeds.data, trip, "upper", "fone", None, m.scale.data, m.scale_coef)
+
+    pk = m.packed_table()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.no_grad(), torch.cuda.stream(side):
+        # (1) no pack yet: the capture must not create one
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, stream=side):
+            out0 = m(trip)
+            out0b = m(trip)           # "second sight" inside the capture: still no allocation into the pool
+        assert pk.pack is None and pk.repacks == 0
+        g0.replay()
+        side.synchronize()
+        assert torch.equal(out0, dense()) and torch.equal(out0b, out0)
+        # (2) with a pack: digest + guarded pack + pair kernel are recorded
+        m(trip); m(trip)
+        assert pk.repacks == 1
+        key = pk.key
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=side):
+            out1 = m(trip)
+        assert pk.key == key          # a capture runs nothing: the host key is left alone
+        g1.replay()
+        side.synchronize()
+        assert rel_err(out1.cpu(), dense().cpu(), atol=1e-13) < 1e-12
+        before = out1.clone()
+        m.embeddings.embeds.data.mul_(1.01)              # invisible to torch
+        g1.replay()
+        side.synchronize()
+        assert rel_err(out1.cpu(), dense().cpu(), atol=1e-13) < 1e-12 and not torch.allclose(out1, before)
+        m.embeddings.embeds.mul_(1.01)                   # visible to torch: the recorded launches do not care either way
+        g1.replay()
+        side.synchronize()
+        assert rel_err(out1.cpu(), dense().cpu(), atol=1e-13) < 1e-12
+        # eager call afterwards: the key moved -> unconditional repack, same values
+        assert rel_err(m(trip).cpu(), dense().cpu(), atol=1e-13) < 1e-12
+    torch.cuda.current_stream(dev).wait_stream(side)
+    ops.check_status(dev)
+
+
+def test_pack_written_on_one_stream_read_on_another(dev):
+    """Round-5 advice: the pack is written on the stream current in ensure() and may be read from another one: the reader is
+    ordered behind the writer's stream (an event recorded at the switch)."""
+    from sympa_amd import ops
+    g = torch.Generator().manual_seed(8)
+    table = points("upper", 3000, 8, 0.4, g).to(dev)
+    trip = torch.randint(0, 3000, (65536, 2), generator=g).to(dev)
+    want = ops.model_forward(table, trip, "upper", "riem")
+    torch.cuda.synchronize(dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    pk = ops.PackedTable("upper")
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            table.mul_(1.0)                       # version moves: forced repack on s1
+            torch.cuda._sleep(20_000_000)         # ... which starts late
+            pk.ensure(table)
+        with torch.cuda.stream(s2):
+            got = ops.model_forward_packed(pk.ensure(table), trip, "riem")
+        s2.synchronize()
+        assert rel_err(got.cpu(), want.cpu(), atol=1e-13) < 1e-12
+    torch.cuda.synchronize(dev)
+    ops.check_status(dev)
+
+
+def test_spd_packed_entry_falls_back_when_the_instantiation_is_demoted(dev):
+    """Round-5 advice: with the sixteen-lanes spd forward demoted by the self-check the packed C entry used to fail; it now runs
+    the one-lane kernel over the pack's images, Model.packed_table() stops offering the pack, and the self-check covers the
+    PACKED instantiation (a separate inline-asm binary) for every n = 6..16."""
+    from sympa_amd import _lib, data, ops, selfcheck
+    from sympa_amd.model import Model
+    lib = _lib.load()
+    table = data.spd_table(300, 16, scale=0.3, seed=3).to(dev)
+    g = torch.Generator().manual_seed(3)
+    trip = torch.randint(0, 300, (5000, 2), generator=g).to(dev)
+    pk = ops.SpdPackedTable().ensure(table)
+    fast = ops.spd_model_forward_packed(pk, trip)
+    _lib.check(lib.sympa_set_instance_fallback(selfcheck.SPD_FWD, 0, 16, 1))
+    try:
+        slow = ops.spd_model_forward_packed(pk, trip)        # C entry: one-lane kernel, rows of n (n + 1) doubles
+        assert rel_err(slow.cpu(), fast.cpu(), atol=1e-13) < 1e-10
+        assert not ops.SpdPackedTable.supported(table)
+
+        class A:
+            manifold, metric, dims, num_points = "spd", "riem", 16, 300
+            scale_coef, scale_init, train_scale = 1.0, 1.0, False
+
+        assert Model(A).to(dev).packed_table() is None
+    finally:
+        _lib.check(lib.sympa_set_instance_fallback(selfcheck.SPD_FWD, 0, 16, 0))
+    assert ops.SpdPackedTable.supported(table)
+    # every packed instantiation passes the first-use comparison on this build
+    for n in range(6, 17):
+        assert all(ok for ok, _ in selfcheck._check_spd_fwd("spd", n, dev)), n
+    ops.check_status(dev)
