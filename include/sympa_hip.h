@@ -202,7 +202,7 @@ int sympa_table_pack(const double* table, int64_t num_rows, int n, int model, vo
  * is remade exactly when the table's bytes differ from those it was made from (first call on a zeroed state: always), on the
  * stream, graph-capturable -- a replayed graph with an optimiser step in front repacks by itself.  Cost when nothing changed: one
  * read of the table (measured: profiles/r06_pack_refresh.txt).  sympa_spd_table_pack_refresh: the same for sympa_spd_table_pack. */
-#define SYMPA_DIGEST_STATE_BYTES 32
+#define SYMPA_DIGEST_STATE_BYTES 4096
 #define SYMPA_DIGEST_CHANGED_WORD 6
 #define SYMPA_FLAG_DIGEST_FORCE 1
 int sympa_table_digest(const void* data, int64_t bytes, void* state, int flags, void* stream);
@@ -216,6 +216,14 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
                                        const int64_t* const* triplets, int64_t stride, const int64_t* b, int num_batches,
                                        int model, int metric, const double* metric_w, double eps, const double* scale,
                                        double scale_coef, double* const* out, int32_t* status, int flags, void* stream);
+
+/* Measurement aid (bench.py `clock`): stamps the shader-cycle counter and the constant 100 MHz counter of SYMPA_CLOCK_STAMP_BLOCKS
+ * one-wave blocks (dealt round-robin over the XCDs) into out[block] = {s_memtime, s_memrealtime, XCC id} (3 x uint64 per block,
+ * device memory).  Two stamps around a stream-ordered region give the shader clock the chip HELD over that region, per XCD:
+ * d(s_memtime) / d(s_memrealtime) x 100 MHz -- what the fp64-issue roof of the timed kernels has to be priced at (the chip lowers
+ * its clock under sustained load).  Not part of the reference's API; no product path calls it. */
+#define SYMPA_CLOCK_STAMP_BLOCKS 64
+int sympa_clock_stamp(void* out, void* stream);
 
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)
  * assembles with N calls of Model.forward over N pairs each (for the mAP metric, sympa/metrics.py:39-63):

@@ -25,6 +25,7 @@ SYMBOLS = (
     "sympa_table_pack_bytes",
     "sympa_table_pack",
     "sympa_table_digest",
+    "sympa_clock_stamp",
     "sympa_table_pack_refresh",
     "sympa_model_forward_packed",
     "sympa_model_forward_batches_packed",
@@ -275,6 +276,8 @@ def load():
     lib.sympa_table_pack_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
     lib.sympa_table_pack.restype = C.c_int
     lib.sympa_table_pack.argtypes = [_c_double_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, _c_i32_p, C.c_void_p]
+    lib.sympa_clock_stamp.restype = C.c_int
+    lib.sympa_clock_stamp.argtypes = [C.c_void_p, C.c_void_p]
     lib.sympa_table_digest.restype = C.c_int
     lib.sympa_table_digest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
     lib.sympa_table_pack_refresh.restype = C.c_int

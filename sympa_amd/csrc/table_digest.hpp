@@ -7,8 +7,8 @@
 // with the digest the pack was made from and writes a `changed` word; the pack kernel that follows on the same stream returns at
 // once when the word is 0.  No host synchronisation, graph-capturable: a replayed graph repacks by itself after an optimiser step.
 //
-// state (caller-owned, 32 bytes of device memory, zero-initialised once): u64 stored digest | u64 accumulator | u32 block
-// counter, u32 unused | u32 changed, u32 number of changes seen.
+// state (caller-owned, SYMPA_DIGEST_STATE_BYTES = 4 096 bytes of device memory, zero-initialised once): u64 stored digest | u64 unused |
+// u32 block counter, u32 unused | u32 changed, u32 number of changes seen | up to 508 per-block partial sums.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,8 +16,9 @@
 
 namespace sympa_hip {
 
-constexpr int DIGEST_BLOCK = 256;
-constexpr int DIGEST_STATE_BYTES = 32;
+constexpr int DIGEST_BLOCK = 1024;
+constexpr int DIGEST_MAX_BLOCKS = 508;     // partial sums behind the four state words
+constexpr int DIGEST_STATE_BYTES = 32 + 8 * DIGEST_MAX_BLOCKS;     // = SYMPA_DIGEST_STATE_BYTES (4 096)
 constexpr int DIGEST_GUARD_WORD = 6;       // index of the `changed` word in the state seen as u32[8]
 
 

@@ -424,7 +424,7 @@ class PackedTable:
                     return None
                 raise RuntimeError("PackedTable.ensure inside a stream capture needs a pack made before the capture")
             self.pack = torch.empty(need, dtype=torch.uint8, device=table.device)
-            self.state = torch.zeros(32, dtype=torch.uint8, device=table.device)
+            self.state = torch.zeros(4096, dtype=torch.uint8, device=table.device)
             self._stream = None
         cur = torch.cuda.current_stream(table.device)
         if self._stream is not None and self._stream != cur and not capturing:

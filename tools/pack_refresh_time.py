@@ -41,7 +41,7 @@ for model, n, nodes, pairs in (("upper", 8, 45500, 262144), ("bounded", 7, 45500
     trip = data.sample_pairs(nodes, pairs, 0, 42).to(dev)
     out = torch.empty(pairs, dtype=torch.float64, device=dev)
     pk = (ops.SpdPackedTable() if spd else ops.PackedTable(model)).ensure(table)
-    state = torch.zeros(32, dtype=torch.uint8, device=dev)
+    state = torch.zeros(4096, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     nbytes = table.numel() * 8
 
