@@ -290,6 +290,11 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not start the two rocprofv3 --pmc child runs that measure roofline.traffic live (N = 1 only); the "
                          "record then carries the committed counter pass of profiles/pmc_latest.json")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="do not append the secondary rows (tools/bench_rows.py: configs[0..4] forward in list and single-call form, "
+                         "training steps of the headline / configs[3] / configs[4]) to the record; they are measured by default "
+                         "when the headline workload runs on one GPU")
+    ap.add_argument("--secondary-budget", type=float, default=150.0, help="seconds the secondary rows may take")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed region is repeated this many times (each repetition: barrier + synchronize, EXACTLY "
                          "K steps, synchronize; the same warm-up in front of the first); ms_per_step / value are those of the MEDIAN "
@@ -433,6 +438,8 @@ def main():
             # launches) plus exact-size graphs for what is left of K and of W, so no step is launched from Python.
             self.graphs = []          # [(nodes, graph)], longest first
             self.gn = nb
+            if spd_pack is not None:
+                spd_pack.ensure(net.embeddings.embeds)
             for i in range(nb):
                 self.step(i)          # warm (allocates the status word etc. outside any capture)
             torch.cuda.synchronize(dev)
@@ -446,8 +453,9 @@ def main():
         def step(self, i, fl=None, dst=None):
             o = (self.outs if dst is None else dst)[i % nb]
             if model == "spd":
-                if spd_pack is not None and fl is None:      # Model's no-grad path: the packed table (one pack per table version)
-                    ops.spd_model_forward_packed(spd_pack.ensure(net.embeddings.embeds), self.batches[i % nb], scale, 1.0, out=o)
+                if spd_pack is not None and fl is None:      # Model's no-grad path: the packed table (made / validated once per
+                    #                                          K-step call by run_steps, like forward_batches' plan: _SpdBatches.run)
+                    ops.spd_model_forward_packed(spd_pack, self.batches[i % nb], scale, 1.0, out=o)
                 else:                                        # fl given: the reference pass of the dense kernel
                     ops.spd_model_forward(table, self.batches[i % nb], scale, 1.0, out=o)
                 return
@@ -504,6 +512,8 @@ def main():
                     self.run_fused(k)
                 return
             done = 0
+            if spd_pack is not None and k > 0:
+                spd_pack.ensure(net.embeddings.embeds)      # one validity check (device-side digest) per K-step call
             for nodes_, g_ in self.graphs:
                 while k - done >= nodes_ and (nodes_ == self.gn or k - done == nodes_):
                     g_.replay()
@@ -558,6 +568,18 @@ def main():
         return {"elapsed": hi[med], "min": min(hi), "max": max(hi), "all": hi, "rank_min_of_median": lo[med],
                 "rank_max_of_median": hi[med], "first": hi[0]}
 
+    # ---- the shader clock the chip HOLDS over a stream-ordered region (C-ABI sympa_clock_stamp: s_memtime against the constant
+    # 100 MHz s_memrealtime, per XCD): the fp64-issue roof is cycles, and the chip lowers its clock under sustained load
+    lib_ = _lib.load()
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import clock_util
+
+    def clock_stamp():
+        return clock_util.stamp(lib_, dev, torch)
+
+    clock_between = clock_util.between
+
     primary = Region(args.scaling)
     batches, outs, my_pairs, global_pairs = primary.batches, primary.outs, primary.my_pairs, primary.global_pairs
     step, capture, run_steps, flags = primary.step, primary.capture, primary.run_steps, primary.flags
@@ -575,11 +597,14 @@ def main():
     # the same K steps once more, untimed by the wall clock, bracketed by HIP events on the launch stream: what the GPU
     # side of such a region takes (recording events INSIDE the wall-timed region costs it ~70 us of host time)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cs0 = clock_stamp()
     ev0.record()
     run_steps(args.steps)
     ev1.record()
+    cs1 = clock_stamp()
     torch.cuda.synchronize(dev)
     device_ms = ev0.elapsed_time(ev1)
+    clock_region = clock_between(cs0, cs1)       # over one K-step region entered from an idle GPU, like the wall-timed ones
     ops.check_status(dev)
     ranks_seen = 1
     if use_dist:
@@ -660,6 +685,12 @@ def main():
             for _ in range(reps):
                 run_steps(args.steps)
         k_timed = timed_groups(fused_group, reps * n_launches)
+        cs0 = clock_stamp()
+        for _ in range(4):
+            fused_group()
+        cs1 = clock_stamp()
+        torch.cuda.synchronize(dev)
+        clock_sustained = clock_between(cs0, cs1)       # back-to-back launches of the timed kernel: what kernel_avg_us was measured at
         timed_pairs_per_launch = my_pairs * args.steps / n_launches
         k_default = kernel_time(0)
         if packed:          # what a table that changes before every call pays on top: one sympa_table_pack over the table
@@ -672,6 +703,11 @@ def main():
     else:
         timed_kernel = kernel_name(model, n, flags & ops.FLAG_LOW_LDS, packed=spd_pack is not None)
         k_timed = kernel_time(None if spd_pack is not None else flags)
+        cs0 = clock_stamp()
+        run_steps(max(args.steps, 64))
+        cs1 = clock_stamp()
+        torch.cuda.synchronize(dev)
+        clock_sustained = clock_between(cs0, cs1)
         timed_pairs_per_launch = my_pairs
         k_default = k_timed if default_kernel == timed_kernel else kernel_time(0)
         if spd_pack is not None:
@@ -867,6 +903,14 @@ def main():
                                                "(sympa_amd/csrc/asm_stats.json, written by the build from the saved assembly: "
                                                "FMA = 2, other fp64 arithmetic = 1, everything else 0)",
                                  "reference_flops_per_pair": (121.0 * n ** 3 if model != "spd" else None)}
+            if clock_sustained:
+                # the same quotient against the issue slots of the clock the chip actually held while the kernel ran back to back
+                peak_now = 1024 * clock_sustained["mhz"] * 1e6 / 4.0
+                phys["frac_at_measured_clock"] = ach / peak_now
+                phys["measured_clock_mhz"] = clock_sustained["mhz"]
+                if clock_region:
+                    phys["frac_whole_job_at_measured_clock"] = ((value / world) * waves_per_pair * valu_per_wave /
+                                                                (1024 * clock_region["mhz"] * 1e6 / 4.0))
             rec["roofline_physical"] = phys
             rec["valu_issue_fraction"] = phys["frac_whole_job"]
             if mix is not None:
@@ -874,6 +918,13 @@ def main():
                                      "reference_flops_per_pair": phys["flops"]["reference_flops_per_pair"],
                                      "frac_own": (value / world) * phys["flops"]["own_flops_per_pair"] / 78.6e12,
                                      "source": valu_source}
+        rec["clock"] = {"spec_peak_mhz": 2400.0, "sustained": clock_sustained, "timed_region": clock_region,
+                        "method": "C-ABI sympa_clock_stamp before and after the region on the launch stream: 2 048 one-wave blocks "
+                                  "each record s_memtime (shader cycles), s_memrealtime (constant 100 MHz) and the CU they ran on; clock = "
+                                  "d(s_memtime) / d(s_memrealtime) x 100 MHz between the stamps of the SAME CU (MI355X_MICROARCH.md, DVFS "
+                                  "give-back item 6), median over the CUs.  sustained: around back-to-back launches of the timed kernel (the region "
+                                  "kernel_avg_us comes from); timed_region: around ONE K-step region entered from an idle GPU "
+                                  "(includes the launch gap in front of its first kernel)"}
         # ---- parity of the timed region's own output (batch 0) against the oracle, same table, same pairs
         want0 = None
         if world == 1 and not args.no_cpu_baseline:
@@ -885,6 +936,20 @@ def main():
             with torch.no_grad():
                 want0 = oracle_forward_fn(model)(table_cpu, batches[0][:k0, :2].cpu(), model, metric)
         rec["parity"] = parity_record(timed_out0[:k0], want0, k0, model)
+        # ---- secondary rows (tools/bench_rows.py): the other configs' forward in both call forms and the training steps,
+        # measured by THIS command, in this JSON line
+        if (world == 1 and args.workload == "upper-riem-n4-b65536" and not args.no_secondary and not args.batch
+                and not os.environ.get("SYMPA_BENCH_PMC_CHILD") and not profiled):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_rows
+            t_sec = time.perf_counter()
+            rec["secondary"] = bench_rows.secondary_rows(dev, args.seed, steps=min(args.steps, 20), budget_s=args.secondary_budget,
+                                                         log=lambda s_: sys.stderr.write(s_ + "\n"))
+            rec["secondary_seconds"] = time.perf_counter() - t_sec
+            bad_rows = [r for r in rec["secondary"] if "parity" in r and not r["parity"]["ok"]]
+            if bad_rows:
+                sys.stderr.write("bench.py: secondary rows with a parity failure: " + ", ".join(
+                    f"{r['workload']}/{r['kind']}/{r.get('form', '')[:6]}" for r in bad_rows) + "\n")
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -218,11 +218,12 @@ int sympa_model_forward_batches_packed(const void* pack, int64_t pack_bytes, int
                                        double scale_coef, double* const* out, int32_t* status, int flags, void* stream);
 
 /* Measurement aid (bench.py `clock`): stamps the shader-cycle counter and the constant 100 MHz counter of SYMPA_CLOCK_STAMP_BLOCKS
- * one-wave blocks (dealt round-robin over the XCDs) into out[block] = {s_memtime, s_memrealtime, XCC id} (3 x uint64 per block,
- * device memory).  Two stamps around a stream-ordered region give the shader clock the chip HELD over that region, per XCD:
- * d(s_memtime) / d(s_memrealtime) x 100 MHz -- what the fp64-issue roof of the timed kernels has to be priced at (the chip lowers
+ * one-wave blocks (several per CU) into out[block] = {s_memtime, s_memrealtime, XCC_ID | HW_ID << 8} (3 x uint64 per block,
+ * device memory).  Two stamps around a stream-ordered region give the shader clock the chip HELD over that region:
+ * d(s_memtime) / d(s_memrealtime) x 100 MHz between stamps taken on the SAME CU (bits 8..15 of HW_ID: CU, SH, SE; the counters of
+ * different CUs are not comparable) -- what the fp64-issue roof of the timed kernels has to be priced at (the chip lowers
  * its clock under sustained load).  Not part of the reference's API; no product path calls it. */
-#define SYMPA_CLOCK_STAMP_BLOCKS 64
+#define SYMPA_CLOCK_STAMP_BLOCKS 2048
 int sympa_clock_stamp(void* out, void* stream);
 
 /* Block of rows of the all-pairs distance matrix that Runner.build_distance_matrix (sympa/runner.py:142-154)

@@ -114,7 +114,14 @@ def test_gpu_backward_golden(dev, model, n):
         g1, g2, gw = ops.siegel_dist_backward(z1, z2, T(g[f"{m}__coeff"]).to(dev), model, m,
                                               torch.ones(n, device=dev))
         ops.check_status(dev)
-        assert relmax(g1.cpu(), g[f"{m}__g1"]) < TOL and relmax(g2.cpu(), g[f"{m}__g2"]) < TOL, (model, n, m)
+        # The reference's autograd runs through a 2n x 2n symeig (1 / eigenvalue-gap terms): its gradient of a SYMMETRIC argument
+        # comes out asymmetric by its own rounding noise -- 4.9e-9 of the largest entry for finf at n = 16, where a well-conditioned
+        # formulation (autograd through svdvals of L1^-1 (Z2 - Z1) L2^-T) differs from it by 9.1e-8 and from these kernels by
+        # 1e-12.  The tolerance is the golden's own noise floor where that is above 1e-8.
+        noise = max(relmax(g[f"{m}__g{k}"], np.swapaxes(g[f"{m}__g{k}"], -1, -2)) for k in (1, 2))
+        tol = max(TOL, 30.0 * noise)
+        assert tol < 1e-6, (model, n, m, noise)
+        assert relmax(g1.cpu(), g[f"{m}__g1"]) < tol and relmax(g2.cpu(), g[f"{m}__g2"]) < tol, (model, n, m)
         if m == "wsum":
             assert relmax(gw.cpu(), g["wsum__gw"].reshape(-1)) < TOL
 

@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""The secondary rows of bench.py's record ("plus the other configs as secondary rows"; round-5 review item 2): every
+claim about a non-headline workload measured by the driver's own command, in the SAME JSON line as the headline.
+
+    forward rows   configs[0..4] (BASELINE.json), each in two forms:
+        "list"    Model.forward_batches(Model.prepare_batches(K batches))   -- the loop of Runner.evaluate (runner.py:124-135) as ONE call
+        "single"  K calls of Model.forward under no_grad                     -- the call the reference makes (model.py:16-30), one per batch
+    training rows  the whole training step of Runner.train_epoch (runner.py:98-118: forward, AverageDistortionLoss, backward,
+                   clip, RiemannianSGD) of the headline, configs[3] and configs[4], replayed hipGraphs (sympa_amd/train_step.py)
+
+Per row: ms_per_step (wall clock: synchronize, K steps, synchronize; median of 5), device_us_per_step (HIP events around back-to-back
+repetitions: every kernel of a step, the pack's validity check included), launches_per_step, the contract fraction
+(SURVEY 8d algorithmic bytes per pair x pairs / device time / 8 TB/s), parity.max_rel_err of the timed code's own output against the
+oracle on a sample, packed_table.pack_us where a packed table is used.  `python tools/bench_rows.py` prints the rows alone."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12
+FORWARD = (   # name, manifold, metric, dims, nodes, batch   (BASELINE.json configs[0..4])
+    ("grid-upper-riem-n2-b512", "upper", "riem", 2, 125, 512),
+    ("tree-upper-riem-n4-b8192", "upper", "riem", 4, 1093, 8192),
+    ("margulis-bounded-finf-n4-b65536", "bounded", "finf", 4, 5041, 65536),
+    ("cartesian-upper-riem-n8-b262144", "upper", "riem", 8, 45500, 262144),
+    ("custom-spd-n16-b1048576", "spd", "riem", 16, 100000, 1048576),
+)
+TRAIN = (
+    ("upper-riem-n4-b65536", "upper", "riem", 4, 5041, 65536),
+    ("cartesian-upper-riem-n8-b262144", "upper", "riem", 8, 45500, 262144),
+    ("custom-spd-n16-b1048576", "spd", "riem", 16, 100000, 1048576),
+)
+
+
+def bytes_per_pair(n, model):
+    return 2 * 8 + 2 * ((1 if model == "spd" else 2) * n * n * 8) + 8
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[(len(xs) - 1) // 2]
+
+
+def _table(model, n, nodes, seed):
+    from sympa_amd import data
+    return data.spd_table(nodes, n, seed=seed) if model == "spd" else data.trained_like_table(nodes, n, model=model, seed=seed)
+
+
+def _net(model, metric, n, nodes, table_cpu, dev, train_scale=False):
+    import torch
+    from sympa_amd.model import Model
+
+    class A:
+        manifold, dims, num_points = model, n, nodes
+        scale_coef, scale_init = 1.0, 1.0
+    A.metric, A.train_scale = metric, train_scale
+    net = Model(A)
+    with torch.no_grad():
+        net.embeddings.embeds.data = table_cpu.clone()
+    return net.to(dev)
+
+
+def _time(run, dev, steps, launches_hint=1):
+    """(wall ms per step: median of 5 repetitions of synchronize / K steps / synchronize; device us per step: HIP events around
+    back-to-back repetitions, >= 64 launches per group where a step is short)."""
+    import torch
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize(dev)
+    wall = []
+    for _ in range(5):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize(dev)
+        wall.append(time.perf_counter() - t0)
+    reps = max(1, -(-64 // max(1, launches_hint)))
+    evs = []
+    for _ in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            run()
+        b.record()
+        torch.cuda.synchronize(dev)
+        evs.append(a.elapsed_time(b) / reps)
+    return _median(wall) / steps * 1e3, _median(evs) / steps * 1e3
+
+
+def _oracle_forward(model, metric, table_cpu, pairs_cpu):
+    import torch
+    from oracle import siegel_oracle as so
+    with torch.no_grad():
+        if model == "spd":
+            return so.spd_model_forward(table_cpu, pairs_cpu, torch.ones(1, dtype=torch.float64), 1.0)
+        return so.model_forward(table_cpu, pairs_cpu, model, metric)
+
+
+def _parity(got, want):
+    import torch
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    ok = bool(torch.isfinite(got).all())
+    rel = float(((got - want).abs() / want.abs().clamp_min(1e-9)).max()) if ok else float("inf")
+    return {"pairs": int(got.numel()), "max_rel_err": rel, "tol": 1e-4, "ok": bool(ok and rel <= 1e-4)}
+
+
+def forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=None):
+    import torch
+    from sympa_amd import data, ops
+    table_cpu = _table(model, n, nodes, seed) if table_cpu is None else table_cpu
+    net = _net(model, metric, n, nodes, table_cpu, dev)
+    nb = 4
+    batches = [data.sample_pairs(nodes, batch, j, seed).to(dev) for j in range(nb)]
+    blist = [batches[i % nb] for i in range(steps)]
+    olist = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(nb)]
+    plan = net.prepare_batches(blist, [olist[i % nb] for i in range(steps)])
+    sample = min(batch, 256 if model == "spd" else 1024)
+    want = _oracle_forward(model, metric, table_cpu, batches[0][:sample, :2].cpu())
+    bpp = bytes_per_pair(n, model)
+    pk = net.packed_table()
+    rows = []
+    last = {}
+
+    def run_list():
+        net.forward_batches(plan)
+
+    def run_single():
+        for i in range(steps):
+            last[i % nb] = net(batches[i % nb])
+
+    with torch.no_grad():
+        for form, run, launches in (("list", run_list, -(-steps // ops.MAX_FUSED_BATCHES) if model != "spd" else steps),
+                                    ("single", run_single, steps)):
+            ms, dev_us = _time(run, dev, steps, launches)
+            ops.check_status(dev)
+            out0 = olist[0] if form == "list" else last[0]
+            packed_now = pk is not None and pk.key is not None and batch * (steps if form == "list" else 1) >= 4096
+            row = {"workload": name, "kind": "forward", "form": form,
+                   "api": ("Model.forward_batches(Model.prepare_batches(K batches))" if form == "list"
+                           else "Model.forward(batch) under no_grad, once per step"),
+                   "config": {"manifold": model, "dist_metric": metric, "dims": n, "nodes": nodes, "pairs_per_step": batch},
+                   "steps": steps, "ms_per_step": ms, "device_us_per_step": dev_us,
+                   "value": batch / (ms * 1e-3), "unit": "pairs/s",
+                   "roofline": {"bound": "hbm", "algorithmic_bytes_per_pair": bpp, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                "achieved": bpp * batch / (dev_us * 1e-6) / 1e9, "frac": bpp * batch / (dev_us * 1e-6) / HBM_PEAK,
+                                "frac_whole_job": bpp * batch / (ms * 1e-3) / HBM_PEAK},
+                   "packed_table_in_use": bool(packed_now),
+                   "parity": _parity(out0[:sample], want)}
+            rows.append(row)
+        if pk is not None and pk.key is not None:
+            def repack():
+                pk.invalidate()
+                pk.ensure(net.embeddings.embeds)
+            _, pack_us = _time(repack, dev, 1, 2)
+
+            def check():
+                pk.ensure(net.embeddings.embeds, strict=True)
+            _, check_us = _time(check, dev, 1, 2)
+            for r in rows:
+                r["packed_table"] = {"pack_us": pack_us, "validity_check_us": check_us, "device_repacks": pk.device_repacks(),
+                                     "note": "pack_us = digest + unconditional pack (table changed); validity_check_us = digest + "
+                                             "a pack kernel that returns at once (table unchanged: part of every `single` step and of "
+                                             "every `list` call)"}
+    del net, plan
+    return rows
+
+
+def _oracle_grad(model, metric, table_cpu, trip_cpu, gd_cpu):
+    """d (AverageDistortionLoss) / d table by torch autograd through the oracle (what the reference trains with)."""
+    import torch
+    from oracle import siegel_oracle as so
+    tab = table_cpu.clone().requires_grad_(True)
+    if model == "spd":
+        d = so.spd_model_forward(tab, trip_cpu, torch.ones(1, dtype=torch.float64), 1.0)
+    else:
+        d = so.model_forward(tab, trip_cpu, model, metric)
+    loss = so.distortion_loss(gd_cpu, d)
+    loss.backward()
+    g = tab.grad
+    return 0.5 * (g + g.transpose(-1, -2)), float(loss)
+
+
+def train_row(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=None):
+    import torch
+    from sympa_amd import data, ops
+    from sympa_amd.optim import RiemannianSGD
+    from sympa_amd.train_step import GraphedTrainStep
+    table_cpu = _table(model, n, nodes, seed) if table_cpu is None else table_cpu
+    # ---- parity first, on its own small model: gradient of the fused loss + backward kernels on a sample against autograd
+    # through the oracle (same table rows, 2 048 pairs)
+    sample = 2048            # (>= 1 024 pairs: the split / three-kernel backward forms the large batches run)
+    rows_used = min(nodes, 400)
+    small = table_cpu[:rows_used].clone()
+    g = torch.Generator().manual_seed(seed)
+    trip = torch.stack((torch.randint(0, rows_used, (sample,), generator=g), torch.randint(0, rows_used, (sample,), generator=g),
+                        torch.randint(1, 9, (sample,), generator=g)), 1)
+    trip[:, 1] = torch.where(trip[:, 1] == trip[:, 0], (trip[:, 1] + 1) % rows_used, trip[:, 1])
+    net = _net(model, metric, n, rows_used, small, dev, train_scale=False)
+    net.embeddings.embeds.grad = None
+    loss_dev = net.fused_loss_backward(trip.to(dev), trip[:, 2].to(torch.float64).to(dev))
+    torch.cuda.synchronize(dev)
+    ops.check_status(dev)
+    want_g, want_loss = _oracle_grad(model, metric, small, trip[:, :2], trip[:, 2].to(torch.float64))
+    got_g = net.embeddings.embeds.grad.cpu()
+    got_g = 0.5 * (got_g + got_g.transpose(-1, -2))
+    rel = float((got_g - want_g).abs().max() / want_g.abs().max().clamp_min(1e-300))
+    lrel = abs(float(loss_dev.cpu()) - want_loss) / max(abs(want_loss), 1e-300)
+    parity = {"pairs": sample, "max_rel_err": max(rel, lrel), "grad_max_rel_err": rel, "loss_rel_err": lrel, "tol": 1e-4,
+              "ok": bool(max(rel, lrel) <= 1e-4),
+              "against": "torch autograd of AverageDistortionLoss through oracle/siegel_oracle.py on the same rows and pairs "
+                         "(error relative to the largest gradient entry)"}
+    del net
+    # ---- the timed step
+    net = _net(model, metric, n, nodes, table_cpu, dev, train_scale=True)
+    opt = RiemannianSGD(net.parameters(), lr=1e-4)
+    k_epoch = max(steps, 8)
+    big = torch.stack((torch.randint(0, nodes, (batch * k_epoch,), generator=g), torch.randint(0, nodes, (batch * k_epoch,), generator=g),
+                       torch.randint(1, 9, (batch * k_epoch,), generator=g)), 1).to(dev)
+    two = model != "spd" and n <= 6
+    step = GraphedTrainStep(net, opt, batch, 50.0, dev, two_kernels=two, deterministic=True if two else False, accumulate_loss=two)
+    if step.mode == "two_kernels":
+        form = "two kernels per step, batches addressed by a device step counter, deterministic accumulation (load_epoch + run_steps)"
+
+        def run():
+            step.load_epoch(big[:batch * steps])
+            step.run_steps(steps)
+        # load_epoch (one sort + copies per EPOCH) stays outside the timed steps
+        def timed():
+            step.run_steps(steps)
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize(dev)
+        wall, evs = [], []
+        for _ in range(5):
+            step.load_epoch(big[:batch * steps])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            timed()
+            torch.cuda.synchronize(dev)
+            wall.append(time.perf_counter() - t0)
+        for _ in range(5):
+            step.load_epoch(big[:batch * steps])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            timed()
+            b.record()
+            torch.cuda.synchronize(dev)
+            evs.append(a.elapsed_time(b))
+        ms, dev_us = _median(wall) / steps * 1e3, _median(evs) / steps * 1e3
+    else:
+        form = "one replayed hipGraph per step (loss + backward, norms, clip, RiemannianSGD), the batch copied in per step"
+        if (model == "upper" and n == 8) or (model == "spd" and 9 <= n <= 16):
+            big = data.sort_batches_by_source(big, batch)       # what the data pipeline does per epoch (sympa_amd/data.py)
+        ids = [big[j * batch:(j + 1) * batch, :2].contiguous() for j in range(4)]
+        gds = [big[j * batch:(j + 1) * batch, 2].to(torch.float64) for j in range(4)]
+
+        def run():
+            for i in range(steps):
+                step(ids[i % 4], gds[i % 4])
+        ms, dev_us = _time(run, dev, steps, steps * 4)
+    ops.check_status(dev)
+    finite = bool(torch.isfinite(net.embeddings.embeds.data).all())
+    parity["table_finite_after_timed_steps"] = finite
+    parity["ok"] = bool(parity["ok"] and finite)
+    # contract: a training step reads both points and adds to both gradient rows (read-modify-write) per pair, plus ids,
+    # graph distance and nothing else: 3 x the forward's point bytes + 32
+    planes = 1 if model == "spd" else 2
+    bpp = 3 * 8 + 2 * (planes * n * n * 8) + 2 * 2 * (planes * n * n * 8)
+    return {"workload": name, "kind": "training_step", "form": form,
+            "api": "sympa_amd.train_step.GraphedTrainStep (runner.py:98-118 as replayed hipGraphs)",
+            "config": {"manifold": model, "dist_metric": metric, "dims": n, "nodes": nodes, "pairs_per_step": batch,
+                       "optimizer": "RiemannianSGD", "max_grad_norm": 50.0},
+            "steps": steps, "ms_per_step": ms, "device_us_per_step": dev_us, "value": batch / (ms * 1e-3), "unit": "pairs/s trained",
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_pair": bpp, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "achieved": bpp * batch / (dev_us * 1e-6) / 1e9, "frac": bpp * batch / (dev_us * 1e-6) / HBM_PEAK,
+                         "note": "per pair: two points read, two gradient rows read-modify-written, ids + graph distance"},
+            "parity": parity}
+
+
+def secondary_rows(dev, seed=42, steps=20, budget_s=150.0, log=None):
+    """All rows, in a fixed order, until the time budget is spent (a row that did not fit is listed with "skipped")."""
+    import torch
+    t_start = time.perf_counter()
+    rows = []
+    tables = {}
+
+    def tab(model, n, nodes):
+        key = (model, n, nodes)
+        if key not in tables:
+            tables[key] = _table(model, n, nodes, seed)
+        return tables[key]
+
+    jobs = [("forward",) + w for w in FORWARD[:4]] + [("train",) + TRAIN[0], ("train",) + TRAIN[1],
+                                                      ("forward",) + FORWARD[4], ("train",) + TRAIN[2]]
+    for kind, name, model, metric, n, nodes, batch in jobs:
+        left = budget_s - (time.perf_counter() - t_start)
+        need = 45.0 if model == "spd" else 8.0
+        if left < need:
+            rows.append({"workload": name, "kind": "forward" if kind == "forward" else "training_step",
+                         "skipped": f"time budget ({budget_s:.0f} s) spent"})
+            continue
+        t0 = time.perf_counter()
+        try:
+            if kind == "forward":
+                new = forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, tab(model, n, nodes))
+            else:
+                new = [train_row(name, model, metric, n, nodes, batch, dev, seed, steps, tab(model, n, nodes))]
+        except Exception as e:  # noqa: BLE001  (a secondary row must never take the headline record down)
+            new = [{"workload": name, "kind": kind, "error": f"{type(e).__name__}: {e}"}]
+        for r in new:
+            r["seconds"] = round(time.perf_counter() - t0, 1)
+        rows += new
+        torch.cuda.empty_cache()
+        if log:
+            log(f"secondary {kind} {name}: {time.perf_counter() - t0:.1f} s")
+    return rows
+
+
+if __name__ == "__main__":
+    import json
+    import torch
+    dev = torch.device("cuda:0")
+    out = secondary_rows(dev, budget_s=float(os.environ.get("BUDGET_S", "400")), log=lambda s: print(s, file=sys.stderr, flush=True))
+    for r in out:
+        if "skipped" in r or "error" in r:
+            print(json.dumps(r))
+            continue
+        pt = r.get("packed_table")
+        print(f"{r['workload']:34s} {r['kind']:13s} {r['form'][:6]:6s}  {r['ms_per_step'] * 1e3:9.1f} us/step wall  {r['device_us_per_step']:9.1f} us device  "
+              f"frac {r['roofline']['frac']:.3f}  parity {r['parity']['max_rel_err']:.1e}" +
+              (f"  pack {pt['pack_us']:.1f} us check {pt['validity_check_us']:.1f} us" if pt else ""), flush=True)
+    print(json.dumps(out))

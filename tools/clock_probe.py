@@ -15,25 +15,12 @@ from sympa_amd.model import Model  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
-NB = 64
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import clock_util  # noqa: E402
 
 
 def stamp():
-    buf = torch.zeros(3 * NB, dtype=torch.int64, device=dev)
-    _lib.check(lib.sympa_clock_stamp(buf.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-    return buf
-
-
-def clocks(a, b):
-    a, b = a.cpu().view(NB, 3), b.cpu().view(NB, 3)
-    out = {}
-    for i in range(NB):
-        if a[i, 2] != b[i, 2]:
-            continue
-        dt, dr = int(b[i, 0] - a[i, 0]), int(b[i, 1] - a[i, 1])
-        if dr > 0:
-            out.setdefault(int(a[i, 2]), []).append(dt / dr * 100.0)
-    return {x: sum(v) / len(v) for x, v in sorted(out.items())}, (int(b[0, 1] - a[0, 1]) / 100.0)
+    return clock_util.stamp(lib, dev, torch)
 
 
 for model, metric, n, nodes, batch in (("upper", "riem", 4, 5041, 65536), ("upper", "riem", 8, 45500, 262144)):
@@ -61,8 +48,8 @@ for model, metric, n, nodes, batch in (("upper", "riem", 4, 5041, 65536), ("uppe
                     net.forward_batches(plan)
                 s1 = stamp()
                 torch.cuda.synchronize()
-                res.append(clocks(s0, s1))
-            for c, us in res:
-                vals = list(c.values())
-                print(f"{model} n={n} [{label}] region {us:9.1f} us  clock MHz per XCD: " + " ".join(f"{x}:{v:6.0f}" for x, v in c.items()) +
-                      f"   mean {sum(vals) / max(len(vals), 1):6.0f}", flush=True)
+                res.append(clock_util.between(s0, s1))
+            for c in res:
+                print(f"{model} n={n} [{label}] region {c['region_us']:9.1f} us  clock {c['mhz']:6.0f} MHz (median of {c['cus_paired']} CUs; "
+                      f"min {c['mhz_min_cu']:6.0f} max {c['mhz_max_cu']:6.0f})  per XCD: " +
+                      " ".join(f"{x}:{v:5.0f}" for x, v in c['mhz_per_xcd'].items()), flush=True)
