@@ -235,11 +235,19 @@ __device__ __attribute__((noinline)) void scatter_add_rows_outlined(const sympa:
 
 // (two 256-register waves per SIMD in the rows-out form at n <= 4: measured slower, 32.2 -> 34.7 us upper, 36.5 -> 51.0 us bounded --
 // 60 spilled registers cost more than the second wave brings, profiles/r03_rejected_variants.txt)
-template <int N, bool SCATTER>
-constexpr int bwd_min_blocks() { return 1; }
+// Round 6: upper model, n = 4 -- the two Cholesky factors (28 doubles) wait in the wave's LDS tile between the solves that form E
+// and the back-substitutions (pair_backward's park / unpark): 294 -> <= 256 registers without scratch, two blocks per CU.
+template <int N, int MODEL>
+#ifdef SYMPA_AB_OLD_N4_BWD
+constexpr bool bwd_parks_factors() { return false; }
+#else
+constexpr bool bwd_parks_factors() { return N == 4 && MODEL == sympa::MODEL_UPPER; }
+#endif
+template <int N, int MODEL, bool SCATTER>
+constexpr int bwd_min_blocks() { return bwd_parks_factors<N, MODEL>() ? 2 : 1; }
 
 template <int N, int MODEL, bool SCATTER>
-__global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, SCATTER>())) void siegel_bwd_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, MODEL, SCATTER>())) void siegel_bwd_kernel(const BwdArgs a) {
     constexpr int BLOCK = bwd_block<N>();
     constexpr int GATHER_SLOTS = DmaTile<N>::ENABLED ? DmaTile<N>::WAVE_SLOTS_LOW : Tile<N>::WAVE_SLOTS;
     constexpr bool ROWS_TILE = !SCATTER && !ScatterTile<N>::BY_PLANE;      // per-pair rows leave through the tile too (n <= 6)
@@ -296,7 +304,34 @@ SYMPA_UNROLL
     for (int k = 0; k < N; ++k) gw[k] = 0.0;
     // every gradient is linear in go: run the adjoint with go = 1 and scale afterwards (the fused loss
     // needs the distance before it knows go)
-    const double dist = sympa::pair_backward<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, 1.0, g1, g2, gw, st);
+    double dist;
+    if constexpr (bwd_parks_factors<N, MODEL>()) {
+        // the factors wait in the wave's tile ([entry][lane]: conflict-free) while the eigen stage and the products run
+        constexpr int TRI = N * (N + 1) / 2;
+        double* const ptile = reinterpret_cast<double*>(tile) + (threadIdx.x & 63);
+        dist = sympa::pair_backward<N, MODEL>(
+            z1, z2, f.metric, f.metric_w, f.inv_eps, 1.0, g1, g2, gw, st,
+            [&](const int which, sympa::Tri<N, false>& l) {
+                double* p = ptile + which * TRI * 64;
+SYMPA_UNROLL
+                for (int r = 0; r < N; ++r) {
+                    p[sympa::tri_index(N, r, r) * 64] = l.rdiag[r];
+SYMPA_UNROLL
+                    for (int c = 0; c < r; ++c) p[sympa::tri_index(N, c, r) * 64] = l.re[r][c];
+                }
+            },
+            [&](const int which, sympa::Tri<N, false>& l) {
+                const double* p = ptile + which * TRI * 64;
+SYMPA_UNROLL
+                for (int r = 0; r < N; ++r) {
+                    l.rdiag[r] = p[sympa::tri_index(N, r, r) * 64];
+SYMPA_UNROLL
+                    for (int c = 0; c < r; ++c) l.re[r][c] = p[sympa::tri_index(N, c, r) * 64];
+                }
+            });
+    } else {
+        dist = sympa::pair_backward<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, 1.0, g1, g2, gw, st);
+    }
     const bool bad = (st & sympa::ST_BAD_INDEX) != 0;
     double go = 0.0, loss_i = 0.0;
     if (graph_dist != nullptr) {   // AverageDistortionLoss (losses.py:10-19): sum |(d/g)^2 - 1|

@@ -560,13 +560,144 @@ SYMPA_UNROLL
     return out;
 }
 
+// S = L^-T M L^-1 for symmetric M (full matrix in, upper triangle i <= j of S out, in m)
+template <int N>
+SYMPA_HD void sym_congruence_inv_t(const Tri<N, false>& l, double (&m)[N][N]) {
+    // W = L^-T M: back substitution down the columns
+SYMPA_UNROLL
+    for (int c = 0; c < N; ++c) {
+SYMPA_UNROLL
+        for (int i = N - 1; i >= 0; --i) {
+            double t = m[i][c];
+SYMPA_UNROLL
+            for (int k = i + 1; k < N; ++k) t = d_fma(-l.re[k][i], m[k][c], t);
+            m[i][c] = t * l.rdiag[i];
+        }
+    }
+    // S = W L^-1, row r: x_j = (x_j - sum_{k > j} x_k L_kj) / L_jj -- only j >= r is wanted and needs only k > j
+SYMPA_UNROLL
+    for (int r = 0; r < N; ++r) {
+SYMPA_UNROLL
+        for (int j = N - 1; j >= r; --j) {
+            double t = m[r][j];
+SYMPA_UNROLL
+            for (int k = j + 1; k < N; ++k) t = d_fma(-m[r][k], l.re[k][j], t);
+            m[r][j] = t * l.rdiag[j];
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Upper model, n <= 4: everything behind the spectral weights in an order that keeps one lane under 128 doubles (round 6; the
+// order of pair_adjoint_gradient_upper, siegel_math_bwd_split.hpp, without a workspace).  The generic tail below holds V, E,
+// the full Hbar and K at once (294 registers at n = 4: one wave per SIMD); here
+//   1. U = E V in place over E (row by row);  Re G = Re U diag(phi) U^H (symmetric: n (n + 1) / 2 values);
+//   2. Ebar = 2 U diag(phi) V^H in place over U (row by row);  Re K = Re V diag(phi lambda) V^H -- V dies.  Never more than
+//      E / U / Ebar (one matrix) + V + two symmetric real matrices at once: Hbar itself is never formed;
+//   3. Dbar = L1^-T Ebar L2^-1 in place, the factors back from wherever the caller parked them;
+//   4. Re planes: g2 = sym(Re Dbar), g1 = -g2;  Im planes: g2 = sym(Im Dbar) - L2^-T Re K L2^-1,  g1 = -sym(Im Dbar) - L1^-T Re G L1^-1.
+// Same arithmetic as the generic tail up to the order of the sums.
+// ---------------------------------------------------------------------------------------------
+template <int N, class Unpark>
+SYMPA_HD void upper_adjoint_tail_lean(CMat<N>& e, const CMat<N>& v, const double (&phi)[N], const double (&philam)[N],
+                                      Tri<N, false>& l1, Tri<N, false>& l2, Unpark&& unpark, CMat<N>& g1, CMat<N>& g2) {
+    // U = E V, row by row over E
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i) {
+        double ur[N], ui[N];
+SYMPA_UNROLL
+        for (int k = 0; k < N; ++k) {
+            double tr = 0.0, ti = 0.0;
+SYMPA_UNROLL
+            for (int m = 0; m < N; ++m) {
+                tr = d_fma(e.re[i][m], v.re[m][k], d_fma(-e.im[i][m], v.im[m][k], tr));
+                ti = d_fma(e.re[i][m], v.im[m][k], d_fma(e.im[i][m], v.re[m][k], ti));
+            }
+            ur[k] = tr; ui[k] = ti;
+        }
+SYMPA_UNROLL
+        for (int k = 0; k < N; ++k) { e.re[i][k] = ur[k]; e.im[i][k] = ui[k]; }
+    }
+    // Re G = Re U diag(phi) U^H (symmetric), before U is overwritten
+    double gg[N][N];
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = i; j < N; ++j) {
+            double g = 0.0;
+SYMPA_UNROLL
+            for (int k = 0; k < N; ++k) g = d_fma(phi[k], d_fma(e.re[i][k], e.re[j][k], e.im[i][k] * e.im[j][k]), g);
+            gg[i][j] = g;
+            gg[j][i] = g;
+        }
+    // Ebar = 2 U diag(phi) V^H, row by row over U
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i) {
+        double pr[N], pi[N], fr[N], fi[N];
+SYMPA_UNROLL
+        for (int k = 0; k < N; ++k) { pr[k] = 2.0 * phi[k] * e.re[i][k]; pi[k] = 2.0 * phi[k] * e.im[i][k]; }
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            double tr = 0.0, ti = 0.0;
+SYMPA_UNROLL
+            for (int k = 0; k < N; ++k) {
+                tr = d_fma(pr[k], v.re[j][k], d_fma(pi[k], v.im[j][k], tr));
+                ti = d_fma(pi[k], v.re[j][k], d_fma(-pr[k], v.im[j][k], ti));
+            }
+            fr[j] = tr; fi[j] = ti;
+        }
+SYMPA_UNROLL
+        for (int j = 0; j < N; ++j) { e.re[i][j] = fr[j]; e.im[i][j] = fi[j]; }
+    }
+    // Re K = Re V diag(phi lambda) V^H (symmetric); V dies
+    double km[N][N];
+SYMPA_UNROLL
+    for (int j = 0; j < N; ++j)
+SYMPA_UNROLL
+        for (int k = j; k < N; ++k) {
+            double kr = 0.0;
+SYMPA_UNROLL
+            for (int i = 0; i < N; ++i) kr = d_fma(philam[i], d_fma(v.re[j][i], v.re[k][i], v.im[j][i] * v.im[k][i]), kr);
+            km[j][k] = kr;
+            km[k][j] = kr;
+        }
+    unpark(0, l1);
+    solve_lh_left<N, false>(l1, e);
+    unpark(1, l2);
+    solve_l_right<N, false, true>(l2, e);
+    sym_congruence_inv_t<N>(l2, km);
+    sym_congruence_inv_t<N>(l1, gg);
+SYMPA_UNROLL
+    for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+        for (int j = i; j < N; ++j) {
+            const double dr = 0.5 * (e.re[i][j] + e.re[j][i]);
+            const double di = 0.5 * (e.im[i][j] + e.im[j][i]);
+            g2.re[i][j] = dr;            g2.re[j][i] = dr;
+            g1.re[i][j] = -dr;           g1.re[j][i] = -dr;
+            const double y2 = di - km[i][j], y1 = -di - gg[i][j];
+            g2.im[i][j] = y2;            g2.im[j][i] = y2;
+            g1.im[i][j] = y1;            g1.im[j][i] = y1;
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One pair: forward value + gradients.  g1, g2: symmetric matrix gradients w.r.t. Z1, Z2 (both planes);
 // gw[k] += d out / d w_k * go for the wsum metric (k = rank of the eigenvalue, ascending).
 // ---------------------------------------------------------------------------------------------
-template <int N, int MODEL>
+// park(k, l) / unpark(k, l): the caller may take the two Cholesky factors out of the registers between the point where E exists
+// and the back-substitutions that need them again (the kernel's LDS tile, free between the gather and the scatter): they are the
+// 56 registers that kept the n = 4 kernel at one wave per SIMD (294 registers; round 6).  Default: nothing moves.
+struct KeepFactors {
+    template <class T>
+    SYMPA_HD void operator()(int, T&) const {}
+};
+
+template <int N, int MODEL, class Park = KeepFactors, class Unpark = KeepFactors>
 SYMPA_HD double pair_backward(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
-                              double inv_eps, double go, CMat<N>& g1, CMat<N>& g2, double (&gw)[N], int& status) {
+                              double inv_eps, double go, CMat<N>& g1, CMat<N>& g2, double (&gw)[N], int& status,
+                              Park&& park = Park(), Unpark&& unpark = Unpark()) {
     constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
     Tri<N, CPLX> l1, l2;
     CMat<N> e;
@@ -586,7 +717,9 @@ SYMPA_UNROLL
             e.im[i][j] = z2.im[i][j] - z1.im[i][j];
         }
     solve_left<N, CPLX>(l1, e);
+    park(0, l1);
     solve_right_t<N, CPLX>(l2, e);
+    park(1, l2);
     Herm<N> h;
     gram<N>(e, h);
     CMat<N> v;
@@ -618,6 +751,17 @@ SYMPA_UNROLL
     bool finite;
     double out = spectral_adjoint<N, MODEL>(h.d, metric, w, inv_eps, go, phi, philam, gw, finite);
 
+#ifndef SYMPA_AB_OLD_N4_BWD
+    if constexpr (MODEL == MODEL_UPPER && N <= 4) {
+        upper_adjoint_tail_lean<N>(e, v, phi, philam, l1, l2, unpark, g1, g2);
+        if (!finite) out = __builtin_nan("");
+        if (!ok) status |= ST_NOT_PD;
+        if (!conv) status |= ST_NO_CONVERGENCE;
+        if (!d_finite(out)) status |= ST_NONFINITE;
+        return out;
+    }
+#endif
+
     // closed forms (header comment): no Cholesky adjoint -- the factors only enter through congruences.
     // (Forming U = E V once and Ebar = 2 U diag(phi) V^H, G = U diag(phi) U^H from it saves a product but keeps three
     //  full matrices alive at once: measured SLOWER for the unrolled kernels, n = 8 1.80 ms against 1.44 ms per 262 144
@@ -628,7 +772,9 @@ SYMPA_UNROLL
     CMat<N> ebar;
     cmatmul<N>(e, hbar, 2.0, ebar);           // Ebar = 2 E Hbar
     cmatmul_bh<N>(ebar, e, 0.5, a1);          // G = E Hbar E^H
+    unpark(0, l1);
     solve_lh_left<N, CPLX>(l1, ebar);         // Dbar = L1^-H Ebar conj(L2)^-1
+    unpark(1, l2);
     solve_l_right<N, CPLX, true>(l2, ebar);
     if (CPLX) {
 SYMPA_UNROLL

@@ -324,33 +324,7 @@ SYMPA_UNROLL
 // pk(k): entry k of the pack (read when it is needed, not before).  Only upper triangles (i <= j) of the emitted matrices
 // are meaningful.
 // ---------------------------------------------------------------------------------------------
-// S = L^-T M L^-1 for symmetric M (full matrix in, upper triangle i <= j of S out, in m)
-template <int N>
-SYMPA_HD void sym_congruence_inv_t(const Tri<N, false>& l, double (&m)[N][N]) {
-    // W = L^-T M: back substitution down the columns
-SYMPA_UNROLL
-    for (int c = 0; c < N; ++c) {
-SYMPA_UNROLL
-        for (int i = N - 1; i >= 0; --i) {
-            double t = m[i][c];
-SYMPA_UNROLL
-            for (int k = i + 1; k < N; ++k) t = d_fma(-l.re[k][i], m[k][c], t);
-            m[i][c] = t * l.rdiag[i];
-        }
-    }
-    // S = W L^-1, row r: x_j = (x_j - sum_{k > j} x_k L_kj) / L_jj -- only j >= r is wanted and needs only k > j
-SYMPA_UNROLL
-    for (int r = 0; r < N; ++r) {
-SYMPA_UNROLL
-        for (int j = N - 1; j >= r; --j) {
-            double t = m[r][j];
-SYMPA_UNROLL
-            for (int k = j + 1; k < N; ++k) t = d_fma(-m[r][k], l.re[k][j], t);
-            m[r][j] = t * l.rdiag[j];
-        }
-    }
-}
-
+// (sym_congruence_inv_t: siegel_math_bwd.hpp)
 template <int N, class Pk, class Park, class Unpark, class PutG, class GetG, class Stage, class Flush>
 SYMPA_HD void pair_adjoint_gradient_upper(const CMat<N>& z1, const CMat<N>& z2, Pk&& pk, Park&& park, Unpark&& unpark,
                                           PutG&& put_g, GetG&& get_g, Stage&& stage, Flush&& flush) {
