@@ -33,6 +33,12 @@ int pack_len(int n, int model) {
     const int offd = n * (n - 1) / 2;
     return 2 * n + 3 * offd + (model == SYMPA_MODEL_UPPER ? 0 : offd);            // sympa::AdjPack<n, model>::LEN
 }
+// entries of the workspace per pair: the pack, or the 2 n^2 doubles of V that stage 1 parks there while it refines the eigenvalues of
+// a graded spectrum (split_refine_eigenvalues) -- whichever is larger
+int ws_entries(int n, int model) {
+    const int pl = pack_len(n, model), vv = 2 * n * n;
+    return pl > vv ? pl : vv;
+}
 int64_t padded(int64_t b) { return (b + 63) / 64 * 64; }
 }  // namespace
 
@@ -42,7 +48,7 @@ bool bwd_split_available(int n, int model) {
 
 int64_t bwd_split_workspace_bytes(int64_t b, int n, int model) {
     if (!bwd_split_available(n, model) || b <= 0) return 0;
-    return (int64_t)pack_len(n, model) * padded(b) * (int64_t)sizeof(double);
+    return (int64_t)ws_entries(n, model) * padded(b) * (int64_t)sizeof(double);
 }
 
 int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* workspace, int64_t workspace_bytes, hipStream_t s) {

@@ -166,6 +166,30 @@ __device__ __forceinline__ void split_rows(const DistArgs& f, const int64_t ii, 
     }
 }
 
+// The rare path of stage 1 (siegel_math_bwd_split.hpp, "Graded spectra"): the eigenvalues of the wave's pairs as Rayleigh quotients
+// ||E v_c||^2, E formed again from the two table rows (plain per-lane loads: this runs for a handful of waves, if any), the
+// eigenvectors streamed back column by column from where the caller parked them: entries [0, 2 n^2) of the workspace, V.re then
+// V.im, row-major.  NOT inlined: its registers (and what it spills) are its own, the common path of the kernel does not see them.
+template <int N, int MODEL>
+__device__ __attribute__((noinline)) void split_refine_eigenvalues(const double* __restrict__ base1, const int r1,
+                                                                   const double* __restrict__ base2, const int r2, double* ws,
+                                                                   const int64_t wss, const unsigned wo, double* __restrict__ lam) {
+    constexpr int64_t ROW = 2 * N * N;
+    sympa::CMat<N> z1, z2;
+    sympa::load_point<N>(base1 + (int64_t)r1 * ROW, z1);
+    sympa::load_point<N>(base2 + (int64_t)r2 * ROW, z2);
+    double out[N];
+    sympa::rayleigh_quotients_from_points<N, MODEL>(z1, z2, [&](const int c, double (&vr)[N], double (&vi)[N]) {
+SYMPA_UNROLL
+        for (int k = 0; k < N; ++k) {
+            vr[k] = *ws_at(ws + (int64_t)(k * N + c) * wss, wo);
+            vi[k] = *ws_at(ws + (int64_t)(N * N + k * N + c) * wss, wo);
+        }
+    }, out);
+SYMPA_UNROLL
+    for (int c = 0; c < N; ++c) lam[c] = out[c];
+}
+
 template <int N, int MODEL>
 __global__ __launch_bounds__(64, 1) void siegel_bwd_spectral_kernel(const SplitArgs sa) {
     using P = sympa::AdjPack<N, MODEL>;
@@ -195,7 +219,33 @@ SYMPA_UNROLL
     {
         sympa::CMat<N> z1, z2;
         gather_pair_passes<N, false>(f.base1, (int)r1, f.base2, (int)r2, lds, z1, z2);
-        dist = sympa::pair_adjoint_spectral<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, pack, gw, st);
+        dist = sympa::pair_adjoint_spectral<N, MODEL>(
+            z1, z2, f.metric, f.metric_w, f.inv_eps, pack, gw, st,
+            [&](sympa::CMat<N>& v, double (&lam)[N]) {
+                // graded spectrum somewhere in this wave: V waits in the workspace (its pack entries are written much later) while
+                // the eigenvalues are refined from the table rows
+                double* const ws = sa.ws;
+                const int64_t wss = sa.ws_stride;
+                const unsigned wo = (unsigned)i * 8u;             // (i < padded(b) = ws_stride: dead lanes have a slot too)
+SYMPA_UNROLL
+                for (int r = 0; r < N; ++r)
+SYMPA_UNROLL
+                    for (int c = 0; c < N; ++c) {
+                        *ws_at(ws + (int64_t)(r * N + c) * wss, wo) = v.re[r][c];
+                        *ws_at(ws + (int64_t)(N * N + r * N + c) * wss, wo) = v.im[r][c];
+                    }
+                double refined[N];
+                split_refine_eigenvalues<N, MODEL>(f.base1, (int)r1, f.base2, (int)r2, ws, wss, wo, refined);
+SYMPA_UNROLL
+                for (int c = 0; c < N; ++c) lam[c] = refined[c];
+SYMPA_UNROLL
+                for (int r = 0; r < N; ++r)
+SYMPA_UNROLL
+                    for (int c = 0; c < N; ++c) {
+                        v.re[r][c] = *ws_at(ws + (int64_t)(r * N + c) * wss, wo);
+                        v.im[r][c] = *ws_at(ws + (int64_t)(N * N + r * N + c) * wss, wo);
+                    }
+            });
     }
     double sc = 1.0;
     bool sc_active = false;

@@ -19,11 +19,11 @@
 // [entry][pair]: every load and store of the workspace is a contiguous 512 bytes per wave.
 //
 // Difference from pair_backward: the eigenvalues that enter phi are the QL's (accurate to eps ||H||), not the Rayleigh
-// quotients ||E v_i||^2 -- E is gone when the vectors exist.  A small eigenvalue therefore carries the relative error
-// eps lambda_max / lambda_i into phi_i ~ lambda_i^-1/2 (fone / fmin / wsum; measured against the one-stage adjoint, profiles/
-// r05_split_graded_spectrum.txt: 5e-9 of the gradient at lambda_min / lambda_max = 1e-8, 7e-5 at 1e-12); riem and finf do not see it
-// (phi_i = 2 / (d (1 + lambda_i))): equal to rounding down to 1e-12.  The dispatcher keeps the one-stage kernels reachable
-// (SYMPA_FLAG_GENERIC / no workspace) and tests/test_backward_split.py pins both behaviours.
+// quotients ||E v_i||^2 -- E is gone when the vectors exist.  riem and finf do not see it (phi_i = 2 / (d (1 + lambda_i))): equal to
+// rounding down to a spread of 1e-12.  fone / fmin / wsum (phi_i ~ lambda_i^-1/2) would carry eps lambda_max / lambda_i (rounds 4, 5:
+// 5e-9 of the gradient at a spread of 1e-8, 7e-5 at 1e-12, profiles/r05_split_graded_spectrum.txt); since round 6 a wave that holds
+// such a pair (spread < SPLIT_GRADED_RATIO) refines its eigenvalues to the same quotients -- see "Graded spectra" below.  The
+// dispatcher keeps the one-stage kernels reachable (SYMPA_FLAG_GENERIC / no workspace); tests/test_backward_split.py compares both.
 #pragma once
 
 #include "siegel_math_bwd.hpp"
@@ -133,11 +133,87 @@ SYMPA_UNROLL
 }
 
 // ---------------------------------------------------------------------------------------------
+// Graded spectra (round 6).  The QL's eigenvalues of H = E^H E are accurate to eps ||H||; fone / fmin / wsum weight eigenvalue i with
+// phi_i ~ lambda_i^-1/2, so a spread lambda_min / lambda_max = r leaves the relative error eps / r in the weights of the small ones
+// (7e-5 of the gradient at r = 1e-12, profiles/r05_split_graded_spectrum.txt).  The one-stage adjoint refines every eigenvalue to the
+// Rayleigh quotient ||E v_i||^2; stage 1 has lost E by the time the vectors exist, so it does the same ONLY where it matters: when a
+// pair of the wave has r < SPLIT_GRADED_RATIO under one of those metrics, `refine(v, lambda)` is called (wave-uniform branch; a
+// generic batch never takes it) and replaces the eigenvalues by the quotients with E formed AGAIN from the points.  The default
+// `refine` still has the points (CPU build, tests); the gfx950 kernel parks V in the workspace, reloads the two rows and streams the
+// vectors back (siegel_bwd_split_kernel.hpp: a separate, not inlined function -- nothing of it touches the common path's registers).
+// ---------------------------------------------------------------------------------------------
+constexpr double SPLIT_GRADED_RATIO = 1e-5;       // eps / 1e-5 = 2e-11 of relative error in a weight is what the QL route may leave
+
+SYMPA_HD bool metric_wants_relative_eigenvalues(const int metric) {
+    return metric == METRIC_FONE || metric == METRIC_FMIN || metric == METRIC_WSUM;
+}
+
+// lambda_c = || E v_c ||^2 with E = L1^-1 (Z2 - Z1) L2^-T formed from the points; `column(c, vr, vi)` hands over eigenvector c
+template <int N, int MODEL, class Column>
+SYMPA_HD void rayleigh_quotients_from_points(const CMat<N>& z1, const CMat<N>& z2, Column&& column, double (&lam)[N]) {
+    constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
+    CMat<N> e;
+    {
+        Tri<N, CPLX> l1, l2;
+        if constexpr (MODEL == MODEL_UPPER) {
+            (void)chol_real<N>(z1.im, l1);
+            (void)chol_real<N>(z2.im, l2);
+        } else {
+            (void)chol_id_minus_wwh<N>(z1, l1);
+            (void)chol_id_minus_wwh<N>(z2, l2);
+        }
+SYMPA_UNROLL
+        for (int i = 0; i < N; ++i)
+SYMPA_UNROLL
+            for (int j = 0; j < N; ++j) {
+                e.re[i][j] = z2.re[i][j] - z1.re[i][j];
+                e.im[i][j] = z2.im[i][j] - z1.im[i][j];
+            }
+        solve_left<N, CPLX>(l1, e);
+        solve_right_t<N, CPLX>(l2, e);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int c = 0; c < N; ++c) {
+        double vr[N], vi[N];
+        column(c, vr, vi);
+        double acc = 0.0;
+SYMPA_UNROLL
+        for (int r = 0; r < N; ++r) {
+            double tr = 0.0, ti = 0.0;
+SYMPA_UNROLL
+            for (int k = 0; k < N; ++k) {
+                tr = d_fma(e.re[r][k], vr[k], d_fma(-e.im[r][k], vi[k], tr));
+                ti = d_fma(e.re[r][k], vi[k], d_fma(e.im[r][k], vr[k], ti));
+            }
+            acc = d_fma(tr, tr, d_fma(ti, ti, acc));
+        }
+        lam[c] = acc;
+    }
+}
+
+// the default `refine` of pair_adjoint_spectral: the caller still holds the points
+template <int N, int MODEL>
+struct RefineFromPoints {
+    const CMat<N>& z1;
+    const CMat<N>& z2;
+    SYMPA_HD void operator()(CMat<N>& v, double (&lam)[N]) const {
+        // (column c by a run-time index: a copy of V the loop can index -- this is the CPU build's path)
+        rayleigh_quotients_from_points<N, MODEL>(z1, z2, [&](const int c, double (&vr)[N], double (&vi)[N]) {
+SYMPA_UNROLL
+            for (int k = 0; k < N; ++k) { vr[k] = v.re[k][c]; vi[k] = v.im[k][c]; }
+        }, lam);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Stage 1.  Returns the metric value (NaN for non-finite input); pack = Hbar, K for go = 1; gw[k] += d out / d w_k.
 // ---------------------------------------------------------------------------------------------
-template <int N, int MODEL>
+template <int N, int MODEL, class Refine>
 SYMPA_HD double pair_adjoint_spectral(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
-                                      double inv_eps, double (&pack)[AdjPack<N, MODEL>::LEN], double (&gw)[N], int& status) {
+                                      double inv_eps, double (&pack)[AdjPack<N, MODEL>::LEN], double (&gw)[N], int& status,
+                                      Refine&& refine) {
     using P = AdjPack<N, MODEL>;
     constexpr bool CPLX = (MODEL == MODEL_BOUNDED);
     Herm<N> h;
@@ -167,6 +243,16 @@ SYMPA_UNROLL
     bool conv;
     if constexpr (N >= 5) conv = herm_eigen_vectors_ql<N>(h, v);
     else conv = herm_eigen_vectors<N>(h, v);
+    if constexpr (N >= 5) {
+        bool graded = false;
+        if (metric_wants_relative_eigenvalues(metric)) {
+            double lo = h.d[0], hi = h.d[0];
+SYMPA_UNROLL
+            for (int i = 1; i < N; ++i) { lo = fmin(lo, h.d[i]); hi = fmax(hi, h.d[i]); }
+            graded = lo < SPLIT_GRADED_RATIO * hi;          // (NaN eigenvalues: false)
+        }
+        if (!wave_all(!graded)) refine(v, h.d);
+    }
 
     double phi[N], philam[N];
     bool finite;
@@ -205,6 +291,12 @@ SYMPA_UNROLL
     if (!conv) status |= ST_NO_CONVERGENCE;
     if (!d_finite(out)) status |= ST_NONFINITE;
     return out;
+}
+
+template <int N, int MODEL>
+SYMPA_HD double pair_adjoint_spectral(const CMat<N>& z1, const CMat<N>& z2, int metric, const double* __restrict__ w,
+                                      double inv_eps, double (&pack)[AdjPack<N, MODEL>::LEN], double (&gw)[N], int& status) {
+    return pair_adjoint_spectral<N, MODEL>(z1, z2, metric, w, inv_eps, pack, gw, status, RefineFromPoints<N, MODEL>{z1, z2});
 }
 
 // ---------------------------------------------------------------------------------------------
