@@ -2,6 +2,23 @@
 #include "siegel_coop_bwd_kernel.hpp"
 #include "siegel_bwd_split_kernel.hpp"
 
+namespace sympa_hip {
+int launch_bwd_one_lane(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s) {
+    switch (n) {
+        case 1: return launch_bwd_n<1>(a, model, scatter, s);
+        case 2: return launch_bwd_n<2>(a, model, scatter, s);
+        case 3: return launch_bwd_n<3>(a, model, scatter, s);
+        case 4: return launch_bwd_n<4>(a, model, scatter, s);
+        case 5: return launch_bwd_n<5>(a, model, scatter, s);
+        case 6: return launch_bwd_n<6>(a, model, scatter, s);
+        case 7: return model == SYMPA_MODEL_UPPER ? launch_bwd_n7_upper(a, scatter, s) : launch_bwd_n7_bounded(a, scatter, s);
+        case 8: return model == SYMPA_MODEL_UPPER ? launch_bwd_n8_upper(a, scatter, s) : launch_bwd_n8_bounded(a, scatter, s);
+        default: break;
+    }
+    return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "one-pair-per-lane backward: dims 1..8");
+}
+}  // namespace sympa_hip
+
 namespace {
 using namespace sympa_hip;
 
@@ -12,6 +29,15 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* workspace
     if ((a.go == nullptr && a.graph_dist == nullptr) || a.g1 == nullptr || a.g2 == nullptr)
         return fail(SYMPA_ERR_BAD_ARG, "null gradient buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // SYMPA_FLAG_MERGE_SRC with per-pair rows: only the one-lane kernels of dims <= 6 leave the merged layout (one row per run of equal
+    // source ids); any other kernel would write every row while the caller's slot list (ops.sorted_slots(merged_src=b)) drops all but
+    // the run ends -- a silently wrong gradient (round-5 advice).  The scatter forms ignore the flag harmlessly (every row is added).
+    const bool merged_rows = (a.f.flags & SYMPA_FLAG_MERGE_SRC) != 0 && !scatter;
+    const auto no_merge = []() {
+        return fail(SYMPA_ERR_BAD_ARG, "SYMPA_FLAG_MERGE_SRC with grad_rows: only the one-pair-per-lane kernels of dims <= 6 write merged "
+                                       "rows (no workspace / SYMPA_FLAG_SPLIT / SYMPA_FLAG_COOP / SYMPA_FLAG_GENERIC, dims <= 6)");
+    };
+    if (merged_rows && (n > 6 || (a.f.flags & (SYMPA_FLAG_COOP | SYMPA_FLAG_SPLIT)))) return no_merge();
     // Eight lanes per pair (two pairs per DPP row, no scratch) where measured faster than one pair per lane
     // (tools/bwd_coop_ab_small.py, per 262 144 pairs): the fused step at n = 8 (upper 1.78 -> 1.49 ms, bounded 2.59 -> 1.99 ms),
     // bounded n = 8 dense rows (2.51 -> 2.15 ms), bounded n = 7 fused (1.70 -> 1.56 ms).  SYMPA_FLAG_COOP forces it for
@@ -40,17 +66,7 @@ int launch_bwd(const BwdArgs& a, int n, int model, bool scatter, void* workspace
         const bool faster = (n == 8 && (scatter || bounded)) || (n == 7 && bounded && scatter);
         if (faster || (a.f.flags & SYMPA_FLAG_COOP)) return launch_bwd_half(a, n, model, scatter, s);
     }
-    switch (n) {
-        case 1: return launch_bwd_n<1>(a, model, scatter, s);
-        case 2: return launch_bwd_n<2>(a, model, scatter, s);
-        case 3: return launch_bwd_n<3>(a, model, scatter, s);
-        case 4: return launch_bwd_n<4>(a, model, scatter, s);
-        case 5: return launch_bwd_n<5>(a, model, scatter, s);
-        case 6: return launch_bwd_n<6>(a, model, scatter, s);
-        case 7: return model == SYMPA_MODEL_UPPER ? launch_bwd_n7_upper(a, scatter, s) : launch_bwd_n7_bounded(a, scatter, s);
-        case 8: return model == SYMPA_MODEL_UPPER ? launch_bwd_n8_upper(a, scatter, s) : launch_bwd_n8_bounded(a, scatter, s);
-        default: break;
-    }
+    if (n >= 1 && n <= 8) return launch_bwd_one_lane(a, n, model, scatter, s);
     if (n > 8 && n <= SYMPA_MAX_DIMS_BACKWARD) {
         // sixteen lanes per pair (siegel_coop_bwd.hpp); SYMPA_FLAG_GENERIC keeps the one-lane-per-pair kernel over scratch
         if (!one_lane) return launch_bwd_coop(a, n, model, scatter, s);

@@ -20,6 +20,8 @@ struct BwdArgs {
     double* wave_partials;      // deterministic mode: [waves][2 + n] per-wave sums (loss, d loss / d scale, d loss / d w_k) are
                                 // WRITTEN here instead of being added to loss / gscale / gw with atomics; a later kernel
                                 // (sympa_segment_sum_rows) adds them up in a fixed order
+    const int* chunk_mask;      // one-pair-per-lane kernels: [ceil(b / 64)] -- a wave whose word is 0 returns at once (the split
+                                // backward hands its graded-spectrum waves to these kernels, siegel_bwd_split.hip); null: all
 };
 
 // (Scattering only the n(n+1) upper-triangle entries of the symmetric rows and mirroring afterwards was
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, MODEL, SCATTER>(
         if (graph_dist != nullptr) graph_dist += off;
     }
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (a.chunk_mask != nullptr && a.chunk_mask[i >> 6] == 0) return;      // (wave-uniform; no block-level barrier in this kernel)
     const bool live = i < f.b;
     const int64_t ii = live ? i : f.b - 1;
 

@@ -33,12 +33,9 @@ int pack_len(int n, int model) {
     const int offd = n * (n - 1) / 2;
     return 2 * n + 3 * offd + (model == SYMPA_MODEL_UPPER ? 0 : offd);            // sympa::AdjPack<n, model>::LEN
 }
-// entries of the workspace per pair: the pack, or the 2 n^2 doubles of V that stage 1 parks there while it refines the eigenvalues of
-// a graded spectrum (split_refine_eigenvalues) -- whichever is larger
-int ws_entries(int n, int model) {
-    const int pl = pack_len(n, model), vv = 2 * n * n;
-    return pl > vv ? pl : vv;
-}
+// behind the packs: one int per wave of 64 pairs (SplitArgs::graded) -- as many as the LARGEST grid that reads them has waves (the
+// one-lane kernels of dims 5, 6 run 256-thread blocks) --, rounded up to 16 bytes
+int64_t flag_bytes(int64_t b) { return (((b + 255) / 256) * 4 * (int64_t)sizeof(int) + 15) / 16 * 16; }
 int64_t padded(int64_t b) { return (b + 63) / 64 * 64; }
 }  // namespace
 
@@ -48,7 +45,7 @@ bool bwd_split_available(int n, int model) {
 
 int64_t bwd_split_workspace_bytes(int64_t b, int n, int model) {
     if (!bwd_split_available(n, model) || b <= 0) return 0;
-    return (int64_t)ws_entries(n, model) * padded(b) * (int64_t)sizeof(double);
+    return (int64_t)pack_len(n, model) * padded(b) * (int64_t)sizeof(double) + flag_bytes(b);
 }
 
 int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* workspace, int64_t workspace_bytes, hipStream_t s) {
@@ -64,6 +61,7 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
     sa.a = a;
     sa.ws = static_cast<double*>(workspace);
     sa.ws_stride = padded(a.f.b);
+    sa.graded = reinterpret_cast<int*>(static_cast<char*>(workspace) + (int64_t)pack_len(n, model) * padded(a.f.b) * (int64_t)sizeof(double));
     // the spectral kernel staggers its first round of gathers like the dims 7, 8 forward: two rounds or more of a table beyond the L2s
     sa.a.f.flags &= ~SYMPA_INTERNAL_FLAG_STAGGER;
     if (a.f.idx1 != nullptr && a.f.b >= 2048 * 64 && a.f.num_rows * (int64_t)(16 * n * n) >= ((int64_t)12 << 20))
@@ -78,6 +76,7 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
         default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "split backward: dims 5..8");
     }
     if (rc != 0) return rc;
+    const auto gradient = [&]() -> int {
     switch (n) {
         case 5:
             if (upper) return scatter ? launch_bwd_split_gradient_upper_5_scatter(sa, s) : launch_bwd_split_gradient_upper_5_dense(sa, s);
@@ -93,6 +92,17 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
             return scatter ? launch_bwd_split_gradient_bounded_8_scatter(sa, s) : launch_bwd_split_gradient_bounded_8_dense(sa, s);
         default: return fail(SYMPA_ERR_UNSUPPORTED_DIMS, "split backward: dims 5..8");
     }
+    };
+    rc = gradient();
+    if (rc != 0) return rc;
+    // the waves stage 1 flagged (graded spectra: siegel_math_bwd_split.hpp) through the one-stage kernel, which refines every
+    // eigenvalue to a Rayleigh quotient; every other wave of this launch returns at once (a few microseconds for the whole grid).
+    // Their packs were zero, so the gradient kernel added / wrote zeros for them; loss, forward values, scale / weight gradients,
+    // the deterministic per-wave sums and the status of those waves come from this launch.
+    BwdArgs fin = a;
+    fin.chunk_mask = sa.graded;
+    fin.f.flags &= ~(SYMPA_FLAG_SPLIT | SYMPA_FLAG_COOP | SYMPA_INTERNAL_FLAG_STAGGER);
+    return launch_bwd_one_lane(fin, n, model, scatter, s);
 }
 
 }  // namespace sympa_hip

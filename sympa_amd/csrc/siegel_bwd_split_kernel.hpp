@@ -16,6 +16,8 @@ struct SplitArgs {
     BwdArgs a;
     double* ws;              // [AdjPack<N, MODEL>::LEN][ws_stride] fp64
     int64_t ws_stride;       // >= b
+    int* graded;             // [ws_stride / 64]: stage 1 writes 1 for a wave whose pairs go to the one-stage kernel instead (graded
+                             // spectrum), 0 otherwise; nullptr: no such hand-over (the eigenvalues stay the QL's)
 };
 
 // entry base (wave-uniform: a scalar register pair) + 32-bit byte offset of the lane's pair: global_load/store ... v_off, s[base]
@@ -166,30 +168,6 @@ __device__ __forceinline__ void split_rows(const DistArgs& f, const int64_t ii, 
     }
 }
 
-// The rare path of stage 1 (siegel_math_bwd_split.hpp, "Graded spectra"): the eigenvalues of the wave's pairs as Rayleigh quotients
-// ||E v_c||^2, E formed again from the two table rows (plain per-lane loads: this runs for a handful of waves, if any), the
-// eigenvectors streamed back column by column from where the caller parked them: entries [0, 2 n^2) of the workspace, V.re then
-// V.im, row-major.  NOT inlined: its registers (and what it spills) are its own, the common path of the kernel does not see them.
-template <int N, int MODEL>
-__device__ __attribute__((noinline)) void split_refine_eigenvalues(const double* __restrict__ base1, const int r1,
-                                                                   const double* __restrict__ base2, const int r2, double* ws,
-                                                                   const int64_t wss, const unsigned wo, double* __restrict__ lam) {
-    constexpr int64_t ROW = 2 * N * N;
-    sympa::CMat<N> z1, z2;
-    sympa::load_point<N>(base1 + (int64_t)r1 * ROW, z1);
-    sympa::load_point<N>(base2 + (int64_t)r2 * ROW, z2);
-    double out[N];
-    sympa::rayleigh_quotients_from_points<N, MODEL>(z1, z2, [&](const int c, double (&vr)[N], double (&vi)[N]) {
-SYMPA_UNROLL
-        for (int k = 0; k < N; ++k) {
-            vr[k] = *ws_at(ws + (int64_t)(k * N + c) * wss, wo);
-            vi[k] = *ws_at(ws + (int64_t)(N * N + k * N + c) * wss, wo);
-        }
-    }, out);
-SYMPA_UNROLL
-    for (int c = 0; c < N; ++c) lam[c] = out[c];
-}
-
 template <int N, int MODEL>
 __global__ __launch_bounds__(64, 1) void siegel_bwd_spectral_kernel(const SplitArgs sa) {
     using P = sympa::AdjPack<N, MODEL>;
@@ -216,36 +194,27 @@ __global__ __launch_bounds__(64, 1) void siegel_bwd_spectral_kernel(const SplitA
 SYMPA_UNROLL
     for (int k = 0; k < N; ++k) gw[k] = 0.0;
     double dist;
+    bool redo = false;
     {
         sympa::CMat<N> z1, z2;
         gather_pair_passes<N, false>(f.base1, (int)r1, f.base2, (int)r2, lds, z1, z2);
-        dist = sympa::pair_adjoint_spectral<N, MODEL>(
-            z1, z2, f.metric, f.metric_w, f.inv_eps, pack, gw, st,
-            [&](sympa::CMat<N>& v, double (&lam)[N]) {
-                // graded spectrum somewhere in this wave: V waits in the workspace (its pack entries are written much later) while
-                // the eigenvalues are refined from the table rows
-                double* const ws = sa.ws;
-                const int64_t wss = sa.ws_stride;
-                const unsigned wo = (unsigned)i * 8u;             // (i < padded(b) = ws_stride: dead lanes have a slot too)
+        // (`refine`: a pair of this wave has a graded spectrum under fone / fmin / wsum -- siegel_math_bwd_split.hpp, "Graded
+        // spectra".  The kernel only takes note: the wave's 64 pairs are handed to the one-stage kernel, see below.)
+        dist = sympa::pair_adjoint_spectral<N, MODEL>(z1, z2, f.metric, f.metric_w, f.inv_eps, pack, gw, st,
+                                                      [&](sympa::CMat<N>&, double (&)[N]) { redo = true; });
+    }
+    // Graded spectrum somewhere in this wave (wave-uniform: the branch that set `redo` was taken by all lanes or none): E is gone, so
+    // the eigenvalues cannot be refined to Rayleigh quotients here.  The wave hands on ZERO packs (the gradient kernel then adds /
+    // writes zeros for its pairs), raises its flag and contributes nothing else; the third launch of launch_bwd_split runs the
+    // one-stage kernel (pair_backward: quotients ||E v_i||^2 for every eigenvalue) on exactly the flagged waves.
+    if (threadIdx.x == 0 && sa.graded != nullptr) sa.graded[blockIdx.x] = redo ? 1 : 0;
+    if (redo && sa.graded != nullptr) {
+        if (live) {
+            const unsigned wo = (unsigned)i * 8u;
 SYMPA_UNROLL
-                for (int r = 0; r < N; ++r)
-SYMPA_UNROLL
-                    for (int c = 0; c < N; ++c) {
-                        *ws_at(ws + (int64_t)(r * N + c) * wss, wo) = v.re[r][c];
-                        *ws_at(ws + (int64_t)(N * N + r * N + c) * wss, wo) = v.im[r][c];
-                    }
-                double refined[N];
-                split_refine_eigenvalues<N, MODEL>(f.base1, (int)r1, f.base2, (int)r2, ws, wss, wo, refined);
-SYMPA_UNROLL
-                for (int c = 0; c < N; ++c) lam[c] = refined[c];
-SYMPA_UNROLL
-                for (int r = 0; r < N; ++r)
-SYMPA_UNROLL
-                    for (int c = 0; c < N; ++c) {
-                        v.re[r][c] = *ws_at(ws + (int64_t)(r * N + c) * wss, wo);
-                        v.im[r][c] = *ws_at(ws + (int64_t)(N * N + r * N + c) * wss, wo);
-                    }
-            });
+            for (int k = 0; k < P::LEN; ++k) *ws_at(sa.ws + k * sa.ws_stride, wo) = 0.0;
+        }
+        return;
     }
     double sc = 1.0;
     bool sc_active = false;
@@ -458,5 +427,8 @@ int launch_bwd_split_gradient(const SplitArgs& sa, hipStream_t s) {
 int64_t bwd_split_workspace_bytes(int64_t b, int n, int model);
 bool bwd_split_available(int n, int model);
 int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* workspace, int64_t workspace_bytes, hipStream_t s);
+// siegel_bwd.hip: the one-stage, one-pair-per-lane kernels of dims 1..8 (siegel_bwd_kernel), whatever the default dispatch prefers;
+// with a.chunk_mask only the 64-pair chunks whose word is non-zero are processed
+int launch_bwd_one_lane(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
 
 }  // namespace sympa_hip

@@ -138,9 +138,12 @@ SYMPA_UNROLL
 // (7e-5 of the gradient at r = 1e-12, profiles/r05_split_graded_spectrum.txt).  The one-stage adjoint refines every eigenvalue to the
 // Rayleigh quotient ||E v_i||^2; stage 1 has lost E by the time the vectors exist, so it does the same ONLY where it matters: when a
 // pair of the wave has r < SPLIT_GRADED_RATIO under one of those metrics, `refine(v, lambda)` is called (wave-uniform branch; a
-// generic batch never takes it) and replaces the eigenvalues by the quotients with E formed AGAIN from the points.  The default
-// `refine` still has the points (CPU build, tests); the gfx950 kernel parks V in the workspace, reloads the two rows and streams the
-// vectors back (siegel_bwd_split_kernel.hpp: a separate, not inlined function -- nothing of it touches the common path's registers).
+// generic batch never takes it).  The default `refine` still has the points (CPU build, tests) and replaces the eigenvalues by the
+// quotients with E formed AGAIN.  The gfx950 spectral kernel only takes note: the wave hands on zero packs and a flag, and a third
+// launch runs the one-stage kernel (pair_backward: the same quotients) on the flagged waves (siegel_bwd_split_kernel.hpp,
+// siegel_bwd_split.hip).  [Doing the refinement inside the spectral kernel -- V parked in the workspace, a not-inlined function
+// that reloads the rows -- was built first: the call's spills landed next to the gather's hand-counted s_waitcnt vmcnt and the
+// common path read its LDS tile early (wrong gradients at n = 7, +6 % time at n = 8).  Nothing of the rare path lives there now.]
 // ---------------------------------------------------------------------------------------------
 constexpr double SPLIT_GRADED_RATIO = 1e-5;       // eps / 1e-5 = 2e-11 of relative error in a weight is what the QL route may leave
 

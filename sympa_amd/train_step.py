@@ -280,6 +280,9 @@ class GraphedTrainStep:
         loss = torch.zeros(1, dtype=torch.float64, device=table.device)
         ids = ids[:, :2].contiguous()
         gd = gd.to(torch.float64).contiguous()
+        if b > 0 and self._merge_flags():           # (as in __call__: runs of equal source ids exist in sorted batches only)
+            order = torch.argsort(ids[:, 0], stable=True)
+            ids, gd = ids[order].contiguous(), gd[order].contiguous()
         if b > 0 and not self.deterministic:
             ops.model_train_backward(table.data, ids, gd, b, loss, man.model_name, man.metric.kind.value,
                                      None if weights is None else weights.data, gw, m.scale.data, gs, m.scale_coef, 1.0,
@@ -396,6 +399,11 @@ class GraphedTrainStep:
                 return self.loss
             return loss
         b = self.batch_size
+        if self.mode == "two_kernels" and self._merge_flags():
+            # the merged-rows backward sums RUNS of equal source ids inside a wave: a caller-ordered batch has next to none and would
+            # only pay the tile walk (round-5 advice) -- the order inside a batch is free, so it is sorted here like load_epoch does
+            order = torch.argsort(ids[:, 0], stable=True)
+            ids, gd = ids[order], gd[order]
         self.ids[:b].copy_(ids[:, :2])
         self.gd[:b].copy_(gd)
         if self.mode == "two_kernels":

@@ -60,6 +60,23 @@ def test_digest_and_refresh_entries_validate_their_arguments_without_gpu():
     assert lib.sympa_spd_table_pack_refresh(al, 10, 16, al, 1 << 20, None, 0, None, None) == -1
 
 
+def test_merged_rows_flag_is_refused_where_no_kernel_honours_it():
+    """SYMPA_FLAG_MERGE_SRC with per-pair rows (round-5 advice): only the one-lane kernels of dims <= 6 write the merged layout; the
+    split / eight-lanes / dims >= 7 kernels would write every row while the caller's slot list drops all but the run ends."""
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)   # never dereferenced: refused before any launch
+    D = ctypes.c_double
+    MERGE, SPLIT, COOP = 128, 64, 32
+
+    def call(n, flags, rows=True):
+        return lib.sympa_model_train_backward(one, 100, n, one, 2, one, 2, one, 64, None, 0, 0, None, D(1e-5), None, D(1.0), D(1.0),
+                                              one, None if rows else one, one if rows else None, None, None, None, None, None, 0,
+                                              flags, None)
+    assert call(8, MERGE) == -1 and b"MERGE_SRC" in lib.sympa_last_error()
+    assert call(7, MERGE) == -1
+    assert call(6, MERGE | SPLIT) == -1 and call(5, MERGE | COOP) == -1
+
+
 def test_radam_entry_points_validate_their_arguments_without_gpu():
     lib = _lib.load()
     one = ctypes.c_void_p(16)   # never dereferenced: validation happens before any launch

@@ -137,10 +137,10 @@ def _ws(b, n, model, dev):
 @pytest.mark.gpu
 def test_gpu_split_workspace_size():
     from sympa_amd import ops
-    # entries per pair: the pack (AdjPack::LEN) or the 2 n^2 doubles of V parked there by the graded-spectrum path, whichever is larger
-    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 128 * 262144 * 8
-    assert ops.siegel_backward_workspace_bytes(65, 5, "bounded") == (2 * 5 + 4 * 10) * 128 * 8
-    assert ops.siegel_backward_workspace_bytes(65, 5, "upper") == 50 * 128 * 8
+    # the packs [AdjPack::LEN][padded b] + one int per wave of 64 pairs (graded-spectrum flags), rounded to 16 bytes
+    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 100 * 262144 * 8 + 4096 * 4
+    assert ops.siegel_backward_workspace_bytes(65, 5, "bounded") == (2 * 5 + 4 * 10) * 128 * 8 + 16
+    assert ops.siegel_backward_workspace_bytes(1000, 6, "upper") == (2 * 6 + 3 * 15) * 1024 * 8 + 64
     assert ops.siegel_backward_workspace_bytes(1000, 4, "upper") == 0 and ops.siegel_backward_workspace_bytes(1000, 9, "upper") == 0
 
 
