@@ -20,8 +20,9 @@ struct BwdArgs {
     double* wave_partials;      // deterministic mode: [waves][2 + n] per-wave sums (loss, d loss / d scale, d loss / d w_k) are
                                 // WRITTEN here instead of being added to loss / gscale / gw with atomics; a later kernel
                                 // (sympa_segment_sum_rows) adds them up in a fixed order
-    const int* chunk_mask;      // one-pair-per-lane kernels: [ceil(b / 64)] -- a wave whose word is 0 returns at once (the split
-                                // backward hands its graded-spectrum waves to these kernels, siegel_bwd_split.hip); null: all
+    const int* chunk_list;      // one-pair-per-lane kernels of dims 5..8 (siegel_bwd_list_kernel): [0] = count, [1 + k] = index of a
+                                // 64-pair chunk of the batch -- only those chunks are processed, by a small fixed grid that walks the
+                                // list (the split backward hands its graded-spectrum waves over this way, siegel_bwd_split.hip); null: all
 };
 
 // (Scattering only the n(n+1) upper-triangle entries of the symmetric rows and mirroring afterwards was
@@ -240,32 +241,24 @@ __device__ __attribute__((noinline)) void scatter_add_rows_outlined(const sympa:
 // Round 6: upper model, n = 4 -- the two Cholesky factors (28 doubles) wait in the wave's LDS tile between the solves that form E
 // and the back-substitutions (pair_backward's park / unpark): 294 -> <= 256 registers without scratch, two blocks per CU.
 template <int N, int MODEL>
-#ifdef SYMPA_AB_OLD_N4_BWD
-constexpr bool bwd_parks_factors() { return false; }
-#else
 constexpr bool bwd_parks_factors() { return N == 4 && MODEL == sympa::MODEL_UPPER; }
-#endif
 template <int N, int MODEL, bool SCATTER>
 constexpr int bwd_min_blocks() { return bwd_parks_factors<N, MODEL>() ? 2 : 1; }
 
+template <int N, bool SCATTER>
+struct BwdLds {
+    static constexpr int GATHER_SLOTS = DmaTile<N>::ENABLED ? DmaTile<N>::WAVE_SLOTS_LOW : Tile<N>::WAVE_SLOTS;
+    static constexpr bool ROWS_TILE = !SCATTER && !ScatterTile<N>::BY_PLANE;      // per-pair rows leave through the tile too (n <= 6)
+    static constexpr int SCATTER_SLOTS = (SCATTER || ROWS_TILE) ? (ScatterTile<N>::WAVE_DOUBLES + 1) / 2 : 1;
+    static constexpr int WAVE_SLOTS = GATHER_SLOTS > SCATTER_SLOTS ? GATHER_SLOTS : SCATTER_SLOTS;
+};
+
+// One wave's 64 pairs [i - lane, i - lane + 64) of the batch window: everything siegel_bwd_kernel does (the kernel below is this
+// body once per wave; siegel_bwd_list_kernel runs it for the chunks of a list).  `tile`: the wave's LDS tile.
 template <int N, int MODEL, bool SCATTER>
-__global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, MODEL, SCATTER>())) void siegel_bwd_kernel(const BwdArgs a) {
-    constexpr int BLOCK = bwd_block<N>();
-    constexpr int GATHER_SLOTS = DmaTile<N>::ENABLED ? DmaTile<N>::WAVE_SLOTS_LOW : Tile<N>::WAVE_SLOTS;
-    constexpr bool ROWS_TILE = !SCATTER && !ScatterTile<N>::BY_PLANE;      // per-pair rows leave through the tile too (n <= 6)
-    constexpr int SCATTER_SLOTS = (SCATTER || ROWS_TILE) ? (ScatterTile<N>::WAVE_DOUBLES + 1) / 2 : 1;
-    constexpr int WAVE_SLOTS = GATHER_SLOTS > SCATTER_SLOTS ? GATHER_SLOTS : SCATTER_SLOTS;
-    __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
-    DistArgs f = a.f;
-    const double* graph_dist = a.graph_dist;
-    if (f.batch_counter != nullptr) {            // the training graph's batch window (see DistArgs)
-        const int64_t off = f.batch_counter[0] * f.b;
-        f.idx1 += off * f.idx1_stride;
-        f.idx2 += off * f.idx2_stride;
-        if (graph_dist != nullptr) graph_dist += off;
-    }
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a.chunk_mask != nullptr && a.chunk_mask[i >> 6] == 0) return;      // (wave-uniform; no block-level barrier in this kernel)
+__device__ __forceinline__ void siegel_bwd_body(const BwdArgs& a, const DistArgs& f, const double* __restrict__ graph_dist,
+                                                const int64_t i, v2d* __restrict__ tile) {
+    constexpr bool ROWS_TILE = BwdLds<N, SCATTER>::ROWS_TILE;
     const bool live = i < f.b;
     const int64_t ii = live ? i : f.b - 1;
 
@@ -283,7 +276,6 @@ __global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, MODEL, SCATTER>(
         }
     }
     constexpr int64_t ROW = 2 * N * N;
-    v2d* tile = lds + (threadIdx.x >> 6) * WAVE_SLOTS;
     sympa::CMat<N> z1, z2;
     if constexpr (DmaTile<N>::ENABLED) {
         gather_pair_dma_low<N>(f.base1, (int)r1, f.base2, (int)r2, tile, z1, z2);
@@ -440,9 +432,61 @@ SYMPA_UNROLL
     }
 }
 
+__device__ __forceinline__ void bwd_batch_window(const BwdArgs& a, DistArgs& f, const double*& graph_dist) {
+    f = a.f;
+    graph_dist = a.graph_dist;
+    if (f.batch_counter != nullptr) {            // the training graph's batch window (see DistArgs)
+        const int64_t off = f.batch_counter[0] * f.b;
+        f.idx1 += off * f.idx1_stride;
+        f.idx2 += off * f.idx2_stride;
+        if (graph_dist != nullptr) graph_dist += off;
+    }
+}
+
+template <int N, int MODEL, bool SCATTER>
+__global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, MODEL, SCATTER>())) void siegel_bwd_kernel(const BwdArgs a) {
+    constexpr int BLOCK = bwd_block<N>();
+    constexpr int WAVE_SLOTS = BwdLds<N, SCATTER>::WAVE_SLOTS;
+    __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
+    DistArgs f;
+    const double* graph_dist;
+    bwd_batch_window(a, f, graph_dist);
+    siegel_bwd_body<N, MODEL, SCATTER>(a, f, graph_dist, (int64_t)blockIdx.x * BLOCK + threadIdx.x, lds + (threadIdx.x >> 6) * WAVE_SLOTS);
+}
+
+// The same body over the chunks of a.chunk_list (dims 5..8): a fixed small grid, wave w takes chunks w, w + W, ...  Launched by the
+// split backward for the waves its first stage flagged (graded spectra): usually none at all, and the 64 waves of this grid cost a
+// few microseconds where a full grid of the (spilling, scratch-heavy) dims 7, 8 kernels whose waves return at once cost ~30.
+constexpr int BWD_LIST_WAVES = 64;
+template <int N, int MODEL, bool SCATTER>
+__global__ __launch_bounds__(bwd_block<N>(), 1) void siegel_bwd_list_kernel(const BwdArgs a) {
+    constexpr int BLOCK = bwd_block<N>();
+    constexpr int WAVE_SLOTS = BwdLds<N, SCATTER>::WAVE_SLOTS;
+    __shared__ v2d lds[(BLOCK / 64) * WAVE_SLOTS];
+    DistArgs f;
+    const double* graph_dist;
+    bwd_batch_window(a, f, graph_dist);
+    const int count = a.chunk_list[0];
+    const int waves = (int)gridDim.x * (BLOCK / 64);
+    for (int c = (int)blockIdx.x * (BLOCK / 64) + (int)(threadIdx.x >> 6); c < count; c += waves) {       // wave-uniform
+        wave_lds_fence();
+        siegel_bwd_body<N, MODEL, SCATTER>(a, f, graph_dist, (int64_t)a.chunk_list[1 + c] * 64 + (threadIdx.x & 63),
+                                           lds + (threadIdx.x >> 6) * WAVE_SLOTS);
+        __builtin_amdgcn_s_waitcnt(0);
+        wave_lds_fence();
+    }
+}
+
 template <int N, int MODEL, bool SCATTER>
 int launch_bwd_nms(const BwdArgs& a, hipStream_t s) {
     constexpr int BLOCK = bwd_block<N>();
+    if constexpr (N >= 5) {
+        if (a.chunk_list != nullptr) {
+            hipLaunchKernelGGL((siegel_bwd_list_kernel<N, MODEL, SCATTER>), dim3(BWD_LIST_WAVES / (BLOCK / 64)), dim3(BLOCK), 0, s, a);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+        }
+    }
     const unsigned grid = (unsigned)((a.f.b + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL((siegel_bwd_kernel<N, MODEL, SCATTER>), dim3(grid), dim3(BLOCK), 0, s, a);
     const hipError_t e = hipGetLastError();

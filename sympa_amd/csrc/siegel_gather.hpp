@@ -381,7 +381,6 @@ __device__ __forceinline__ void pass_issue(const double* __restrict__ base, cons
                                            v2d* __restrict__ buf, const int my_chunk) {
     constexpr int K = PassTile<N, MASKED>::K;
     const int lane = threadIdx.x & 63;
-#ifndef SYMPA_OLD_PASS_ISSUE          // (tools/build_variant.sh -DSYMPA_OLD_PASS_ISSUE: the per-instruction form for an A/B)
     // One lane mask around the pass instead of a save / restore of EXEC per instruction, the LDS destinations without a null check
     // (lds_dest); the row indices are read (v_readlane: a scalar base address per row) IN FRONT of the mask -- behind the branch the
     // compiler may compute `row` for the active lanes only, and a pass reads lanes K..63 as well.  Both models since the end of
@@ -399,15 +398,6 @@ __device__ __forceinline__ void pass_issue(const double* __restrict__ base, cons
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
         }
     }
-#else
-#pragma unroll
-    for (int j = 0; j < PassTile<N>::ROWS; ++j) {
-        const int rr = MASKED ? __shfl(row, 16 * pass + j) : __builtin_amdgcn_readlane(row, 16 * pass + j);
-        const double* src = base + (int64_t)rr * (2 * N * N) + 2 * my_chunk;
-        if (K == 64 || lane < K)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, lds_dest(buf + j * PassTile<N, MASKED>::PITCH), 16, 0, 0);
-    }
-#endif
 }
 
 template <int N, bool MASKED>

@@ -751,7 +751,6 @@ SYMPA_UNROLL
     bool finite;
     double out = spectral_adjoint<N, MODEL>(h.d, metric, w, inv_eps, go, phi, philam, gw, finite);
 
-#ifndef SYMPA_AB_OLD_N4_BWD
     if constexpr (MODEL == MODEL_UPPER && N <= 4) {
         upper_adjoint_tail_lean<N>(e, v, phi, philam, l1, l2, unpark, g1, g2);
         if (!finite) out = __builtin_nan("");
@@ -760,7 +759,6 @@ SYMPA_UNROLL
         if (!d_finite(out)) status |= ST_NONFINITE;
         return out;
     }
-#endif
 
     // closed forms (header comment): no Cholesky adjoint -- the factors only enter through congruences.
     // (Forming U = E V once and Ebar = 2 U diag(phi) V^H, G = U diag(phi) U^H from it saves a product but keeps three

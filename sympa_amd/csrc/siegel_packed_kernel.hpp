@@ -25,13 +25,11 @@
 #pragma once
 #include "siegel_common.hpp"
 
-// x 64 cycles per step of the staggered first round (tools/build_variant.sh -DSYMPA_PACKED_STAGGER_SLEEP=<k> for an A/B; measured on
-// the final build of round 5, 262 144 pairs of 45 500 rows: n = 8 0 / 6 / 12 / 16 / 20 / 28 / 40 -> 129.7 / 124.1 / 117.7 / 116.9 /
-// 116.6 / 121.9 / 131.4 us, n = 7 0 / 12 / 16 / 20 / 28 -> 99.0 / 90.3 / 90.3 / 93.5 / 99.5 us; sleeping AFTER the first tile's head
-// is in flight: no better)
-#ifndef SYMPA_PACKED_STAGGER_SLEEP
-#define SYMPA_PACKED_STAGGER_SLEEP (N >= 8 ? 20 : 16)
-#endif
+// x 64 cycles per step of the staggered first round (measured on the final build of round 5, 262 144 pairs of 45 500 rows: n = 8
+// 0 / 6 / 12 / 16 / 20 / 28 / 40 -> 129.7 / 124.1 / 117.7 / 116.9 / 116.6 / 121.9 / 131.4 us, n = 7 0 / 12 / 16 / 20 / 28 -> 99.0 / 90.3 /
+// 90.3 / 93.5 / 99.5 us; sleeping AFTER the first tile's head is in flight: no better)
+template <int N>
+constexpr int packed_stagger_sleep() { return N >= 8 ? 20 : 16; }
 
 namespace sympa_hip {
 
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(64, 1) void packed_forward_kernel(const PackedArgs 
     // waves stay out of step from there on; upper n = 8: 135.9 -> 126.9 us)
     if (a.stagger && blockIdx.x < 1024u) {
         const int k = (int)((blockIdx.x >> 5) & 31u);
-        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(packed_stagger_sleep<N>());
     }
     unsigned t = blockIdx.x;
     if (t >= a.tiles) return;
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(64, 1) void dense_forward_kernel(const PackedArgs a
     v2d* buf1 = tile + R::BUF_SLOTS;
     if (a.stagger && blockIdx.x < 1024u) {
         const int k = (int)((blockIdx.x >> 5) & 31u);
-        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(SYMPA_PACKED_STAGGER_SLEEP);
+        for (int j = 0; j < k; ++j) __builtin_amdgcn_s_sleep(packed_stagger_sleep<N>());
     }
     unsigned t = blockIdx.x;
     if (t >= a.tiles) return;

@@ -137,10 +137,10 @@ def _ws(b, n, model, dev):
 @pytest.mark.gpu
 def test_gpu_split_workspace_size():
     from sympa_amd import ops
-    # the packs [AdjPack::LEN][padded b] + one int per wave of 64 pairs (graded-spectrum flags), rounded to 16 bytes
-    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 100 * 262144 * 8 + 4096 * 4
+    # the packs [AdjPack::LEN][padded b] + the list of graded-spectrum waves (a count + one int per wave of 64 pairs), rounded to 16 bytes
+    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 100 * 262144 * 8 + (4097 * 4 + 15) // 16 * 16
     assert ops.siegel_backward_workspace_bytes(65, 5, "bounded") == (2 * 5 + 4 * 10) * 128 * 8 + 16
-    assert ops.siegel_backward_workspace_bytes(1000, 6, "upper") == (2 * 6 + 3 * 15) * 1024 * 8 + 64
+    assert ops.siegel_backward_workspace_bytes(1000, 6, "upper") == (2 * 6 + 3 * 15) * 1024 * 8 + 80
     assert ops.siegel_backward_workspace_bytes(1000, 4, "upper") == 0 and ops.siegel_backward_workspace_bytes(1000, 9, "upper") == 0
 
 
@@ -211,8 +211,11 @@ def test_gpu_split_backward_on_graded_spectra(dev, model, n):
             ops.check_status(dev)
             o1, o2, ow = ops.siegel_dist_backward(z1.to(dev), z2.to(dev), go.to(dev), model, m, w.to(dev), flags=ops.FLAG_GENERIC)
             ops.check_status(dev)
-            assert per_pair_rel(s1.cpu(), o1.cpu()).max() < tol and per_pair_rel(s2.cpu(), o2.cpu()).max() < tol, \
-                (model, n, grade, m, per_pair_rel(s1.cpu(), o1.cpu()).max())
+            e1, e2 = per_pair_rel(s1.cpu(), o1.cpu()), per_pair_rel(s2.cpu(), o2.cpu())
+            # pairs 64..191 sit in the two waves that hold the graded pairs (100..139): the one-stage kernel itself ran them
+            assert e1[64:192].max() < 1e-13 and e2[64:192].max() < 1e-13, (model, n, grade, m, e1[64:192].max(), e2[64:192].max())
+            # the other two waves: generic pairs through the split kernels (QL eigenvalues), as in the test above
+            assert e1.max() < 1e-9 and e2.max() < 1e-9, (model, n, grade, m, e1.max(), e2.max())
             h = hostsim_dist_bwd_split(z1.numpy(), z2.numpy(), go.numpy(), model, m, w.numpy())
             assert per_pair_rel(s1.cpu(), h[1]).max() < max(tol, 1e-9) and per_pair_rel(s2.cpu(), h[2]).max() < max(tol, 1e-9), (model, n, grade, m)
             if m == "wsum":
