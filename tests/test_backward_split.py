@@ -216,10 +216,67 @@ def test_gpu_split_backward_on_graded_spectra(dev, model, n):
             assert e1[64:192].max() < 1e-13 and e2[64:192].max() < 1e-13, (model, n, grade, m, e1[64:192].max(), e2[64:192].max())
             # the other two waves: generic pairs through the split kernels (QL eigenvalues), as in the test above
             assert e1.max() < 1e-9 and e2.max() < 1e-9, (model, n, grade, m, e1.max(), e2.max())
+            # Against the CPU build of the two stages (which refines in place).  On ONE platform the one-stage and the two-stage adjoint
+            # agree to 5e-11 even at a spread of 1e-12 (same H, same eigenvectors); ACROSS platforms (v_rsq / v_rcp seeds + corrections
+            # here, libm there) the eigenvectors of the small eigenvalues of H = E^H E move by eps / spread, and the gradient with them:
+            # measured 2e-9 at a spread of 1e-8, 1e-6 .. 8e-6 at 1e-12 -- the floor of ANY adjoint built on H at such spreads
+            # (north_star: 1e-4).
+            cross = {3: 1e-9, 4: 1e-8, 6: 1e-4}[grade]
             h = hostsim_dist_bwd_split(z1.numpy(), z2.numpy(), go.numpy(), model, m, w.numpy())
-            assert per_pair_rel(s1.cpu(), h[1]).max() < max(tol, 1e-9) and per_pair_rel(s2.cpu(), h[2]).max() < max(tol, 1e-9), (model, n, grade, m)
+            assert per_pair_rel(s1.cpu(), h[1]).max() < cross and per_pair_rel(s2.cpu(), h[2]).max() < cross, (model, n, grade, m)
             if m == "wsum":
-                assert relmax(sw.cpu(), ow.cpu()) < max(tol, 1e-9)
+                assert relmax(sw.cpu(), ow.cpu()) < 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_split_fused_step_with_graded_waves(dev):
+    """The fused training backward (loss + scatter into the table gradient + scale gradient + forward values) over a batch whose
+    waves 1 and 2 hold graded pairs: split kernels + the list kernel == the one-stage kernel, and the deterministic rows form with its
+    per-wave sums likewise; a replayed hipGraph of the three launches (+ the 4-byte memset of the list's counter) gives the same."""
+    from sympa_amd import ops
+    n, model, grade = 8, "upper", 4
+    g = torch.Generator().manual_seed(5)
+    ga, gb = graded_pairs(40, n, grade, seed=11)
+    pts = torch.cat((points(model, 300, n, 0.4, g), T(ga), T(gb)))                  # rows 300..339: z1 of the graded pairs, 340..379: z2
+    b = 1000
+    trip = torch.randint(0, 300, (b, 3), generator=g)
+    trip[100:140, 0] = torch.arange(300, 340)
+    trip[100:140, 1] = torch.arange(340, 380)
+    gd = (1.0 + (trip[:, 0] + trip[:, 1]) % 7).to(torch.float64)
+    table, trip_d, gd_d = pts.to(dev), trip.to(dev), gd.to(dev)
+    sc = torch.tensor([1.3], dtype=torch.float64, device=dev)
+
+    def run(flags, ws):
+        grad = torch.zeros_like(table)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.model_loss_backward(table, trip_d, gd_d, grad, loss, model, "fone", scale=sc, grad_scale=gs, flags=flags, workspace=ws)
+        ops.check_status(dev)
+        return grad, loss, gs
+
+    ws = _ws(b, n, model, dev)
+    g_s, l_s, s_s = run(0, ws)                      # split (default for upper n = 8 with a workspace)
+    g_o, l_o, s_o = run(ops.FLAG_GENERIC, None)     # one-stage
+    assert relmax(g_s.cpu(), g_o.cpu()) < 1e-9 and relmax(l_s.cpu(), l_o.cpu()) < 1e-12 and relmax(s_s.cpu(), s_o.cpu()) < 1e-10
+    # the rows of the graded pairs' table rows come from the list kernel alone: equal to the one-stage kernel's to rounding of the atomics
+    assert relmax(g_s[300:380].cpu(), g_o[300:380].cpu()) < 1e-13
+    # replayed
+    grad = torch.zeros_like(table)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        ops.model_loss_backward(table, trip_d, gd_d, grad, loss, model, "fone", scale=sc, workspace=ws)       # warm
+        grad.zero_(); loss.zero_()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            ops.model_loss_backward(table, trip_d, gd_d, grad, loss, model, "fone", scale=sc, workspace=ws)
+        grad.zero_(); loss.zero_()
+        gr.replay(); gr.replay()
+        side.synchronize()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    assert relmax(grad.cpu(), 2.0 * g_o.cpu()) < 1e-9 and relmax(loss.cpu(), 2.0 * l_o.cpu()) < 1e-12
+    ops.check_status(dev)
 
 
 @pytest.mark.gpu
