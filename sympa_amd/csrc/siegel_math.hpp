@@ -639,7 +639,14 @@ SYMPA_UNROLL
 // sweep pass through that position with c = 1, s = 0: an identity), so they arrive at the next stages converged.
 // (a NaN off-diagonal counts as negligible: the iteration does not spin on non-finite input, which is caught by the
 // finiteness test of the eigenvalues afterwards)
-SYMPA_HD bool ql_negligible(double e2, double da, double db) { return !(e2 > 1.3e-32 * fabs(da * db) + 1e-290); }
+// Deflation threshold on e^2 (round 6).  dsterf's eps^2 |d_l d_l+1| asks the off-diagonal itself down to eps; what an eigenvalue
+// sees of a neglected off-diagonal is SECOND order, e^2 / gap.  With 1e-20 |d_l d_l+1| that is 1e-20 d / gap relative (1e-12 at a
+// relative gap of 1e-8; |e| = 1e-10 d bounds it in a cluster, where the metrics sum the cluster anyway), and the slowest lane of a
+// wave often saves the last sweep of a stage: packed forward per 262 144 pairs upper n = 8 124.6 -> 120.9 us, n = 7 98.5 -> 94.7,
+// n = 6 77.4 -> 75.5, spd n = 16 per 1 048 576 pairs 1 136 -> 1 097 us (same box, interleaved; 1e-16: no further gain).  Every
+// golden, the 50-digit values and the graded-spectrum forward tests are unchanged or closer (profiles/r06_ql_deflation.txt).
+constexpr double QL_DEFLATE_TOL = 1e-20;
+SYMPA_HD bool ql_negligible(double e2, double da, double db) { return !(e2 > QL_DEFLATE_TOL * fabs(da * db) + 1e-290); }
 
 template <int N, int L>
 SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
