@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64, (coop_two_waves<MODEL, M>() ? 2 : 1)) void sieg
         finish_parked<M, TB>(park_all, lane, d, e2);
     }
     // one pair per lane: eigenvalues of H = E^H E, vector-valued distance, metric
-    const bool conv = sympa::tridiag_ql_lockstep<M>(d, e2);
+    const bool conv = sympa::tridiag_ql_lockstep<M, 0, true>(d, e2);      // (forward: eigenvalues only)
     double v[M];
     constexpr double quarter = (MODEL == sympa::MODEL_UPPER) ? 0.25 : 1.0;      // sinh(v/2) = sigma / 2 (upper), sigma (bounded)
     bool finite = true;          // tested before the clamp: fmax would turn a NaN eigenvalue into distance 0

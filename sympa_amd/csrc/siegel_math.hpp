@@ -645,27 +645,33 @@ SYMPA_UNROLL
 // wave often saves the last sweep of a stage: packed forward per 262 144 pairs upper n = 8 124.6 -> 120.9 us, n = 7 98.5 -> 94.7,
 // n = 6 77.4 -> 75.5, spd n = 16 per 1 048 576 pairs 1 136 -> 1 097 us (same box, interleaved; 1e-16: no further gain).  Every
 // golden, the 50-digit values and the graded-spectrum forward tests are unchanged or closer (profiles/r06_ql_deflation.txt).
+// FORWARD only (eigenvalues are all that leaves): the iterations that accumulate or feed eigenVECTORS (backward: tridiag_ql_vectors,
+// the inverse-iteration routes) keep eps^2 -- a vector sees a neglected off-diagonal in FIRST order, e / gap.
 constexpr double QL_DEFLATE_TOL = 1e-20;
-SYMPA_HD bool ql_negligible(double e2, double da, double db) { return !(e2 > QL_DEFLATE_TOL * fabs(da * db) + 1e-290); }
+SYMPA_HD bool ql_negligible(double e2, double da, double db) { return !(e2 > 1.3e-32 * fabs(da * db) + 1e-290); }
+template <bool VALUES_ONLY>
+SYMPA_HD bool ql_deflated(double e2, double da, double db) {
+    return !(e2 > (VALUES_ONLY ? QL_DEFLATE_TOL : 1.3e-32) * fabs(da * db) + 1e-290);
+}
 
-template <int N, int L>
+template <int N, int L, bool VALUES_ONLY>
 SYMPA_HD bool tridiag_ql_stage(double (&d)[N], double (&e2)[N]) {
     bool conv = false;
     for (int it = 0; it < 60; ++it) {
-        conv = ql_negligible(e2[L], d[L], d[L + 1]);
+        conv = ql_deflated<VALUES_ONLY>(e2[L], d[L], d[L + 1]);
         if (wave_all(conv)) break;
         double dl = d[L], dl1 = d[L + 1], el = e2[L];
         bool idle = conv;
         e2[L] = conv ? 0.0 : e2[L];
         if constexpr (L + 1 <= N - 2) {
-            const bool c1 = ql_negligible(e2[L + 1], d[L + 1], d[L + 2]);
+            const bool c1 = ql_deflated<VALUES_ONLY>(e2[L + 1], d[L + 1], d[L + 2]);
             dl = idle ? d[L + 1] : dl;
             dl1 = idle ? d[L + 2] : dl1;
             el = idle ? e2[L + 1] : el;
             idle = idle && c1;
             e2[L + 1] = idle ? 0.0 : e2[L + 1];
             if constexpr (L + 2 <= N - 2) {
-                const bool c2 = ql_negligible(e2[L + 2], d[L + 2], d[L + 3]);
+                const bool c2 = ql_deflated<VALUES_ONLY>(e2[L + 2], d[L + 2], d[L + 3]);
                 dl = idle ? d[L + 2] : dl;
                 dl1 = idle ? d[L + 3] : dl1;
                 el = idle ? e2[L + 2] : el;
@@ -708,13 +714,15 @@ SYMPA_UNROLL
     return conv;
 }
 
-template <int N, int L = 0>
+// VALUES_ONLY = true: the forward's eigenvalues (deflation at QL_DEFLATE_TOL); false (default): eps^2, for callers whose
+// eigenvalues feed eigenvectors or spectral weights of a backward
+template <int N, int L = 0, bool VALUES_ONLY = false>
 SYMPA_HD bool tridiag_ql_lockstep(double (&d)[N], double (&e2)[N]) {
     if constexpr (L >= N - 1) {
         return true;
     } else {
-        const bool here = tridiag_ql_stage<N, L>(d, e2);
-        const bool rest = tridiag_ql_lockstep<N, L + 1>(d, e2);
+        const bool here = tridiag_ql_stage<N, L, VALUES_ONLY>(d, e2);
+        const bool rest = tridiag_ql_lockstep<N, L + 1, VALUES_ONLY>(d, e2);
         return here && rest;
     }
 }
@@ -729,7 +737,7 @@ SYMPA_HD bool herm_eigenvalues(Herm<N>& h) {
     } else {
         double a[N], b2[N];
         herm_tridiagonalize<N>(h, a, b2);
-        const bool ok = tridiag_ql_lockstep<N>(a, b2);
+        const bool ok = tridiag_ql_lockstep<N, 0, true>(a, b2);
 SYMPA_UNROLL
         for (int i = 0; i < N; ++i) h.d[i] = a[i];
         return ok;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64, (spd_coop::trailing_block<M>() <= 10 ? 2 : 1)) 
 #pragma unroll
         for (int k = 0; k < M; ++k) { d[k] = dr[k]; e2[k] = er[k]; }
     }
-    const bool conv = sympa::tridiag_ql_lockstep<M>(d, e2);
+    const bool conv = sympa::tridiag_ql_lockstep<M, 0, true>(d, e2);      // (forward: eigenvalues only)
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < M; ++k) {

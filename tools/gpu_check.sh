@@ -2,7 +2,7 @@
 # One gpurun call: GPU tests, smoke, the numerical self-check of every lanes-per-pair kernel instantiation, bench at the
 # driver's K and at the default K, rocprofv3 kernel trace + PMC passes, secondary workloads, training path.
 # usage: tools/gpu_check.sh <tag> [notests]
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -93,5 +93,11 @@ echo "== round 5: soak of the packed indexed forward, the LDS-DMA micro-benchmar
 timeout 400 python3 tools/fuzz_packed.py 240 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/packed_soak.txt
 grep -q "fuzz ok" $OUT/packed_soak.txt || FAIL=1
 ( cd tools/microbench && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o lds_dma_rate lds_dma_rate.hip > /dev/null 2>&1 ); timeout 120 ./tools/microbench/lds_dma_rate 2>&1 | tee $OUT/lds_dma_rate.txt | tail -4
+echo "== round 6: device-side pack validity, measured clock, secondary rows alone, n = 4 backward at larger batches, rows + segmented sum at n = 8"
+timeout 300 python3 tools/pack_refresh_time.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pack_refresh.txt
+timeout 300 python3 tools/clock_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_probe.txt
+BUDGET_S=400 timeout 600 python3 tools/bench_rows.py 2>/dev/null | grep -v "^\[" | grep -v amdgpu.ids | tee $OUT/bench_rows.txt
+timeout 300 python3 tools/n4_bwd_batches.py 2>&1 | grep "upper n=4" | tee $OUT/n4_bwd_batches.txt
+timeout 300 python3 tools/n8_rows_vs_atomics.py 2>&1 | grep "upper n=" | tee $OUT/n8_rows_vs_atomics.txt
 echo "== gpu_check status: FAIL=$FAIL"
 exit $FAIL
