@@ -101,10 +101,14 @@ class Model(nn.Module):
                                         (weights is not None and weights.requires_grad)):
             return sa.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
         # no autograd graph to build (Runner.evaluate / build_distance_matrix run under no_grad): straight to the binding --
-        # dims 5..8 over the packed table once the same table version is seen a second time (ops.PackedTable)
+        # dims 5..8 over the packed table once the same table version is seen a second time (ops.PackedTable).  A SINGLE call pays
+        # the pack's validity check (a device-side digest of the table: ops.PackedTable.strict) every time: for the upper model that
+        # is what the pack saves (n = 8, 262 144 pairs of 45 500 rows: packed 121 + check 18-21 us against 133 dense; n = 6: 75 + 14
+        # against 84), so its single calls stay on the dense kernels and the pack serves the list forms (one check per K batches);
+        # the bounded model gains far more than the check costs (154 + 18 against 244).
         if 5 <= table.shape[-1] <= 8 and input_triplet.shape[0] >= PACKED_MIN_PAIRS:
             pk = self.packed_table()
-            if pk is not None and pk.current(table, input_triplet.shape[0]):
+            if pk is not None and (model_name == "bounded" or not pk.strict) and pk.current(table, input_triplet.shape[0]):
                 return ops.model_forward_packed(pk, input_triplet, metric_name, weights, scale, self.scale_coef)
         return ops.model_forward(table, input_triplet, model_name, metric_name, weights, scale, self.scale_coef)
 

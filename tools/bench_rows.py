@@ -137,7 +137,9 @@ def forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, table_c
             ms, dev_us = _time(run, dev, steps, launches)
             ops.check_status(dev)
             out0 = olist[0] if form == "list" else last[0]
-            packed_now = pk is not None and pk.key is not None and batch * (steps if form == "list" else 1) >= 4096
+            # (single calls of the upper model stay on the dense kernel while the pack's validity check is on: sympa_amd/model.py)
+            packed_now = pk is not None and pk.key is not None and batch * (steps if form == "list" else 1) >= 4096 and \
+                (form == "list" or model != "upper" or not pk.strict)
             row = {"workload": name, "kind": "forward", "form": form,
                    "api": ("Model.forward_batches(Model.prepare_batches(K batches))" if form == "list"
                            else "Model.forward(batch) under no_grad, once per step"),

@@ -26,5 +26,23 @@ cp $SRC/eval_epoch.txt $DST/${TAG}_eval_epoch.txt
 cp $SRC/host_call.txt $DST/${TAG}_host_call.txt
 cp $SRC/dist_step.txt $DST/${TAG}_dist_step.txt
 tail -3 $SRC/pytest.log > $DST/${TAG}_gpu_pytest_tail.txt
-[ -f profiles/pmc_latest.json ] && python3 tools/pmc_summary.py --help > /dev/null 2>&1 || true
+# round 6
+for F in pack_refresh clock_probe bench_rows n4_bwd_batches n8_rows_vs_atomics packed_soak atomic_rate lds_dma_rate; do
+  [ -f $SRC/$F.txt ] && cp $SRC/$F.txt $DST/${TAG}_$F.txt
+done
+# the PMC pass of the headline command (tools/pmc_collect.sh <tag>): per-round summary + the entry bench.py falls back to
+if [ -f gpurun_out/pmc_$TAG/summary.json ]; then
+  cp gpurun_out/pmc_$TAG/summary.json $DST/${TAG}_pmc_summary.json
+  python3 - "$TAG" <<'PY'
+import json, sys
+tag = sys.argv[1]
+cur = json.load(open("profiles/pmc_latest.json"))
+new = json.load(open(f"gpurun_out/pmc_{tag}/summary.json"))
+new["round"] = tag
+new["source"] = (f"tools/pmc_collect.sh {tag} (rocprofv3 --pmc, one counter group per pass, `bench.py --steps 128 --warmup 32`: fused "
+                 "launches of 32 steps, every counter normalised by the work-items of its dispatches)")
+cur["upper-riem-n4-b65536"] = new
+json.dump(cur, open("profiles/pmc_latest.json", "w"), indent=1)
+PY
+fi
 echo copied
