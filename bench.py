@@ -140,7 +140,8 @@ def cpu_baseline(model, metric, n, nodes, batch, seed, budget_s=12.0, pairs=None
     best = (None, 0.0)
     by_threads = {}
     with torch.no_grad():
-        for threads in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
+        # (every logical CPU of a 256-thread host collapses batched LAPACK to ~900 pairs/s and costs 3 s of this leg: capped at 64)
+        for threads in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
             torch.set_num_threads(threads)
             oracle_forward(table, probe[:1024], model, metric)     # warm
             t0 = time.perf_counter()
