@@ -331,3 +331,36 @@ def test_sort_batches_by_source():
         assert bool((b[1:, 0] >= b[:-1, 0]).all())
         assert torch.equal(b, a[torch.argsort(a[:, 0], stable=True)])
     assert torch.equal(data.sort_batches_by_source(t[:100], 256), t[:100])
+
+
+def test_clock_stamps_are_paired_per_cu():
+    """tools/clock_util.between (host side of C-ABI sympa_clock_stamp, bench.py `clock`): the shader-cycle counters of different CUs
+    are not comparable, so only stamps taken on the SAME CU (XCC id + the CU / SH / SE bits of HW_ID) are paired; the clock is the
+    median over the CUs seen by both stamps."""
+    import os
+    import sys
+    from tests.helpers import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import clock_util
+
+    def stamp(offsets, t_real, mhz):
+        rows = torch.zeros(clock_util.BLOCKS, 3, dtype=torch.int64)
+        for b in range(clock_util.BLOCKS):
+            cu = b % 32                      # 32 CUs, 64 blocks each
+            xcc = cu % 8
+            hw = (cu // 8) << 8              # CU field of HW_ID (bits 8..11)
+            rows[b, 0] = offsets[cu] + int(t_real * mhz[cu] / 100.0)
+            rows[b, 1] = t_real + b          # blocks start a little apart (100 MHz ticks)
+            rows[b, 2] = xcc | (hw << 8)
+        return rows.reshape(-1)
+
+    offsets = [10 ** 9 * (k + 1) for k in range(32)]         # wildly different counter origins per CU
+    mhz = [2000.0 + 10.0 * k for k in range(32)]
+    a = stamp(offsets, 1_000_000, mhz)
+    b = stamp(offsets, 1_000_000 + 50_000, mhz)              # 500 us later
+    # (the synthetic counter is linear in the real time of block 0: every CU's clock comes back exactly)
+    r = clock_util.between(a, b)
+    assert r["cus_paired"] == 32 and abs(r["region_us"] - 500.0) < 1e-6
+    assert abs(r["mhz_min_cu"] - 2000.0) < 0.5 and abs(r["mhz_max_cu"] - 2310.0) < 0.5 and abs(r["mhz"] - 2160.0) < 0.5
+    assert sorted(r["mhz_per_xcd"]) == [str(x) for x in range(8)]
+    assert clock_util.between(None, b) is None
