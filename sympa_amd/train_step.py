@@ -141,6 +141,8 @@ class GraphedTrainStep:
         self.graph = None            # the captured launches hold the old addresses
 
     def _merge_flags(self):
+        if not self.__dict__.get("_sorted_by_source", True):       # (a fresh object assumes the load_epoch path)
+            return 0
         return ops.FLAG_MERGE_SRC if merges_source_rows(self.model, self.deterministic, self.batch_size) else 0
 
     def _bwd_ws(self, table, b):
@@ -312,7 +314,7 @@ class GraphedTrainStep:
         return (tuple((float(g["lr"]), float(g.get("weight_decay", 0.0)),
                        tuple(float(x) for x in g["betas"]) if "betas" in g else None,
                        float(g["eps"]) if "eps" in g else None) for g in self.opt.param_groups),
-                self.max_grad_norm)
+                self.max_grad_norm, self._merge_flags())
 
     def _fused_signature(self):
         """What the fused optimiser kernel's plan bakes in beside lr / weight decay (passed per run): the addresses of the
@@ -399,11 +401,11 @@ class GraphedTrainStep:
                 return self.loss
             return loss
         b = self.batch_size
-        if self.mode == "two_kernels" and self._merge_flags():
-            # the merged-rows backward sums RUNS of equal source ids inside a wave: a caller-ordered batch has next to none and would
-            # only pay the tile walk (round-5 advice) -- the order inside a batch is free, so it is sorted here like load_epoch does
-            order = torch.argsort(ids[:, 0], stable=True)
-            ids, gd = ids[order], gd[order]
+        # the merged-rows backward sums RUNS of equal source ids inside a wave: a caller-ordered batch has next to none and would only
+        # pay the tile walk (round-5 advice).  Sorting it here costs more than the walk (argsort + two gathers: +67 us per step at the
+        # headline shape, measured), so the flag is simply off for batches this object did not sort itself (load_epoch does);
+        # the captured graph bakes the flag in and is re-captured when a caller switches between the two ways of feeding it.
+        self._sorted_by_source = False
         self.ids[:b].copy_(ids[:, :2])
         self.gd[:b].copy_(gd)
         if self.mode == "two_kernels":
@@ -435,6 +437,7 @@ class GraphedTrainStep:
             triplets = data.sort_batches_by_source(triplets, b)
         self.ids[:total].copy_(triplets[:, :2])
         self.gd[:total].copy_(triplets[:, 2])
+        self._sorted_by_source = True
         if self.deterministic and steps > 0:
             used = self.ids[:steps * b].view(steps, b, 2)
             order, rowptr = ops.sorted_slots(torch.cat((used[:, :, 0], used[:, :, 1]), dim=1),
