@@ -20,9 +20,9 @@ struct BwdArgs {
     double* wave_partials;      // deterministic mode: [waves][2 + n] per-wave sums (loss, d loss / d scale, d loss / d w_k) are
                                 // WRITTEN here instead of being added to loss / gscale / gw with atomics; a later kernel
                                 // (sympa_segment_sum_rows) adds them up in a fixed order
-    const int* chunk_list;      // one-pair-per-lane kernels of dims 5..8 (siegel_bwd_list_kernel): [0] = count, [1 + k] = index of a
-                                // 64-pair chunk of the batch -- only those chunks are processed, by a small fixed grid that walks the
-                                // list (the split backward hands its graded-spectrum waves over this way, siegel_bwd_split.hip); null: all
+    const int* chunk_flags;     // one-pair-per-lane kernels of dims 5..8 (siegel_bwd_list_kernel): one word per 64-pair chunk of the
+                                // batch -- only the chunks whose word is non-zero are processed, by a small fixed grid that scans the
+                                // words (the split backward hands its graded-spectrum waves over this way, siegel_bwd_split.hip); null: all
 };
 
 // (Scattering only the n(n+1) upper-triangle entries of the symmetric rows and mirroring afterwards was
@@ -454,9 +454,11 @@ __global__ __launch_bounds__(bwd_block<N>(), (bwd_min_blocks<N, MODEL, SCATTER>(
     siegel_bwd_body<N, MODEL, SCATTER>(a, f, graph_dist, (int64_t)blockIdx.x * BLOCK + threadIdx.x, lds + (threadIdx.x >> 6) * WAVE_SLOTS);
 }
 
-// The same body over the chunks of a.chunk_list (dims 5..8): a fixed small grid, wave w takes chunks w, w + W, ...  Launched by the
-// split backward for the waves its first stage flagged (graded spectra): usually none at all, and the 64 waves of this grid cost a
-// few microseconds where a full grid of the (spilling, scratch-heavy) dims 7, 8 kernels whose waves return at once cost ~30.
+// The same body over the flagged chunks of a.chunk_flags (dims 5..8): a fixed small grid; wave w reads the words [64 (w + k W),
+// 64 (w + k W) + 64), one per lane, and runs the body for every set one (wave-uniform loop over the ballot).  Launched by the split
+// backward for the waves its first stage flagged (graded spectra): usually none at all, and the 64 waves of this grid cost a few
+// microseconds where a full grid of the (spilling, scratch-heavy) dims 7, 8 kernels whose waves return at once cost ~30.  No counter,
+// no atomics, nothing to reset between launches: every wave of stage 1 writes its own word.
 constexpr int BWD_LIST_WAVES = 64;
 template <int N, int MODEL, bool SCATTER>
 __global__ __launch_bounds__(bwd_block<N>(), 1) void siegel_bwd_list_kernel(const BwdArgs a) {
@@ -466,14 +468,20 @@ __global__ __launch_bounds__(bwd_block<N>(), 1) void siegel_bwd_list_kernel(cons
     DistArgs f;
     const double* graph_dist;
     bwd_batch_window(a, f, graph_dist);
-    const int count = a.chunk_list[0];
+    const int chunks = (int)((f.b + 63) / 64);
     const int waves = (int)gridDim.x * (BLOCK / 64);
-    for (int c = (int)blockIdx.x * (BLOCK / 64) + (int)(threadIdx.x >> 6); c < count; c += waves) {       // wave-uniform
-        wave_lds_fence();
-        siegel_bwd_body<N, MODEL, SCATTER>(a, f, graph_dist, (int64_t)a.chunk_list[1 + c] * 64 + (threadIdx.x & 63),
-                                           lds + (threadIdx.x >> 6) * WAVE_SLOTS);
-        __builtin_amdgcn_s_waitcnt(0);
-        wave_lds_fence();
+    const int lane = (int)(threadIdx.x & 63);
+    for (int base = 64 * ((int)blockIdx.x * (BLOCK / 64) + (int)(threadIdx.x >> 6)); base < chunks; base += 64 * waves) {
+        const int word = (base + lane < chunks) ? a.chunk_flags[base + lane] : 0;
+        unsigned long long todo = __ballot(word != 0);                  // wave-uniform
+        while (todo != 0ull) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            wave_lds_fence();
+            siegel_bwd_body<N, MODEL, SCATTER>(a, f, graph_dist, (int64_t)(base + k) * 64 + lane, lds + (threadIdx.x >> 6) * WAVE_SLOTS);
+            __builtin_amdgcn_s_waitcnt(0);
+            wave_lds_fence();
+        }
     }
 }
 
@@ -481,7 +489,7 @@ template <int N, int MODEL, bool SCATTER>
 int launch_bwd_nms(const BwdArgs& a, hipStream_t s) {
     constexpr int BLOCK = bwd_block<N>();
     if constexpr (N >= 5) {
-        if (a.chunk_list != nullptr) {
+        if (a.chunk_flags != nullptr) {
             hipLaunchKernelGGL((siegel_bwd_list_kernel<N, MODEL, SCATTER>), dim3(BWD_LIST_WAVES / (BLOCK / 64)), dim3(BLOCK), 0, s, a);
             const hipError_t e = hipGetLastError();
             return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));

@@ -33,9 +33,9 @@ int pack_len(int n, int model) {
     const int offd = n * (n - 1) / 2;
     return 2 * n + 3 * offd + (model == SYMPA_MODEL_UPPER ? 0 : offd);            // sympa::AdjPack<n, model>::LEN
 }
-// behind the packs: the list of waves stage 1 hands to the one-stage kernel (SplitArgs::graded: a count + at most one entry per wave
-// of 64 pairs), rounded up to 16 bytes
-int64_t flag_bytes(int64_t b) { return ((1 + (b + 63) / 64) * (int64_t)sizeof(int) + 15) / 16 * 16; }
+// behind the packs: one word per wave of 64 pairs (SplitArgs::graded: 1 = stage 1 hands the wave to the one-stage kernel), rounded up
+// to 16 bytes
+int64_t flag_bytes(int64_t b) { return (((b + 63) / 64) * (int64_t)sizeof(int) + 15) / 16 * 16; }
 int64_t padded(int64_t b) { return (b + 63) / 64 * 64; }
 }  // namespace
 
@@ -66,7 +66,6 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
     sa.a.f.flags &= ~SYMPA_INTERNAL_FLAG_STAGGER;
     if (a.f.idx1 != nullptr && a.f.b >= 2048 * 64 && a.f.num_rows * (int64_t)(16 * n * n) >= ((int64_t)12 << 20))
         sa.a.f.flags |= SYMPA_INTERNAL_FLAG_STAGGER;
-    if (hipMemsetAsync(sa.graded, 0, sizeof(int), s) != hipSuccess) return fail(SYMPA_ERR_BAD_ARG, "split backward: workspace not writable");
     const bool upper = model == SYMPA_MODEL_UPPER;
     int rc;
     switch (n) {
@@ -97,11 +96,11 @@ int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* wor
     rc = gradient();
     if (rc != 0) return rc;
     // the waves stage 1 listed (graded spectra: siegel_math_bwd_split.hpp) through the one-stage kernel, which refines every
-    // eigenvalue to a Rayleigh quotient: a fixed grid of 64 waves that walks the list (usually empty).  Their packs were zero, so the
+    // eigenvalue to a Rayleigh quotient: a fixed grid of 64 waves that scans the words (usually all zero).  Their packs were zero, so the
     // gradient kernel added / wrote zeros for them; loss, forward values, scale / weight gradients, the deterministic per-wave
     // sums and the status of those waves come from this launch.
     BwdArgs fin = a;
-    fin.chunk_list = sa.graded;
+    fin.chunk_flags = sa.graded;
     fin.f.flags &= ~(SYMPA_FLAG_SPLIT | SYMPA_FLAG_COOP | SYMPA_INTERNAL_FLAG_STAGGER);
     return launch_bwd_one_lane(fin, n, model, scatter, s);
 }

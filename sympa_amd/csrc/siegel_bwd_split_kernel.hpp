@@ -16,8 +16,8 @@ struct SplitArgs {
     BwdArgs a;
     double* ws;              // [AdjPack<N, MODEL>::LEN][ws_stride] fp64
     int64_t ws_stride;       // >= b
-    int* graded;             // [0] = count (zeroed by the launcher), [1 + k] = a wave of 64 pairs stage 1 hands to the one-stage kernel
-                             // (graded spectrum: BwdArgs::chunk_list of the third launch); nullptr: no such hand-over
+    int* graded;             // [wave]: stage 1 writes 1 for a wave of 64 pairs it hands to the one-stage kernel (graded spectrum), 0
+                             // otherwise (BwdArgs::chunk_flags of the third launch); nullptr: no such hand-over
 };
 
 // entry base (wave-uniform: a scalar register pair) + 32-bit byte offset of the lane's pair: global_load/store ... v_off, s[base]
@@ -207,8 +207,8 @@ SYMPA_UNROLL
     // the eigenvalues cannot be refined to Rayleigh quotients here.  The wave hands on ZERO packs (the gradient kernel then adds /
     // writes zeros for its pairs), raises its flag and contributes nothing else; the third launch of launch_bwd_split runs the
     // one-stage kernel (pair_backward: quotients ||E v_i||^2 for every eigenvalue) on exactly the flagged waves.
+    if (threadIdx.x == 0 && sa.graded != nullptr) sa.graded[blockIdx.x] = redo ? 1 : 0;
     if (redo && sa.graded != nullptr) {
-        if (threadIdx.x == 0) sa.graded[1 + atomicAdd(&sa.graded[0], 1)] = (int)blockIdx.x;
         if (live) {
             const unsigned wo = (unsigned)i * 8u;
 SYMPA_UNROLL
@@ -428,7 +428,7 @@ int64_t bwd_split_workspace_bytes(int64_t b, int n, int model);
 bool bwd_split_available(int n, int model);
 int launch_bwd_split(const BwdArgs& a, int n, int model, bool scatter, void* workspace, int64_t workspace_bytes, hipStream_t s);
 // siegel_bwd.hip: the one-stage, one-pair-per-lane kernels of dims 1..8 (siegel_bwd_kernel), whatever the default dispatch prefers;
-// with a.chunk_list (dims 5..8) only the listed 64-pair chunks are processed, by a small fixed grid
+// with a.chunk_flags (dims 5..8) only the flagged 64-pair chunks are processed, by a small fixed grid
 int launch_bwd_one_lane(const BwdArgs& a, int n, int model, bool scatter, hipStream_t s);
 
 }  // namespace sympa_hip

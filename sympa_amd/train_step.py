@@ -22,7 +22,8 @@ import os
 
 import torch
 
-from sympa_amd import data, ops
+from sympa_amd import _lib, data, ops
+from sympa_amd import selfcheck as _sc
 from sympa_amd.manifolds.metrics import MetricType
 
 
@@ -193,21 +194,52 @@ class GraphedTrainStep:
             self._backward(self.counter)
             self._fused_step()
             return
+        # classic graph.  Siegel models (round 6): the backward addresses its batch through the device step counter like the
+        # two-kernel step (C-ABI sympa_model_train_backward), so an epoch's triplets are loaded ONCE (load_epoch / run_steps) and no
+        # batch is copied in per step (configs[3]: two copies of 4 + 2 MB, ~10 us of the 725 us step); __call__ zeroes the counter and
+        # copies its batch to the front of the same buffers.  The counter moves at the end of the graph.
+        windowed = self._classic_windowed()
         if self._zero_list is None:
             self.opt.zero_grad(set_to_none=False)
-            self.model.fused_loss_backward(self.ids[:self.batch_size], self.gd[:self.batch_size],
-                                           loss_out=self.loss, zero_loss_out=not self.accumulate_loss)
+            if windowed:
+                if not self.accumulate_loss:
+                    self.loss.zero_()
+                self._backward(self.counter)
+            else:
+                self.model.fused_loss_backward(self.ids[:self.batch_size], self.gd[:self.batch_size],
+                                               loss_out=self.loss, zero_loss_out=not self.accumulate_loss)
             self._clip_and_step()
+            if windowed:
+                self.counter.add_(1)
             return
         # gradients, the loss word and the optimiser's squared-norm word zeroed by ONE multi-tensor launch
         torch._foreach_zero_(self._zero_list)
-        self.model.fused_loss_backward(self.ids[:self.batch_size], self.gd[:self.batch_size], loss_out=self.loss,
-                                       zero_loss_out=False)
+        if windowed:
+            self._backward(self.counter)
+        else:
+            self.model.fused_loss_backward(self.ids[:self.batch_size], self.gd[:self.batch_size], loss_out=self.loss,
+                                           zero_loss_out=False)
         self.opt._sqnorm_zeroed_by_caller = True
         try:
             self._clip_and_step()
         finally:
             self.opt._sqnorm_zeroed_by_caller = False
+        if windowed:
+            self.counter.add_(1)
+
+    def _classic_windowed(self):
+        """Classic graph of a Siegel model on the GPU with dims <= 8 or the sixteen-lanes kernels (every family that honours the
+        batch window; the rolled one-lane kernels of dims 9..16 behind an instance fallback do not)."""
+        m = self.model
+        if self.mode != "classic" or getattr(m.manifold, "model_name", None) not in ("upper", "bounded") or self.deterministic:
+            return False
+        table = m.embeddings.embeds
+        if not (table.is_cuda and table.dim() == 4 and table.dtype == torch.float64):
+            return False
+        n = table.shape[2]
+        if n > 8 and _lib.load().sympa_get_instance_fallback(_sc.SIEGEL_BWD, ops.MODEL_IDS[m.manifold.model_name], int(n)):
+            return False
+        return True
 
     def _clip_and_step(self):
         if hasattr(self.opt, "clip_max_norm"):       # sympa_amd.optim.RiemannianSGD: the clip rides inside the step
@@ -408,6 +440,8 @@ class GraphedTrainStep:
         self._sorted_by_source = False
         self.ids[:b].copy_(ids[:, :2])
         self.gd[:b].copy_(gd)
+        if self.mode == "classic" and self._classic_windowed():
+            self.counter.zero_()
         if self.mode == "two_kernels":
             self.counter.zero_()
             if self.deterministic:
@@ -425,9 +459,10 @@ class GraphedTrainStep:
         shard, train.py:105-110).  Copies them into the step's persistent buffers once, builds the deterministic mode's
         sorted slot lists with ONE sort, resets the device step counter.  Returns the number of FULL batches
         `run_steps` may replay; the ragged remainder triplets[steps * batch:] goes through `eager` (or `__call__`)."""
-        if self.mode != "two_kernels":
-            raise RuntimeError("load_epoch / run_steps need the two-kernel step; this model runs the classic graph: "
-                               "call the object once per batch")
+        if self.mode != "two_kernels" and not self._classic_windowed():
+            raise RuntimeError("load_epoch / run_steps need a step whose backward addresses its batch through the device step "
+                               "counter (the Siegel models); this model runs the classic graph on a static batch: call the "
+                               "object once per batch")
         total = triplets.shape[0]
         b = self.batch_size
         steps = total // b

@@ -137,10 +137,10 @@ def _ws(b, n, model, dev):
 @pytest.mark.gpu
 def test_gpu_split_workspace_size():
     from sympa_amd import ops
-    # the packs [AdjPack::LEN][padded b] + the list of graded-spectrum waves (a count + one int per wave of 64 pairs), rounded to 16 bytes
-    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 100 * 262144 * 8 + (4097 * 4 + 15) // 16 * 16
+    # the packs [AdjPack::LEN][padded b] + one word per wave of 64 pairs (graded-spectrum flags), rounded to 16 bytes
+    assert ops.siegel_backward_workspace_bytes(262144, 8, "upper") == 100 * 262144 * 8 + 4096 * 4
     assert ops.siegel_backward_workspace_bytes(65, 5, "bounded") == (2 * 5 + 4 * 10) * 128 * 8 + 16
-    assert ops.siegel_backward_workspace_bytes(1000, 6, "upper") == (2 * 6 + 3 * 15) * 1024 * 8 + 80
+    assert ops.siegel_backward_workspace_bytes(1000, 6, "upper") == (2 * 6 + 3 * 15) * 1024 * 8 + 64
     assert ops.siegel_backward_workspace_bytes(1000, 4, "upper") == 0 and ops.siegel_backward_workspace_bytes(1000, 9, "upper") == 0
 
 
@@ -232,7 +232,7 @@ def test_gpu_split_backward_on_graded_spectra(dev, model, n):
 def test_gpu_split_fused_step_with_graded_waves(dev):
     """The fused training backward (loss + scatter into the table gradient + scale gradient + forward values) over a batch whose
     waves 1 and 2 hold graded pairs: split kernels + the list kernel == the one-stage kernel, and the deterministic rows form with its
-    per-wave sums likewise; a replayed hipGraph of the three launches (+ the 4-byte memset of the list's counter) gives the same."""
+    per-wave sums likewise; a replayed hipGraph of the three launches gives the same."""
     from sympa_amd import ops
     n, model, grade = 8, "upper", 4
     g = torch.Generator().manual_seed(5)

@@ -535,3 +535,43 @@ def test_harness_deterministic_training_is_bitwise_reproducible():
     assert h1 == h2
     assert torch.equal(m1.embeddings.embeds, m2.embeddings.embeds) and torch.equal(m1.scale, m2.scale)
     assert h1[-1][2] < h1[0][2]
+
+
+@pytest.mark.parametrize("n", [7, 8, 10])
+def test_classic_graph_addresses_its_batches_through_the_step_counter(n):
+    """Round 6: the classic graph of the Siegel models (dims >= 7: split backward at 7, 8, sixteen lanes at 10) reads its batch
+    through the device step counter like the two-kernel step, so `load_epoch` + `run_steps` work there too and no batch is copied
+    in per step.  Same tables, scale and loss as the same object called batch by batch (tolerance: atomics), with an eager ragged
+    batch at the end of each epoch and a per-batch call interleaved (it must not shift the window)."""
+    from sympa_amd import ops
+    from sympa_amd.optim import RiemannianSGD
+    from sympa_amd.train_step import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    nodes, batch, steps = 300, 2048, 3
+    g = torch.Generator().manual_seed(19)
+    total = steps * batch + 200
+    trip = torch.stack((torch.randint(0, nodes, (total,), generator=g), torch.randint(0, nodes, (total,), generator=g),
+                        torch.randint(1, 9, (total,), generator=g)), 1).to(dev)
+
+    def run(form):
+        m = _toy_model("upper", "riem", n, nodes, dev)
+        opt = RiemannianSGD(m.parameters(), lr=5e-3)
+        st = GraphedTrainStep(m, opt, batch, 2.0, dev, accumulate_loss=True)
+        assert st.mode == "classic" and st._classic_windowed()
+        for epoch in range(2):
+            if form == "calls":
+                for s in range(0, total, batch):
+                    st(trip[s:s + batch, :2], trip[s:s + batch, 2].to(torch.float64))
+            else:
+                full = st.load_epoch(trip)
+                assert full == steps
+                st.run_steps(2)
+                st.run_steps()
+                st(trip[full * batch:, :2], trip[full * batch:, 2].to(torch.float64))      # ragged remainder: eager
+        ops.check_status(dev)
+        return m.embeddings.embeds.detach().clone(), m.scale.detach().clone(), st.loss.clone()
+
+    a, b_ = run("calls"), run("epoch")
+    assert float((a[0] - b_[0]).abs().max()) < 1e-9
+    assert abs(float(a[1] - b_[1])) < 1e-9 and abs(float(a[2] - b_[2])) < 1e-8 * abs(float(a[2]))
+    assert float((a[0] - _toy_model("upper", "riem", n, nodes, dev).embeddings.embeds.detach()).abs().max()) > 1e-4

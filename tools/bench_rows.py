@@ -255,8 +255,11 @@ def train_row(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=
                        torch.randint(1, 9, (batch * k_epoch,), generator=g)), 1).to(dev)
     two = model != "spd" and n <= 6
     step = GraphedTrainStep(net, opt, batch, 50.0, dev, two_kernels=two, deterministic=True if two else False, accumulate_loss=two)
-    if step.mode == "two_kernels":
-        form = "two kernels per step, batches addressed by a device step counter, deterministic accumulation (load_epoch + run_steps)"
+    if step.mode == "two_kernels" or step._classic_windowed():
+        form = ("two kernels per step, batches addressed by a device step counter, deterministic accumulation (load_epoch + run_steps)"
+                if step.mode == "two_kernels" else
+                "one replayed hipGraph per step (loss + split backward, norms, clip, RiemannianSGD), batches addressed by a device step "
+                "counter (load_epoch + run_steps)")
 
         def run():
             step.load_epoch(big[:batch * steps])

@@ -3,6 +3,7 @@
 RiemannianSGD step on the table and the scale) as hipGraph replays (sympa_amd/train_step.py), on the BASELINE.json
 workloads, every form the step exists in:
    classic         round 2's graph (zero, fused loss+backward, norms, RSGD, scale step), the batch copied in per step
+   classic, epoch  the same graph with the batches addressed by the device step counter (round 6: Siegel models), nothing copied per step
    2k, copy        two kernels per step (train_backward + rsgd_step_fused), the batch copied in per step
    2k, epoch       two kernels per step, batches addressed by the device step counter: K replays, nothing in between
    2k, epoch, det  the same with per-pair rows + segmented sum + fixed-order scalar sums (bitwise reproducible)
@@ -55,7 +56,7 @@ for name, manifold, metric, n, nodes, batch in WORKLOADS:
     if not os.environ.get("NO_BATCH_SORT") and ((manifold == "upper" and n == 8) or (manifold == "spd" and 9 <= n <= 16)):
         trip = data.sort_batches_by_source(trip, batch)
     ids, gd = trip[:batch, :2].contiguous(), trip[:batch, 2].to(torch.float64)
-    for form in ("classic", "2k, copy", "2k, epoch", "2k, epoch, det"):
+    for form in ("classic", "classic, epoch", "2k, copy", "2k, epoch", "2k, epoch, det"):
         m = fresh(manifold, metric, n, nodes)
         if os.environ.get("OPTIM", "rsgd") == "radam":           # train.py:69-70
             if manifold == "spd":
@@ -64,11 +65,13 @@ for name, manifold, metric, n, nodes, batch in WORKLOADS:
         else:
             opt = RiemannianSGD(m.parameters(), lr=1e-4)
         try:
-            step = GraphedTrainStep(m, opt, batch, 50.0, dev, two_kernels=form != "classic", deterministic=form.endswith("det"),
-                                    accumulate_loss=form != "classic")
+            step = GraphedTrainStep(m, opt, batch, 50.0, dev, two_kernels=not form.startswith("classic"), deterministic=form.endswith("det"),
+                                    accumulate_loss=not form.startswith("classic"))
         except ValueError:
             continue
-        if form != "classic" and step.mode != "two_kernels":
+        if not form.startswith("classic") and step.mode != "two_kernels":
+            continue
+        if form == "classic, epoch" and not step._classic_windowed():
             continue
         if "epoch" in form:
             def run(k):
