@@ -946,11 +946,12 @@ def main():
             t_sec = time.perf_counter()
             rec["secondary"] = bench_rows.secondary_rows(dev, args.seed, steps=min(args.steps, 20), budget_s=args.secondary_budget,
                                                          log=lambda s_: sys.stderr.write(s_ + "\n"))
-            rec["secondary_seconds"] = time.perf_counter() - t_sec
+            rec["secondary_seconds"] = round(time.perf_counter() - t_sec, 1)
+            rec["secondary_legend"] = bench_rows.LEGEND
             bad_rows = [r for r in rec["secondary"] if "parity" in r and not r["parity"]["ok"]]
             if bad_rows:
                 sys.stderr.write("bench.py: secondary rows with a parity failure: " + ", ".join(
-                    f"{r['workload']}/{r['kind']}/{r.get('form', '')[:6]}" for r in bad_rows) + "\n")
+                    f"{r['workload']}/{r['kind']}/{r.get('form', '')}" for r in bad_rows) + "\n")
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -39,6 +39,33 @@ def bytes_per_pair(n, model):
     return 2 * 8 + 2 * ((1 if model == "spd" else 2) * n * n * 8) + 8
 
 
+def _r(x, digits=5):
+    """floats of the rows to five significant digits: the rows ride in bench.py's ONE JSON line"""
+    return float(f"{x:.{digits}g}") if x is not None and x == x and abs(x) != float("inf") else x
+
+
+LEGEND = {
+    "forms": {"list": "Model.forward_batches(Model.prepare_batches(K batches)): the loop of Runner.evaluate (runner.py:124-135) as one call",
+              "single": "Model.forward(batch) under no_grad, once per step: the call the reference makes (model.py:16-30)",
+              "training_step": "sympa_amd.train_step.GraphedTrainStep: runner.py:98-118 as replayed hipGraphs (RiemannianSGD, max_grad_norm "
+                               "50; headline: two kernels per step, deterministic accumulation; dims >= 7 / spd: one graph per step); "
+                               "batches addressed by the device step counter where `windowed` is true"},
+    "ms_per_step": "wall clock: synchronize, K steps, synchronize; median of 5",
+    "device_us_per_step": "HIP events around back-to-back repetitions (>= 64 launches per group): every kernel of a step, the pack's "
+                          "validity check included where a packed table is used",
+    "roofline.frac": "SURVEY 8d algorithmic bytes per pair x pairs per step / device_us_per_step / 8 TB/s (training: two points read, two "
+                     "gradient rows read-modify-written, ids + graph distance); frac_whole_job: the same with ms_per_step",
+    "parity": "forward: the timed code's own output of batch 0 against oracle/siegel_oracle.py on a sample, relative, tol 1e-4.  training: "
+              "the table gradient and the loss of the fused loss + backward kernels on 2 048 pairs of 400 rows against torch autograd of "
+              "AverageDistortionLoss through the oracle (relative to the largest gradient entry); checker_noise_floor = the asymmetry "
+              "of the oracle's own gradient; vs_svd_formulation = the same gradient against autograd through svdvals of "
+              "L1^-1 (Z2 - Z1) L2^-T, a well-conditioned formulation that is not the reference's chain and adjudicates the few pairs per "
+              "thousand on which the reference's 2n x 2n symeig backward is off by 1e-5 .. 5e-5",
+    "packed_table": "pack_us = digest + unconditional pack (table changed); validity_check_us = digest + a pack kernel that returns at "
+                    "once (table unchanged: part of every `single` step that uses the pack and of every `list` call)",
+}
+
+
 def _median(xs):
     xs = sorted(xs)
     return xs[(len(xs) - 1) // 2]
@@ -104,7 +131,7 @@ def _parity(got, want):
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
     ok = bool(torch.isfinite(got).all())
     rel = float(((got - want).abs() / want.abs().clamp_min(1e-9)).max()) if ok else float("inf")
-    return {"pairs": int(got.numel()), "max_rel_err": rel, "tol": 1e-4, "ok": bool(ok and rel <= 1e-4)}
+    return {"pairs": int(got.numel()), "max_rel_err": _r(rel), "ok": bool(ok and rel <= 1e-4)}
 
 
 def forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=None):
@@ -140,17 +167,11 @@ def forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, table_c
             # (single calls of the upper model stay on the dense kernel while the pack's validity check is on: sympa_amd/model.py)
             packed_now = pk is not None and pk.key is not None and batch * (steps if form == "list" else 1) >= 4096 and \
                 (form == "list" or model != "upper" or not pk.strict)
-            row = {"workload": name, "kind": "forward", "form": form,
-                   "api": ("Model.forward_batches(Model.prepare_batches(K batches))" if form == "list"
-                           else "Model.forward(batch) under no_grad, once per step"),
-                   "config": {"manifold": model, "dist_metric": metric, "dims": n, "nodes": nodes, "pairs_per_step": batch},
-                   "steps": steps, "ms_per_step": ms, "device_us_per_step": dev_us,
-                   "value": batch / (ms * 1e-3), "unit": "pairs/s",
-                   "roofline": {"bound": "hbm", "algorithmic_bytes_per_pair": bpp, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                "achieved": bpp * batch / (dev_us * 1e-6) / 1e9, "frac": bpp * batch / (dev_us * 1e-6) / HBM_PEAK,
-                                "frac_whole_job": bpp * batch / (ms * 1e-3) / HBM_PEAK},
-                   "packed_table_in_use": bool(packed_now),
-                   "parity": _parity(out0[:sample], want)}
+            row = {"workload": name, "kind": "forward", "form": form, "steps": steps, "pairs_per_step": batch,
+                   "ms_per_step": _r(ms), "device_us_per_step": _r(dev_us), "value": _r(batch / (ms * 1e-3)),
+                   "roofline": {"bytes_per_pair": bpp, "frac": _r(bpp * batch / (dev_us * 1e-6) / HBM_PEAK),
+                                "frac_whole_job": _r(bpp * batch / (ms * 1e-3) / HBM_PEAK)},
+                   "packed": bool(packed_now), "parity": _parity(out0[:sample], want)}
             rows.append(row)
         if pk is not None and pk.key is not None:
             def repack():
@@ -162,10 +183,7 @@ def forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, table_c
                 pk.ensure(net.embeddings.embeds, strict=True)
             _, check_us = _time(check, dev, 1, 2)
             for r in rows:
-                r["packed_table"] = {"pack_us": pack_us, "validity_check_us": check_us, "device_repacks": pk.device_repacks(),
-                                     "note": "pack_us = digest + unconditional pack (table changed); validity_check_us = digest + "
-                                             "a pack kernel that returns at once (table unchanged: part of every `single` step and of "
-                                             "every `list` call)"}
+                r["packed_table"] = {"pack_us": _r(pack_us), "validity_check_us": _r(check_us)}
     del net, plan
     return rows
 
@@ -237,15 +255,9 @@ def train_row(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=
     if model == "upper":
         alt = _adjudicator_grad(metric, small, trip[:, :2], trip[:, 2].to(torch.float64))
         adj = float((got_g - alt).abs().max() / alt.abs().max().clamp_min(1e-300))
-    parity = {"pairs": sample, "max_rel_err": max(rel, lrel), "grad_max_rel_err": rel, "loss_rel_err": lrel, "tol": 1e-4,
-              "checker_noise_floor": noise, "grad_max_rel_err_vs_svd_formulation": adj,
-              "ok": bool(max(rel, lrel) <= 1e-4),
-              "against": "torch autograd of AverageDistortionLoss through oracle/siegel_oracle.py on the same rows and pairs "
-                         "(error relative to the largest gradient entry; checker_noise_floor = the asymmetry of the oracle's own "
-                         "gradient of the symmetric rows: its 2n x 2n symeig backward divides by eigenvalue gaps; "
-                         "grad_max_rel_err_vs_svd_formulation = the same gradient against autograd through svdvals of "
-                         "L1^-1 (Z2 - Z1) L2^-T, a well-conditioned formulation that is not the reference's chain: it adjudicates the few "
-                         "pairs per thousand on which the reference's own autograd is off by 1e-5 .. 5e-5)"}
+    parity = {"pairs": sample, "max_rel_err": _r(max(rel, lrel)), "grad_max_rel_err": _r(rel), "loss_rel_err": _r(lrel),
+              "checker_noise_floor": _r(noise), "vs_svd_formulation": _r(adj),
+              "ok": bool(max(rel, lrel) <= 1e-4)}
     del net
     # ---- the timed step
     net = _net(model, metric, n, nodes, table_cpu, dev, train_scale=True)
@@ -255,11 +267,8 @@ def train_row(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=
                        torch.randint(1, 9, (batch * k_epoch,), generator=g)), 1).to(dev)
     two = model != "spd" and n <= 6
     step = GraphedTrainStep(net, opt, batch, 50.0, dev, two_kernels=two, deterministic=True if two else False, accumulate_loss=two)
-    if step.mode == "two_kernels" or step._classic_windowed():
-        form = ("two kernels per step, batches addressed by a device step counter, deterministic accumulation (load_epoch + run_steps)"
-                if step.mode == "two_kernels" else
-                "one replayed hipGraph per step (loss + split backward, norms, clip, RiemannianSGD), batches addressed by a device step "
-                "counter (load_epoch + run_steps)")
+    windowed = step.mode == "two_kernels" or step._classic_windowed()
+    if windowed:
 
         def run():
             step.load_epoch(big[:batch * steps])
@@ -288,7 +297,6 @@ def train_row(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=
             evs.append(a.elapsed_time(b))
         ms, dev_us = _median(wall) / steps * 1e3, _median(evs) / steps * 1e3
     else:
-        form = "one replayed hipGraph per step (loss + backward, norms, clip, RiemannianSGD), the batch copied in per step"
         if (model == "upper" and n == 8) or (model == "spd" and 9 <= n <= 16):
             big = data.sort_batches_by_source(big, batch)       # what the data pipeline does per epoch (sympa_amd/data.py)
         ids = [big[j * batch:(j + 1) * batch, :2].contiguous() for j in range(4)]
@@ -306,14 +314,9 @@ def train_row(name, model, metric, n, nodes, batch, dev, seed, steps, table_cpu=
     # graph distance and nothing else: 3 x the forward's point bytes + 32
     planes = 1 if model == "spd" else 2
     bpp = 3 * 8 + 2 * (planes * n * n * 8) + 2 * 2 * (planes * n * n * 8)
-    return {"workload": name, "kind": "training_step", "form": form,
-            "api": "sympa_amd.train_step.GraphedTrainStep (runner.py:98-118 as replayed hipGraphs)",
-            "config": {"manifold": model, "dist_metric": metric, "dims": n, "nodes": nodes, "pairs_per_step": batch,
-                       "optimizer": "RiemannianSGD", "max_grad_norm": 50.0},
-            "steps": steps, "ms_per_step": ms, "device_us_per_step": dev_us, "value": batch / (ms * 1e-3), "unit": "pairs/s trained",
-            "roofline": {"bound": "hbm", "algorithmic_bytes_per_pair": bpp, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "achieved": bpp * batch / (dev_us * 1e-6) / 1e9, "frac": bpp * batch / (dev_us * 1e-6) / HBM_PEAK,
-                         "note": "per pair: two points read, two gradient rows read-modify-written, ids + graph distance"},
+    return {"workload": name, "kind": "training_step", "form": "training_step", "windowed": bool(windowed), "steps": steps,
+            "pairs_per_step": batch, "ms_per_step": _r(ms), "device_us_per_step": _r(dev_us), "value": _r(batch / (ms * 1e-3)),
+            "roofline": {"bytes_per_pair": bpp, "frac": _r(bpp * batch / (dev_us * 1e-6) / HBM_PEAK)},
             "parity": parity}
 
 
