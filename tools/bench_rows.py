@@ -52,7 +52,8 @@ LEGEND = {
                                "batches addressed by the device step counter where `windowed` is true"},
     "ms_per_step": "wall clock: synchronize, K steps, synchronize; median of 5",
     "device_us_per_step": "HIP events around back-to-back repetitions (>= 64 launches per group): every kernel of a step, the pack's "
-                          "validity check included where a packed table is used",
+                          "validity check included where a packed table is used; kernel_avg_us = the same per launch of the pair "
+                          "kernel (a list of K <= 32 Siegel batches is ONE launch)",
     "roofline.frac": "SURVEY 8d algorithmic bytes per pair x pairs per step / device_us_per_step / 8 TB/s (training: two points read, two "
                      "gradient rows read-modify-written, ids + graph distance); frac_whole_job: the same with ms_per_step",
     "parity": "forward: the timed code's own output of batch 0 against oracle/siegel_oracle.py on a sample, relative, tol 1e-4.  training: "
@@ -168,7 +169,8 @@ def forward_rows(name, model, metric, n, nodes, batch, dev, seed, steps, table_c
             packed_now = pk is not None and pk.key is not None and batch * (steps if form == "list" else 1) >= 4096 and \
                 (form == "list" or model != "upper" or not pk.strict)
             row = {"workload": name, "kind": "forward", "form": form, "steps": steps, "pairs_per_step": batch,
-                   "ms_per_step": _r(ms), "device_us_per_step": _r(dev_us), "value": _r(batch / (ms * 1e-3)),
+                   "ms_per_step": _r(ms), "device_us_per_step": _r(dev_us), "kernel_avg_us": _r(dev_us * steps / launches),
+                   "value": _r(batch / (ms * 1e-3)),
                    "roofline": {"bytes_per_pair": bpp, "frac": _r(bpp * batch / (dev_us * 1e-6) / HBM_PEAK),
                                 "frac_whole_job": _r(bpp * batch / (ms * 1e-3) / HBM_PEAK)},
                    "packed": bool(packed_now), "parity": _parity(out0[:sample], want)}
