@@ -432,8 +432,10 @@ class PackedTable:
             ev = torch.cuda.Event()
             ev.record(self._stream)
             cur.wait_event(ev)
+        # (inside a capture the recorded launch must not bake "changed" in: every replay would repack; the digest decides there --
+        # the pack depends on the table's bytes alone, so equal bytes under a moved key need no repack either)
         with torch.cuda.device(table.device):
-            rc = self._refresh(lib, table, need, fresh or not same, cur.cuda_stream)
+            rc = self._refresh(lib, table, need, (fresh or not same) and not capturing, cur.cuda_stream)
         _lib.check(rc)
         self.refreshes += 1
         if not capturing:          # (a capture runs nothing: the key keeps describing what really is in the buffer)
